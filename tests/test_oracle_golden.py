@@ -1,0 +1,131 @@
+"""Pins the CPU oracle against every known-answer the reference holds for the hot path.
+Citations are relative to /root/reference (not read at run time: the vectors are restated here as data)."""
+import math
+
+import numpy as np
+import pytest
+
+
+def test_clustersolutions_reference_unit_vector(oracle):
+    # test/test_cluster_unit.jl:36-54: clustersolutions([f1, f2], true) with 4x2 factors (columns = signals).
+    # Our entry point takes k x m matrices and transposes like clusterWmatrix=false does (Clus:426-428).
+    f1 = np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 0.0], [0.0, 1.0]])
+    f2 = np.array([[0.0, 1.0], [1.0, 0.0], [0.0, 1.0], [1.0, 0.0]])
+    for tb in (32, 64):
+        labels, centers = oracle.clustersolutions([f1.T, f2.T], tbits=tb)
+        assert labels.shape == (2, 2)
+        assert labels[:, 0].tolist() == [1, 2]
+        assert sorted(labels[:, 1].tolist()) == [1, 2]
+        assert centers.shape == (2, 4)
+        # hand trace of Clus:464-516
+        assert labels.tolist() == [[1, 2], [2, 1]]
+        np.testing.assert_allclose(centers, [[1, 0, 1, 0], [0, 1, 0, 1]])
+    lab_np, cen_np = oracle.clustersolutions_np([f1.T, f2.T])
+    assert lab_np.tolist() == [[1, 2], [2, 1]]
+
+
+def test_zerostoepsilon_reference_vector(oracle):
+    # test/test_normalize.jl:44-55
+    x = np.array([0.0, -1.0, 1e-20, 1.0])
+    y = oracle.zerostoepsilon(x)
+    e = np.finfo(np.float64).eps ** 2
+    assert np.all(y >= e)
+    assert y[2] == 1e-20 and y[3] == 1.0
+    assert x[0] == 0.0  # copy, not in place
+    assert oracle.zerostoepsilon(np.float32([0, 1]))[0] == np.float32(np.finfo(np.float32).eps) ** 2
+
+
+def test_ssqrnan_normnan(oracle):
+    # src/NMFkHelpers.jl:222-228 (NaN entries are skipped); test/test_helpers.jl:60-67 family
+    x = np.array([[3.0, np.nan], [4.0, np.nan]])
+    assert oracle.ssqrnan(x) == 25.0
+    assert oracle.normnan(x) == 5.0
+
+
+def test_getk_rules(oracle):
+    # src/NMFkPostprocess.jl:7-41
+    assert oracle.getk(range(2, 6), [0.99, 0.85, -0.57, -0.67]) == 3  # Readme.md:127-134
+    assert oracle.getk(range(2, 6), [0.9940184, 0.7097371, 0.3770708, -0.5794082]) == 3  # BSS notebook :258-264
+    assert oracle.getk(range(2, 5), [0.1, 0.2, 0.3]) is None
+    assert oracle.getk(range(2, 5), [0.1, 0.2, 0.3], strict=False) == 4
+    assert oracle.getk(range(2, 5), [np.nan] * 3) == 0
+    assert oracle.getk([3], [0.6]) == 3
+    assert oracle.getk([3], [0.4]) is None
+    assert oracle.getk([3], [0.4], strict=False) == 3
+    assert oracle.getk(range(2, 5), [0.6, 0.5, 0.7]) == 4  # strictly greater than the cutoff; LAST such k
+    # robustness given as the full 1-based vector (Exec:225 passes robustness[nkrange])
+    assert oracle.getk(range(2, 4), [-1, 0.9, 0.2]) == 2
+
+
+def test_execute_singlerun_smoke_invariants(oracle):
+    # test/test_execute_smoke.jl:6-20: X = abs.(randn(5,4)), k=2, maxiter=50, tol=1e-8
+    rng = np.random.default_rng(123)
+    X = np.abs(rng.standard_normal((5, 4)))
+    W0, H0 = oracle.init_factors(123, 5, 4, 2)
+    r = oracle.singlerun(X, 2, W0, H0, maxiter=50, tol=1e-8)
+    W, H = r["W"], r["H"]
+    assert W.shape == (5, 2) and H.shape == (2, 4)
+    assert math.isfinite(r["objvalue"]) and np.isfinite(W).all() and np.isfinite(H).all()
+    assert (W >= 0).all() and (H >= 0).all()
+    np.testing.assert_allclose(H.sum(axis=1), 1.0, atol=1e-4)
+    assert r["iters"] == 50 and r["reason"] == oracle.STOP_MAXITER
+
+
+def test_execute_run_nk1(oracle):
+    # test/test_execute_smoke.jl:22-32: nk=1 => minsilhouette == 1, finite phi and AIC
+    rng = np.random.default_rng(321)
+    X = np.abs(rng.standard_normal((6, 5)))
+    inits = [oracle.init_factors(s, 6, 5, 1) for s in (1, 2)]
+    r = oracle.execute_run(X, 1, 2, inits, maxiter=40, tol=1e-8)
+    assert r["Wa"].shape == (6, 1) and r["Ha"].shape == (1, 5)
+    assert math.isfinite(r["phi"]) and math.isfinite(r["aic"])
+    assert r["minsilhouette"] == 1
+
+
+def test_negative_entries_rejected(oracle):
+    # src/NMFkMultiplicative.jl:4-7
+    X = np.ones((4, 3))
+    X[1, 1] = -0.5
+    W0, H0 = oracle.init_factors(1, 4, 3, 2)
+    with pytest.raises(ValueError, match="All matrix entries must be nonnegative!"):
+        oracle.multiplicative(X, 2, W0, H0)
+
+
+def test_bss_notebook_known_answers(oracle, bss_X):
+    """notebooks/blind_source_separation/blind_source_separation.md:161-181 (X), :219-264 (results).
+
+    The notebook predates the switch of the reported fit from sum-of-squares to the Frobenius norm
+    (src/NMFkExecute.jl:791-792 today): its k=2 'Fit 13.93858' over ten runs spans
+    [13.938575834075827, 13.939149136011867] and equals phi^2 of the current code; its AIC
+    -46.21209 = 2(15*2+2*5) + 75*log(13.93858/75).  The k=2 optimum is unique enough that any correct
+    restatement of the KL multiplicative updates + stop rule must land inside that interval."""
+    X = bss_X
+    W, H, fit, rob, aic, kopt, det = oracle.execute(X, range(2, 6), 10, seed=2021)
+    assert kopt == 3  # :263
+    sse2 = float(fit[1]) ** 2
+    assert 13.9385 <= sse2 <= 13.9392
+    obj2 = np.sort(det[2]["objvalue"].astype(np.float64) ** 2)
+    assert obj2[0] >= 13.9385 and obj2[-1] <= 13.9392  # 'OF: min ... max ...' line, :221
+    aic_notebook_convention = 2 * (15 * 2 + 2 * 5) + 75 * math.log(sse2 / 75)
+    assert abs(aic_notebook_convention - (-46.21209)) < 5e-3  # X is only printed to 6 s.f.
+    assert abs(rob[1] - 0.9940184) < 5e-3  # k=2 silhouette, :258
+    assert rob[2] > 0.5 and rob[4] < 0  # k=3 robust, k=5 not (:259-261; examples/bss.jl:20-21 criterion)
+    # every run stops by the stagnation rule well before maxiter on this toy (240-730 iterations)
+    for nk in range(2, 6):
+        assert all(r == oracle.STOP_STAGNATION for r in det[nk]["reasons"])
+        assert all(100 <= it <= 2000 and it % 10 == 0 for it in det[nk]["iters"])
+        assert (H[nk] >= 0).all() and (W[nk] >= 0).all()
+    # signals ordered by contribution (Post:148-158)
+    for nk in range(2, 6):
+        s = W[nk].sum(axis=0) * H[nk].sum(axis=1)
+        assert np.all(np.diff(s) <= 1e-12)
+
+
+def test_readme_construction_kopt(oracle):
+    # Readme.md:97-134: X = [a+3c, 10a+b, b, 5b+c, a+2b+5c], k=2:5 => kopt 3
+    u = oracle.uniform_fill(7, 0, 45).reshape(3, 15)
+    a, b, c = u
+    X = np.stack([a + 3 * c, 10 * a + b, b, 5 * b + c, a + 2 * b + 5 * c], axis=1)
+    W, H, fit, rob, aic, kopt, det = oracle.execute(X, range(2, 6), 10, seed=11)
+    assert kopt == 3
+    assert rob[1] > 0.9 and rob[2] > 0.5 and rob[3] < 0.5

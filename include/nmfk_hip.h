@@ -1,0 +1,151 @@
+/*
+ * nmfk_hip.h -- C ABI of libnmfk_hip.so: the MI355X (gfx950) implementation of the NMFk.jl
+ * `execute(X, krange, nNMF; method=:simple)` hot path.
+ *
+ * The reference (pure Julia, /root/reference) has no FFI for this path; the seam is the Julia function
+ * signature.  Each entry point below names the reference function(s) it replaces (file:line relative to
+ * the reference root) -- a Julia maintainer binds them with `ccall` (INTEGRATION.md shows the stub), the
+ * tests bind them with ctypes.
+ *
+ * Conventions
+ *  - All matrices are COLUMN-MAJOR (Julia native), float32 on the boundary (T = Float32, the BASELINE dtype).
+ *  - Every bulk pointer may be a host pointer or a HIP device pointer; the library copies with
+ *    hipMemcpyDefault into/out of its own HBM workspace and never retains a caller pointer after return.
+ *  - Every function returns an nmfk_status (0 = ok).  No C++ exception crosses the boundary;
+ *    nmfk_last_error() gives the message of the last failure on the calling thread.
+ *  - A context is bound to one GPU and is not re-entrant.  Multi-GPU = one process (and one context) per
+ *    GPU; the (k, restart) work list is sharded by the host layer.
+ */
+#ifndef NMFK_HIP_H
+#define NMFK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nmfk_ctx nmfk_ctx;
+
+typedef enum {
+  NMFK_OK = 0,
+  NMFK_ERR_BAD_ARG = 1,      /* null pointer, zero dimension (Exec:242-244), size mismatch (Mult:40,50)       */
+  NMFK_ERR_NEGATIVE = 2,     /* "All matrix entries must be nonnegative!" (Mult:4-7)                          */
+  NMFK_ERR_NAN_INIT = 3,     /* "Initial values for the W/H matrix entries include NaNs!" (Mult:42-44,52-54)  */
+  NMFK_ERR_NO_X = 4,         /* nmfk_set_X has not been called                                                */
+  NMFK_ERR_HIP = 5,          /* a HIP runtime call failed                                                      */
+  NMFK_ERR_UNSUPPORTED = 6,  /* k > NMFK_MAX_K                                                                 */
+  NMFK_ERR_NO_DEVICE = 7     /* no usable gfx950 device: the library has NO CPU fallback                      */
+} nmfk_status;
+
+enum { NMFK_MAX_K = 64 };
+
+/* why a restart left the MU loop (Mult:64, 75-78, 112-115) */
+enum { NMFK_STOP_MAXITER = 1, NMFK_STOP_STAGNATION = 2, NMFK_STOP_TOL = 3, NMFK_STOP_CONSISTENCY = 4 };
+
+/* arithmetic of the inner loop */
+enum {
+  NMFK_COMPUTE_F32 = 0, /* W, H, W*H in fp32; column/row sums and the objective accumulated in fp64 (default) */
+  NMFK_COMPUTE_F64 = 1  /* everything in fp64, like the reference's default path (Mult:38,48): validation    */
+};
+
+/* keyword arguments of NMFmultiplicative (Mult:24) as forwarded by execute_singlerun_compute (Exec:729,762) */
+typedef struct {
+  double tol;            /* 1e-19  (Exec:729)  objective < tol => stop                                        */
+  double tolOF;          /* 1e-3   (Mult:24)   absolute SSE improvement per 10 iterations                    */
+  double lambda;         /* 1e-32  (Mult:24)   replacement of zeros / first-iteration value of missing data  */
+  double weight;         /* 1      (Mult:24)   scalar weight of the monitored objective (Mult:74)            */
+  int64_t maxiter;       /* 10000  (Exec:729)                                                                 */
+  int32_t maxreattempts; /* 2      (Mult:24)                                                                  */
+  int32_t maxbaditers;   /* 10     (Mult:24)                                                                  */
+  int32_t stopconv;      /* 1000   (Mult:24)                                                                  */
+  int32_t Wfixed;        /* 0      (Mult:24,69)                                                               */
+  int32_t Hfixed;        /* 0      (Mult:24,66)                                                               */
+  int32_t normalize;     /* 1      modifymatrices (Exec:486-489, 795-805): rows of H sum to 1, W rescaled    */
+  int32_t compute;       /* NMFK_COMPUTE_F32                                                                  */
+  int32_t reserved;
+} nmfk_mu_params;
+
+/* library / device ---------------------------------------------------------------------------------------- */
+int nmfk_version(void);
+const char *nmfk_last_error(void);
+int nmfk_device_count(int *count);
+/* Creates a context on GPU `device`.  Fails with NMFK_ERR_NO_DEVICE when there is none. */
+int nmfk_create(int device, nmfk_ctx **out);
+int nmfk_destroy(nmfk_ctx *ctx);
+int nmfk_device_info(nmfk_ctx *ctx, char *name, int name_len, int *compute_units, int64_t *hbm_bytes);
+/* Fills *p with the reference defaults listed above. */
+int nmfk_mu_default_params(nmfk_mu_params *p);
+
+/* data ---------------------------------------------------------------------------------------------------- */
+/* Replaces NMFpreprocessing! (Mult:3-22) + the implicit capture of X by execute_singlerun (Exec:535-541).
+ * X: n x m, leading dimension ldx >= n.  NaN = missing.  Entries <= 0 become lambda in the device copy (the
+ * caller's array is never modified, so nothing has to be restored as in Mult:123-124).  Keeps two HBM
+ * copies: column-major (W half-step, objective) and row-major (H half-step).
+ * nan_count / zero_count (optional) receive count(isnan, X) and count(X .<= 0). */
+int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, int64_t ldx, double lambda, int64_t *nan_count,
+               int64_t *zero_count);
+
+/* Portable counter-based U(0,1) generator standing in for Julia's rand (Mult:38,48); bit-identical to the
+ * oracle's (oracle/nmfk_oracle.c).  out[i] = u(seed, offset + i), i < count. */
+int nmfk_fill_uniform(nmfk_ctx *ctx, uint64_t seed, uint64_t offset, int64_t count, float *out);
+
+/* multiplicative updates ------------------------------------------------------------------------------------ */
+/* Replaces the restart loop of execute_run (Exec:527-543) around execute_singlerun_compute(:simple)
+ * (Exec:729-807) around NMFmultiplicative (Mult:24-127), for ALL ranks of a sweep at once (the reference's
+ * `for nk in nkrange` at Exec:203 is serial; here every (k, restart) pair is one unit of a flat work list).
+ *
+ *  nk, ks[nk]        ranks to factorize (1 <= k <= NMFK_MAX_K)
+ *  nruns             restarts per rank
+ *  Winit[q], Hinit[q]  q < nk: nruns stacked n x ks[q] / ks[q] x m initial factors, or NULL (also the arrays
+ *                    themselves may be NULL) => generated on the device from seeds (W first, then H, Mult:38,48)
+ *  seeds[q*nruns+r]  seed of restart r of rank ks[q]; required where inits are NULL
+ *  W_out[q]          nruns stacked n x ks[q]   (after the Exec:801-803 normalisation when params->normalize)
+ *  H_out[q]          nruns stacked ks[q] x m
+ *  frob_out[q]       nruns: objvalue = normnan(X - W*H) (Exec:791-792), rounded to T like objvalue::Vector{T}
+ *  sse_out[q]        nruns: sum(((X-W*H).*weight)[.!inan].^2) (Mult:125)            (optional: NULL)
+ *  iters_out[q]      nruns: iterations executed                                      (optional)
+ *  reason_out[q]     nruns: NMFK_STOP_*                                              (optional)
+ */
+int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nruns, const float *const *Winit,
+                  const float *const *Hinit, const uint64_t *seeds, const nmfk_mu_params *params, float *const *W_out,
+                  float *const *H_out, float *const *frob_out, double *const *sse_out, int32_t *const *iters_out,
+                  int32_t *const *reason_out);
+
+/* One rank: the body of execute_run's restart loop (Exec:527-543).  Same arguments, without the outer arrays. */
+int nmfk_mu_batch(nmfk_ctx *ctx, int k, int nruns, const float *Winit, const float *Hinit, const uint64_t *seeds,
+                  const nmfk_mu_params *params, float *W_out, float *H_out, float *frob_out, double *sse_out,
+                  int32_t *iters_out, int32_t *reason_out);
+
+/* robustness ------------------------------------------------------------------------------------------------ */
+/* Replaces clustersolutions(HBig[idxsort][idxsol], false) (Clus:425-517, call site Exec:623) and the
+ * silhouette part of finalize(W, H, idx, false) (Fin:36-66, call site Exec:637), in T = Float32 as the
+ * reference does for Float32 X (Clus:463).
+ *  Hstack     nsol stacked k x m solutions, ALREADY sorted by objective and filtered by the caller
+ *  labels     k x nsol, 1-based cluster of signal a of solution t (labels[:,1] = 1:k)
+ *  centroids  k x m   (running sums / nsol, Clus:512-516)
+ *  point_sil  k x nsol silhouettes (NaN -> 0, Fin:58)
+ *  cluster_sil k      mean silhouette per cluster (Fin:66); robustness = minimum (Exec:638) is the caller's */
+int nmfk_cluster_silhouette(nmfk_ctx *ctx, int k, int nsol, int64_t m, const float *Hstack, int32_t *labels,
+                            float *centroids, float *point_sil, float *cluster_sil);
+
+/* Cluster means and corrected variances of W and H (Fin:64-77; used when best=false, Exec:655-658).
+ *  Wstack nsol x (n x k), Hstack nsol x (k x m), labels k x nsol  ->  Wmean, Wvar (n x k), Hmean, Hvar (k x m) */
+int nmfk_cluster_stats(nmfk_ctx *ctx, int k, int nsol, int64_t n, int64_t m, const float *Wstack, const float *Hstack,
+                       const int32_t *labels, float *Wmean, float *Hmean, float *Wvar, float *Hvar);
+
+/* normnan(X - W*H) with NaN -> skipped (Help:226-228): the re-checks at Exec:603, 664-667 and 212-222. */
+int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float *H, double *out);
+
+/* measurement ----------------------------------------------------------------------------------------------- */
+/* HIP-event timing of the MU kernels on the stream they are launched on (bench.py's roofline leg).
+ * After a sweep with profiling enabled: names[i] / total_ms[i] / launches[i] / flops[i] for i < *count
+ * (flops = algorithmic 4*n*m*k per half-step per ACTIVE restart, summed over the launches). */
+int nmfk_set_profiling(nmfk_ctx *ctx, int enabled);
+int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *total_ms, int64_t *launches,
+                     double *flops, int *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

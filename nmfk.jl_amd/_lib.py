@@ -1,0 +1,258 @@
+"""ctypes binding of libnmfk_hip.so (include/nmfk_hip.h).  There is NO CPU fallback: every entry point needs
+the HIP library and a gfx950 GPU, and fails loudly otherwise."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnmfk_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nmfk_hip.h")
+
+NMFK_OK = 0
+ERR_BAD_ARG, ERR_NEGATIVE, ERR_NAN_INIT, ERR_NO_X, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = 1, 2, 3, 4, 5, 6, 7
+STOP_MAXITER, STOP_STAGNATION, STOP_TOL, STOP_CONSISTENCY = 1, 2, 3, 4
+COMPUTE_F32, COMPUTE_F64 = 0, 1
+MAX_K = 64
+
+
+class NMFkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class MuParams(C.Structure):
+    """nmfk_mu_params (include/nmfk_hip.h): keyword arguments of NMFmultiplicative, src/NMFkMultiplicative.jl:24."""
+    _fields_ = [("tol", C.c_double), ("tolOF", C.c_double), ("lambda_", C.c_double), ("weight", C.c_double),
+                ("maxiter", C.c_int64), ("maxreattempts", C.c_int32), ("maxbaditers", C.c_int32),
+                ("stopconv", C.c_int32), ("Wfixed", C.c_int32), ("Hfixed", C.c_int32), ("normalize", C.c_int32),
+                ("compute", C.c_int32), ("reserved", C.c_int32)]
+
+
+def build(force=False, verbose=False):
+    """Compile libnmfk_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-j4"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("building libnmfk_hip.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (symbols only: no GPU is touched until a context is created)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NMFkError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                       "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, fp, dp, ip, i64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)
+    L.nmfk_version.restype = C.c_int
+    L.nmfk_last_error.restype = C.c_char_p
+    L.nmfk_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.nmfk_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.nmfk_destroy.argtypes = [vp]
+    L.nmfk_device_info.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), i64p]
+    L.nmfk_mu_default_params.argtypes = [C.POINTER(MuParams)]
+    L.nmfk_set_X.argtypes = [vp, fp, C.c_int64, C.c_int64, C.c_int64, C.c_double, i64p, i64p]
+    L.nmfk_fill_uniform.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64, fp]
+    pp = C.POINTER(C.c_void_p)
+    L.nmfk_mu_sweep.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.c_int, pp, pp, C.POINTER(C.c_uint64),
+                                C.POINTER(MuParams), pp, pp, pp, pp, pp, pp]
+    L.nmfk_mu_batch.argtypes = [vp, C.c_int, C.c_int, fp, fp, C.POINTER(C.c_uint64), C.POINTER(MuParams), fp, fp, fp,
+                                dp, ip, ip]
+    L.nmfk_cluster_silhouette.argtypes = [vp, C.c_int, C.c_int, C.c_int64, fp, ip, fp, fp, fp]
+    L.nmfk_cluster_stats.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int64, fp, fp, ip, fp, fp, fp, fp]
+    L.nmfk_frobenius.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_double)]
+    L.nmfk_set_profiling.argtypes = [vp, C.c_int]
+    L.nmfk_get_profile.argtypes = [vp, C.c_int, C.c_void_p, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != NMFK_OK:
+        raise NMFkError(rc, lib().nmfk_last_error().decode("utf-8", "replace"))
+
+
+def default_params(**kw):
+    p = MuParams()
+    _check(lib().nmfk_mu_default_params(C.byref(p)))
+    for key, val in kw.items():
+        name = "lambda_" if key in ("lambda", "lambda_") else key
+        if not hasattr(p, name):
+            raise TypeError(f"unknown MU parameter {key!r}")
+        cur = getattr(p, name)
+        setattr(p, name, type(cur)(val) if not isinstance(val, bool) else int(val))
+    return p
+
+
+def device_count():
+    c = C.c_int(0)
+    _check(lib().nmfk_device_count(C.byref(c)))
+    return c.value
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Context:
+    """One GPU (nmfk_ctx).  Arrays cross the boundary as float32 numpy arrays in Julia (column-major) layout:
+    a stack of R matrices n x k is passed as a C-contiguous array of shape (R, k, n)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().nmfk_create(int(device), C.byref(self._h)))
+        self.n = self.m = 0
+        self.nan_count = self.zero_count = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().nmfk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_int(), C.c_int64()
+        _check(lib().nmfk_device_info(self._h, name, 256, C.byref(cus), C.byref(mem)))
+        return dict(name=name.value.decode(), compute_units=cus.value, hbm_bytes=mem.value)
+
+    def set_X(self, X, lambda_=1e-32):
+        """NMFpreprocessing! (Mult:3-22).  X: (n, m) array (any layout); NaN = missing.  The caller's array is
+        not modified."""
+        X = np.asarray(X)
+        if X.ndim != 2:
+            raise NMFkError(ERR_BAD_ARG, "NMFk analysis can be executed for matrices!")  # Exec:110-112
+        Xf = np.asfortranarray(X, dtype=np.float32)
+        n, m = Xf.shape
+        nan, zero = C.c_int64(), C.c_int64()
+        _check(lib().nmfk_set_X(self._h, Xf.ctypes.data, n, m, max(n, 1), float(lambda_), C.byref(nan), C.byref(zero)))
+        self.n, self.m = n, m
+        self.nan_count, self.zero_count = nan.value, zero.value
+        return self
+
+    def fill_uniform(self, seed, offset, count):
+        out = np.empty(count, dtype=np.float32)
+        _check(lib().nmfk_fill_uniform(self._h, C.c_uint64(seed), C.c_uint64(offset), count, out.ctypes.data))
+        return out
+
+    def mu_sweep(self, ks, nruns, seeds=None, Winit=None, Hinit=None, params=None, **kw):
+        """nmfk_mu_sweep.  ks: list of ranks; seeds: (len(ks), nruns) uint64; Winit/Hinit: optional dicts
+        k -> array (nruns, n, k) / (nruns, k, m) in natural (row, col) indexing.
+        Returns dict k -> dict(W (nruns, n, k), H (nruns, k, m), objvalue (nruns,) float32, sse, iters, reason)."""
+        P = params if params is not None else default_params(**kw)
+        ks = [int(k) for k in ks]
+        nk, n, m = len(ks), self.n, self.m
+        arr_k = (C.c_int32 * nk)(*ks)
+        PP = C.c_void_p * nk
+        keep = []
+
+        def table(d, shape_of):
+            t = PP()
+            any_ = False
+            for q, k in enumerate(ks):
+                a = None if d is None else d.get(k)
+                if a is None:
+                    t[q] = None
+                    continue
+                a = np.asarray(a, dtype=np.float32)
+                if a.shape != shape_of(k):
+                    raise NMFkError(ERR_BAD_ARG, f"initial factor for k={k} has shape {a.shape}, expected {shape_of(k)}")
+                # natural (r, row, col) -> stacked column-major: (r, col, row) C-contiguous
+                a = np.ascontiguousarray(np.transpose(a, (0, 2, 1)))
+                keep.append(a)
+                t[q] = a.ctypes.data
+                any_ = True
+            return t if any_ else None
+
+        wi = table(Winit, lambda k: (nruns, n, k))
+        hi = table(Hinit, lambda k: (nruns, k, m))
+        sd = None
+        if seeds is not None:
+            sd_np = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64).reshape(nk, nruns))
+            keep.append(sd_np)
+            sd = sd_np.ctypes.data_as(C.POINTER(C.c_uint64))
+        out = {}
+        tw, th, tf, ts, ti, tr = PP(), PP(), PP(), PP(), PP(), PP()
+        for q, k in enumerate(ks):
+            o = dict(Wt=np.empty((nruns, k, n), dtype=np.float32), Ht=np.empty((nruns, m, k), dtype=np.float32),
+                     objvalue=np.empty(nruns, dtype=np.float32), sse=np.empty(nruns, dtype=np.float64),
+                     iters=np.empty(nruns, dtype=np.int32), reason=np.empty(nruns, dtype=np.int32))
+            out[k] = o
+            tw[q], th[q], tf[q] = o["Wt"].ctypes.data, o["Ht"].ctypes.data, o["objvalue"].ctypes.data
+            ts[q], ti[q], tr[q] = o["sse"].ctypes.data, o["iters"].ctypes.data, o["reason"].ctypes.data
+        _check(lib().nmfk_mu_sweep(self._h, nk, arr_k, int(nruns), wi, hi, sd, C.byref(P), tw, th, tf, ts, ti, tr))
+        for k, o in out.items():
+            o["W"] = np.transpose(o.pop("Wt"), (0, 2, 1))  # views: (nruns, n, k), Fortran-ordered per restart
+            o["H"] = np.transpose(o.pop("Ht"), (0, 2, 1))  # (nruns, k, m)
+        return out
+
+    def cluster_silhouette(self, Hs):
+        """nmfk_cluster_silhouette.  Hs: (nsol, k, m) sorted by objective.  Returns labels (k, nsol) int32 1-based,
+        centroids (k, m), point silhouettes (k, nsol), cluster silhouettes (k,)."""
+        Hs = np.asarray(Hs, dtype=np.float32)
+        nsol, k, m = Hs.shape
+        stack = np.ascontiguousarray(np.transpose(Hs, (0, 2, 1)))  # (nsol, m, k): column-major k x m per solution
+        labels = np.empty((nsol, k), dtype=np.int32)
+        cent = np.empty((m, k), dtype=np.float32)
+        psil = np.empty((nsol, k), dtype=np.float32)
+        csil = np.empty(k, dtype=np.float32)
+        _check(lib().nmfk_cluster_silhouette(self._h, k, nsol, m, stack.ctypes.data, labels.ctypes.data,
+                                             cent.ctypes.data, psil.ctypes.data, csil.ctypes.data))
+        return labels.T, cent.T, psil.T, csil
+
+    def cluster_stats(self, Ws, Hs, labels):
+        """nmfk_cluster_stats (Fin:64-77).  Ws (nsol, n, k), Hs (nsol, k, m), labels (k, nsol)."""
+        Ws, Hs = np.asarray(Ws, dtype=np.float32), np.asarray(Hs, dtype=np.float32)
+        nsol, n, k = Ws.shape
+        m = Hs.shape[2]
+        wst = np.ascontiguousarray(np.transpose(Ws, (0, 2, 1)))
+        hst = np.ascontiguousarray(np.transpose(Hs, (0, 2, 1)))
+        lab = np.ascontiguousarray(np.asarray(labels, dtype=np.int32).T)
+        Wm, Wv = np.empty((k, n), np.float32), np.empty((k, n), np.float32)
+        Hm, Hv = np.empty((m, k), np.float32), np.empty((m, k), np.float32)
+        _check(lib().nmfk_cluster_stats(self._h, k, nsol, n, m, wst.ctypes.data, hst.ctypes.data, lab.ctypes.data,
+                                        Wm.ctypes.data, Hm.ctypes.data, Wv.ctypes.data, Hv.ctypes.data))
+        return Wm.T, Hm.T, Wv.T, Hv.T
+
+    def frobenius(self, W, H):
+        """normnan(X - W*H) (Help:226-228)."""
+        W = np.asfortranarray(W, dtype=np.float32)
+        H = np.asfortranarray(H, dtype=np.float32)
+        if W.shape[0] != self.n or H.shape[1] != self.m or W.shape[1] != H.shape[0]:
+            return float("inf")  # Exec:213-215: size mismatch => fit = Inf
+        out = C.c_double()
+        _check(lib().nmfk_frobenius(self._h, W.shape[1], W.ctypes.data, H.ctypes.data, C.byref(out)))
+        return out.value
+
+    def set_profiling(self, on=True):
+        _check(lib().nmfk_set_profiling(self._h, int(on)))
+
+    def get_profile(self):
+        nmax = 16
+        names = ((C.c_char * 64) * nmax)()
+        ms = (C.c_double * nmax)()
+        launches = (C.c_int64 * nmax)()
+        flops = (C.c_double * nmax)()
+        cnt = C.c_int()
+        _check(lib().nmfk_get_profile(self._h, nmax, C.cast(names, C.c_void_p), ms, launches, flops, C.byref(cnt)))
+        return {names[i].value.decode(): dict(ms=ms[i], launches=launches[i], flops=flops[i]) for i in range(cnt.value)}

@@ -1,0 +1,756 @@
+// libnmfk_hip: C ABI (include/nmfk_hip.h) and host orchestration of the MU sweep.
+//
+// Host-side structure of one sweep (replaces Exec:203 `for nk in nkrange` x Exec:535-541 `for i = 1:nNMF`):
+// every (k, restart) pair is one unit of a flat list sorted by k descending; all units advance in
+// lock-step, one kernel launch per half-step covers all of them (grid.y = unit), and a unit whose stop rule
+// fired simply stops contributing workgroups.  Per iteration: H numerators, H finish, W numerators, W finish;
+// every 10th iteration: objective partials + the check block (Mult:73-117).  The host never waits for the
+// GPU inside the loop: the unit states are copied to pinned memory after each check and inspected one check
+// later, so the queue stays full.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/nmfk_hip.h"
+#include "nmfk_common.h"
+
+#define NMFK_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIPCHECK(expr)                                                                              \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) {                                                                         \
+      char _b[512];                                                                                 \
+      snprintf(_b, sizeof(_b), "HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__, \
+               #expr);                                                                              \
+      return fail(NMFK_ERR_HIP, _b);                                                                \
+    }                                                                                               \
+  } while (0)
+
+struct DevBuf {
+  char *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + (bytes >> 3) + 4096;
+    if (hipMalloc((void **)&p, want) != hipSuccess) return 1;
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+enum { PK_HSTEP = 0, PK_HRED, PK_WSTEP, PK_WRED, PK_SSE, PK_CHECK, PK_OTHER, PK_COUNT };
+const char *const kProfNames[PK_COUNT] = {"mu_h_numerators", "mu_h_finish", "mu_w_numerators", "mu_w_finish",
+                                          "mu_objective",    "mu_check",    "mu_init_finish"};
+
+}  // namespace
+
+struct nmfk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipDeviceProp_t prop;
+  // data
+  int64_t n = 0, m = 0;
+  float *Xc = nullptr, *Xr = nullptr;
+  int64_t nan_count = 0, zero_count = 0;
+  double lambda = 1e-32;
+  // workspaces
+  DevBuf arena;    // sweep
+  DevBuf scratch;  // set_X staging, clustering
+  void *pinned = nullptr;
+  size_t pinned_cap = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> events;
+  double prof_ms[PK_COUNT] = {0};
+  int64_t prof_launches[PK_COUNT] = {0};
+  double prof_flops[PK_COUNT] = {0};
+};
+
+namespace {
+
+struct Bump {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+
+int ensure_pinned(nmfk_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->pinned_cap) return 0;
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  ctx->pinned = nullptr;
+  ctx->pinned_cap = 0;
+  if (hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault) != hipSuccess) return 1;
+  ctx->pinned_cap = bytes;
+  return 0;
+}
+
+struct Marks {
+  nmfk_ctx *ctx;
+  std::vector<int> kinds;
+  size_t used = 0;
+  bool on;
+  explicit Marks(nmfk_ctx *c) : ctx(c), on(c->profiling) {}
+  // record "a kernel of class `kind` ends here"
+  void mark(int kind) {
+    if (!on) return;
+    if (used == ctx->events.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) {
+        on = false;
+        return;
+      }
+      ctx->events.push_back(e);
+    }
+    (void)hipEventRecord(ctx->events[used++], ctx->stream);
+    kinds.push_back(kind);
+  }
+  void resolve() {
+    if (!on || used < 2) return;
+    for (size_t i = 1; i < used; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->events[i - 1], ctx->events[i]) == hipSuccess) {
+        ctx->prof_ms[kinds[i]] += ms;
+        ctx->prof_launches[kinds[i]] += 1;
+      }
+    }
+  }
+};
+
+}  // namespace
+
+NMFK_EXPORT int nmfk_version(void) { return 100; }
+
+NMFK_EXPORT const char *nmfk_last_error(void) { return g_last_error.c_str(); }
+
+NMFK_EXPORT int nmfk_device_count(int *count) {
+  if (!count) return fail(NMFK_ERR_BAD_ARG, "count is null");
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+  *count = c;
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_mu_default_params(nmfk_mu_params *p) {
+  if (!p) return fail(NMFK_ERR_BAD_ARG, "params is null");
+  memset(p, 0, sizeof(*p));
+  p->tol = 1e-19;
+  p->tolOF = 1e-3;
+  p->lambda = 1e-32;
+  p->weight = 1.0;
+  p->maxiter = 10000;
+  p->maxreattempts = 2;
+  p->maxbaditers = 10;
+  p->stopconv = 1000;
+  p->Wfixed = 0;
+  p->Hfixed = 0;
+  p->normalize = 1;
+  p->compute = NMFK_COMPUTE_F32;
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_create(int device, nmfk_ctx **out) {
+  if (!out) return fail(NMFK_ERR_BAD_ARG, "out is null");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(NMFK_ERR_NO_DEVICE, "no HIP device is visible; libnmfk_hip has no CPU fallback");
+  if (device < 0 || device >= count) return fail(NMFK_ERR_BAD_ARG, "device index out of range");
+  HIPCHECK(hipSetDevice(device));
+  nmfk_ctx *ctx = new nmfk_ctx();
+  ctx->device = device;
+  if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) {
+    delete ctx;
+    return fail(NMFK_ERR_HIP, "hipGetDeviceProperties failed");
+  }
+  if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+    std::string msg = std::string("device is ") + ctx->prop.gcnArchName + "; libnmfk_hip is built for gfx950 only";
+    delete ctx;
+    return fail(NMFK_ERR_NO_DEVICE, msg);
+  }
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return fail(NMFK_ERR_HIP, "hipStreamCreate failed");
+  }
+  *out = ctx;
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_destroy(nmfk_ctx *ctx) {
+  if (!ctx) return NMFK_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+  if (ctx->Xc) (void)hipFree(ctx->Xc);
+  if (ctx->Xr) (void)hipFree(ctx->Xr);
+  ctx->arena.release();
+  ctx->scratch.release();
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_device_info(nmfk_ctx *ctx, char *name, int name_len, int *compute_units, int64_t *hbm_bytes) {
+  if (!ctx) return fail(NMFK_ERR_BAD_ARG, "ctx is null");
+  if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+  if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, int64_t ldx, double lambda,
+                           int64_t *nan_count, int64_t *zero_count) {
+  if (!ctx || !X) return fail(NMFK_ERR_BAD_ARG, "ctx or X is null");
+  if (n <= 0 || m <= 0) return fail(NMFK_ERR_BAD_ARG, "Input array has a zero dimension!");  // Exec:242-244
+  if (ldx < n) return fail(NMFK_ERR_BAD_ARG, "ldx < n");
+  if (n > 0x7fffff00 || m > 0x7fffff00) return fail(NMFK_ERR_UNSUPPORTED, "dimension exceeds int32 range");
+  HIPCHECK(hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)n * (size_t)m * sizeof(float);
+  if (ctx->Xc) (void)hipFree(ctx->Xc);
+  if (ctx->Xr) (void)hipFree(ctx->Xr);
+  ctx->Xc = ctx->Xr = nullptr;
+  ctx->n = ctx->m = 0;
+  HIPCHECK(hipMalloc((void **)&ctx->Xc, bytes));
+  HIPCHECK(hipMalloc((void **)&ctx->Xr, bytes));
+  const size_t inbytes = (size_t)ldx * (size_t)m * sizeof(float);
+  if (ctx->scratch.ensure(inbytes + 256)) return fail(NMFK_ERR_HIP, "out of device memory (X staging)");
+  unsigned long long *counts = (unsigned long long *)ctx->scratch.p;
+  float *Xin = (float *)(ctx->scratch.p + 256);
+  HIPCHECK(hipMemsetAsync(counts, 0, 3 * sizeof(unsigned long long), ctx->stream));
+  HIPCHECK(hipMemcpyAsync(Xin, X, ((size_t)ldx * (size_t)(m - 1) + (size_t)n) * sizeof(float), hipMemcpyDefault,
+                          ctx->stream));
+  nmfk_launch_preprocess(Xin, ldx, n, m, (float)lambda, ctx->Xc, ctx->Xr, counts, ctx->stream);
+  HIPCHECK(hipGetLastError());
+  unsigned long long h[3] = {0, 0, 0};
+  HIPCHECK(hipMemcpyAsync(h, counts, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  if (h[0] > 0) {
+    (void)hipFree(ctx->Xc);
+    (void)hipFree(ctx->Xr);
+    ctx->Xc = ctx->Xr = nullptr;
+    return fail(NMFK_ERR_NEGATIVE, "All matrix entries must be nonnegative!");  // Mult:4-7
+  }
+  ctx->n = n;
+  ctx->m = m;
+  ctx->lambda = lambda;
+  ctx->nan_count = (int64_t)h[1];
+  ctx->zero_count = (int64_t)h[2];
+  if (nan_count) *nan_count = ctx->nan_count;
+  if (zero_count) *zero_count = ctx->zero_count;
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_fill_uniform(nmfk_ctx *ctx, uint64_t seed, uint64_t offset, int64_t count, float *out) {
+  if (!ctx || !out || count < 0) return fail(NMFK_ERR_BAD_ARG, "bad argument");
+  if (count == 0) return NMFK_OK;
+  HIPCHECK(hipSetDevice(ctx->device));
+  if (ctx->scratch.ensure((size_t)count * sizeof(float))) return fail(NMFK_ERR_HIP, "out of device memory");
+  nmfk_launch_fill_uniform(seed, offset, count, (float *)ctx->scratch.p, ctx->stream);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(out, ctx->scratch.p, (size_t)count * sizeof(float), hipMemcpyDefault, ctx->stream));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_set_profiling(nmfk_ctx *ctx, int enabled) {
+  if (!ctx) return fail(NMFK_ERR_BAD_ARG, "ctx is null");
+  ctx->profiling = enabled != 0;
+  for (int i = 0; i < PK_COUNT; ++i) {
+    ctx->prof_ms[i] = 0;
+    ctx->prof_launches[i] = 0;
+    ctx->prof_flops[i] = 0;
+  }
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *total_ms, int64_t *launches,
+                                 double *flops, int *count) {
+  if (!ctx || !count) return fail(NMFK_ERR_BAD_ARG, "bad argument");
+  int c = 0;
+  for (int i = 0; i < PK_COUNT && c < max_entries; ++i) {
+    if (names) snprintf(names[c], 64, "%s", kProfNames[i]);
+    if (total_ms) total_ms[c] = ctx->prof_ms[i];
+    if (launches) launches[c] = ctx->prof_launches[i];
+    if (flops) flops[c] = ctx->prof_flops[i];
+    ++c;
+  }
+  *count = c;
+  return NMFK_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// the sweep
+// --------------------------------------------------------------------------------------------------------
+NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nruns, const float *const *Winit,
+                              const float *const *Hinit, const uint64_t *seeds, const nmfk_mu_params *params,
+                              float *const *W_out, float *const *H_out, float *const *frob_out,
+                              double *const *sse_out, int32_t *const *iters_out, int32_t *const *reason_out) {
+  if (!ctx || !ks || !params || !W_out || !H_out || !frob_out) return fail(NMFK_ERR_BAD_ARG, "null argument");
+  if (!ctx->Xc) return fail(NMFK_ERR_NO_X, "nmfk_set_X has not been called");
+  if (nk <= 0 || nruns <= 0) return fail(NMFK_ERR_BAD_ARG, "nk and nruns must be positive");
+  const nmfk_mu_params P = *params;
+  if (P.compute != NMFK_COMPUTE_F32 && P.compute != NMFK_COMPUTE_F64) return fail(NMFK_ERR_BAD_ARG, "bad compute mode");
+  if (P.maxiter < 0 || P.maxiter > 0x7ffffff0) return fail(NMFK_ERR_BAD_ARG, "bad maxiter");
+  const int n = (int)ctx->n, m = (int)ctx->m;
+  for (int q = 0; q < nk; ++q) {
+    if (ks[q] < 1) return fail(NMFK_ERR_BAD_ARG, "k must be >= 1");
+    if (ks[q] > NMFK_MAX_K) return fail(NMFK_ERR_UNSUPPORTED, "k exceeds NMFK_MAX_K (64)");
+    const bool hasW = Winit && Winit[q], hasH = Hinit && Hinit[q];
+    if ((!hasW || !hasH) && !seeds) return fail(NMFK_ERR_BAD_ARG, "seeds are required where Winit/Hinit are null");
+    if (!W_out[q] || !H_out[q] || !frob_out[q]) return fail(NMFK_ERR_BAD_ARG, "null output pointer");
+  }
+  HIPCHECK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const bool f64 = P.compute == NMFK_COMPUTE_F64;
+  const size_t tsz = f64 ? sizeof(double) : sizeof(float);
+  const int nunits = nk * nruns;
+
+  // ranks sorted by k descending (long units first; units with kp > 16 form a prefix)
+  std::vector<int> order(nk);
+  for (int q = 0; q < nk; ++q) order[q] = q;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ks[a] > ks[b]; });
+
+  // loop-dimension splits: aim at >= 4 workgroups per CU per launch
+  const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+  const int target = 4 * cus;
+  const int tiles_m = (m + NMFK_TILE - 1) / NMFK_TILE, tiles_n = (n + NMFK_TILE - 1) / NMFK_TILE;
+  auto splits = [&](int tiles, int D) {
+    int64_t have = (int64_t)tiles * nunits;
+    int S = (int)((target + have - 1) / have);
+    int maxS = std::max(1, D / 64);
+    S = std::max(1, std::min(S, maxS));
+    return S;
+  };
+  const int Sh = splits(tiles_m, n), Sw = splits(tiles_n, m);
+  const int dchunk_h = (n + Sh - 1) / Sh, dchunk_w = (m + Sw - 1) / Sw;
+
+  // arena layout
+  Bump B;
+  const size_t o_runs = B.take(sizeof(NmfkRun) * nunits);
+  const size_t o_state = B.take(sizeof(NmfkState) * nunits);
+  const size_t o_flag = B.take(256);
+  const size_t o_ptrs = B.take(sizeof(void *) * 7 * nk);
+  std::vector<NmfkRun> runs(nunits);
+  std::vector<size_t> o_Wi(nk, 0), o_Hi(nk, 0), o_Wo(nk), o_Ho(nk), o_frob(nk), o_iters(nk), o_reason(nk);
+  int nlarge = 0;
+  {
+    int u = 0;
+    for (int oi = 0; oi < nk; ++oi) {
+      const int q = order[oi], k = ks[q], kp = nmfk_padded_k(k);
+      for (int r = 0; r < nruns; ++r, ++u) {
+        NmfkRun &rd = runs[u];
+        rd.k = k;
+        rd.kp = kp;
+        rd.kidx = q;
+        rd.ridx = r;
+        rd.oWt = (int64_t)B.take(tsz * (size_t)kp * n);
+        rd.oH0 = (int64_t)B.take(tsz * (size_t)kp * m);
+        rd.oH1 = P.Hfixed ? rd.oH0 : (int64_t)B.take(tsz * (size_t)kp * m);
+        const size_t pe = std::max((size_t)Sh * kp * m, (size_t)Sw * kp * n);
+        rd.opart = (int64_t)B.take(std::max(tsz * pe, sizeof(int32_t) * (size_t)m));
+        rd.osumW = (int64_t)B.take(tsz * kp);
+        rd.osumH = (int64_t)B.take(tsz * kp);
+        rd.ossepart = (int64_t)B.take(sizeof(double) * tiles_n);
+        rd.ocanon = (int64_t)B.take(sizeof(int32_t) * (size_t)m);
+        rd.seed = seeds ? seeds[(size_t)q * nruns + r] : 0;
+        if (kp > 16) nlarge = u + 1;
+      }
+    }
+  }
+  for (int q = 0; q < nk; ++q) {
+    const size_t k = (size_t)ks[q];
+    if (Winit && Winit[q]) o_Wi[q] = B.take(sizeof(float) * nruns * k * n);
+    if (Hinit && Hinit[q]) o_Hi[q] = B.take(sizeof(float) * nruns * k * m);
+    o_Wo[q] = B.take(sizeof(float) * nruns * k * n);
+    o_Ho[q] = B.take(sizeof(float) * nruns * k * m);
+    o_frob[q] = B.take(sizeof(float) * nruns);
+    o_iters[q] = B.take(sizeof(int32_t) * nruns);
+    o_reason[q] = B.take(sizeof(int32_t) * nruns);
+  }
+  if (ctx->arena.ensure(B.off)) return fail(NMFK_ERR_HIP, "out of device memory (sweep arena)");
+  char *A = ctx->arena.p;
+  if (ensure_pinned(ctx, 2 * sizeof(NmfkState) * (size_t)nunits + 4096)) return fail(NMFK_ERR_HIP, "hipHostMalloc failed");
+
+  // pointer tables: [Winit | Hinit | Wout | Hout | frob | iters | reason] x nk
+  std::vector<void *> ptrs(7 * (size_t)nk, nullptr);
+  for (int q = 0; q < nk; ++q) {
+    ptrs[0 * nk + q] = (Winit && Winit[q]) ? (void *)(A + o_Wi[q]) : nullptr;
+    ptrs[1 * nk + q] = (Hinit && Hinit[q]) ? (void *)(A + o_Hi[q]) : nullptr;
+    ptrs[2 * nk + q] = A + o_Wo[q];
+    ptrs[3 * nk + q] = A + o_Ho[q];
+    ptrs[4 * nk + q] = A + o_frob[q];
+    ptrs[5 * nk + q] = A + o_iters[q];
+    ptrs[6 * nk + q] = A + o_reason[q];
+  }
+  HIPCHECK(hipMemcpyAsync(A + o_runs, runs.data(), sizeof(NmfkRun) * nunits, hipMemcpyHostToDevice, st));
+  HIPCHECK(hipMemcpyAsync(A + o_ptrs, ptrs.data(), sizeof(void *) * ptrs.size(), hipMemcpyHostToDevice, st));
+  HIPCHECK(hipMemsetAsync(A + o_flag, 0, 256, st));
+  for (int q = 0; q < nk; ++q) {
+    const size_t k = (size_t)ks[q];
+    if (Winit && Winit[q])
+      HIPCHECK(hipMemcpyAsync(A + o_Wi[q], Winit[q], sizeof(float) * nruns * k * n, hipMemcpyDefault, st));
+    if (Hinit && Hinit[q])
+      HIPCHECK(hipMemcpyAsync(A + o_Hi[q], Hinit[q], sizeof(float) * nruns * k * m, hipMemcpyDefault, st));
+  }
+  // the host vectors above must outlive the async copies
+  HIPCHECK(hipStreamSynchronize(st));
+
+  const NmfkRun *d_runs = (const NmfkRun *)(A + o_runs);
+  NmfkState *d_state = (NmfkState *)(A + o_state);
+  void **d_ptrs = (void **)(A + o_ptrs);
+
+  Marks marks(ctx);
+  marks.mark(PK_OTHER);
+
+  NmfkInitArgs ia;
+  ia.arena = A;
+  ia.n = n;
+  ia.m = m;
+  ia.runs = d_runs;
+  ia.state = d_state;
+  ia.nunits = nunits;
+  ia.Winit = (const float *const *)(d_ptrs + 0 * nk);
+  ia.Hinit = (const float *const *)(d_ptrs + 1 * nk);
+  ia.nan_flag = (int32_t *)(A + o_flag);
+  if (f64)
+    nmfk_launch_init_f64(ia, st);
+  else
+    nmfk_launch_init_f32(ia, st);
+  HIPCHECK(hipGetLastError());
+  marks.mark(PK_OTHER);
+  {
+    int32_t flag = 0;
+    HIPCHECK(hipMemcpyAsync(&flag, A + o_flag, sizeof(flag), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    if (flag) return fail(NMFK_ERR_NAN_INIT, "Initial values for the W/H matrix entries include NaNs!");
+  }
+
+  NmfkStepArgs hs;
+  hs.arena = A;
+  hs.X = ctx->Xr;
+  hs.ld = m;
+  hs.L = m;
+  hs.D = n;
+  hs.S = Sh;
+  hs.dchunk = dchunk_h;
+  hs.which = 0;
+  hs.it = 0;
+  hs.has_nan = ctx->nan_count > 0;
+  hs.lambda = (float)ctx->lambda;
+  hs.runs = d_runs;
+  hs.state = d_state;
+  hs.nunits = nunits;
+  hs.nlarge = nlarge;
+  hs.force = 0;
+  NmfkStepArgs ws = hs;
+  ws.X = ctx->Xc;
+  ws.ld = n;
+  ws.L = n;
+  ws.D = m;
+  ws.S = Sw;
+  ws.dchunk = dchunk_w;
+  ws.which = 1;
+
+  NmfkSseArgs sa;
+  sa.arena = A;
+  sa.Xc = ctx->Xc;
+  sa.n = n;
+  sa.m = m;
+  sa.hsel = 0;
+  sa.weight = P.weight;
+  sa.runs = d_runs;
+  sa.state = d_state;
+  sa.nunits = nunits;
+  sa.force = 0;
+  sa.total_iters = 0;
+
+  NmfkCheckArgs ca;
+  ca.arena = A;
+  ca.n = n;
+  ca.m = m;
+  ca.it = 0;
+  ca.ntile_n = tiles_n;
+  ca.tol = P.tol;
+  ca.tolOF = P.tolOF;
+  ca.maxiter = P.maxiter;
+  ca.maxbaditers = P.maxbaditers;
+  ca.maxreattempts = P.maxreattempts;
+  ca.stopconv = P.stopconv;
+  ca.runs = d_runs;
+  ca.state = d_state;
+  ca.nunits = nunits;
+
+  // Mult:64 guard before the first iteration
+  const bool guard0 = P.maxiter > 0 && P.maxbaditers > 0 && P.maxreattempts > 0;
+  NmfkState *snap[2] = {(NmfkState *)ctx->pinned, (NmfkState *)ctx->pinned + nunits};
+  hipEvent_t snap_ev[2];
+  HIPCHECK(hipEventCreateWithFlags(&snap_ev[0], hipEventDisableTiming));
+  HIPCHECK(hipEventCreateWithFlags(&snap_ev[1], hipEventDisableTiming));
+  int total_iters = 0;
+  int nchecks = 0;
+  bool all_done = !guard0;
+  const int maxiter = guard0 ? (int)P.maxiter : 0;
+  for (int it = 0; it < maxiter && !all_done; ++it) {
+    if (!P.Hfixed) {  // Mult:66-68
+      hs.it = it;
+      if (f64) {
+        nmfk_launch_step_f64(hs, st);
+        marks.mark(PK_HSTEP);
+        nmfk_launch_reduce_f64(hs, st);
+      } else {
+        nmfk_launch_step_f32(hs, st);
+        marks.mark(PK_HSTEP);
+        nmfk_launch_reduce_f32(hs, st);
+      }
+      marks.mark(PK_HRED);
+    }
+    if (!P.Wfixed) {  // Mult:69-71
+      ws.it = it;
+      if (f64) {
+        nmfk_launch_step_f64(ws, st);
+        marks.mark(PK_WSTEP);
+        nmfk_launch_reduce_f64(ws, st);
+      } else {
+        nmfk_launch_step_f32(ws, st);
+        marks.mark(PK_WSTEP);
+        nmfk_launch_reduce_f32(ws, st);
+      }
+      marks.mark(PK_WRED);
+    }
+    total_iters = it + 1;
+    if ((it + 1) % 10 == 0) {  // Mult:73
+      sa.hsel = (it + 1) & 1;
+      ca.it = it;
+      if (f64) {
+        nmfk_launch_sse_f64(sa, st);
+        marks.mark(PK_SSE);
+        nmfk_launch_check_f64(ca, st);
+      } else {
+        nmfk_launch_sse_f32(sa, st);
+        marks.mark(PK_SSE);
+        nmfk_launch_check_f32(ca, st);
+      }
+      marks.mark(PK_CHECK);
+      const int slot = nchecks & 1;
+      if (nchecks > 0) {  // inspect the PREVIOUS check while this one is still queued
+        HIPCHECK(hipEventSynchronize(snap_ev[slot ^ 1]));
+        bool any = false;
+        for (int u = 0; u < nunits; ++u) any = any || snap[slot ^ 1][u].active;
+        if (!any) all_done = true;
+      }
+      HIPCHECK(hipMemcpyAsync(snap[slot], d_state, sizeof(NmfkState) * nunits, hipMemcpyDeviceToHost, st));
+      HIPCHECK(hipEventRecord(snap_ev[slot], st));
+      nchecks++;
+    }
+  }
+  HIPCHECK(hipGetLastError());
+
+  // objvalue = normnan(X - W*H) on the final factors, normalisation, T-typed outputs (Exec:790-805)
+  sa.hsel = -1;
+  sa.weight = 1.0;
+  sa.force = 1;
+  sa.total_iters = total_iters;
+  NmfkFinishArgs fa;
+  fa.arena = A;
+  fa.n = n;
+  fa.m = m;
+  fa.ntile_n = tiles_n;
+  fa.total_iters = total_iters;
+  fa.normalize = P.normalize;
+  fa.runs = d_runs;
+  fa.state = d_state;
+  fa.nunits = nunits;
+  fa.Wout = (float *const *)(d_ptrs + 2 * nk);
+  fa.Hout = (float *const *)(d_ptrs + 3 * nk);
+  fa.frob = (float *const *)(d_ptrs + 4 * nk);
+  fa.iters = (int32_t *const *)(d_ptrs + 5 * nk);
+  fa.reason = (int32_t *const *)(d_ptrs + 6 * nk);
+  if (f64) {
+    nmfk_launch_sse_f64(sa, st);
+    nmfk_launch_finish_f64(fa, st);
+  } else {
+    nmfk_launch_sse_f32(sa, st);
+    nmfk_launch_finish_f32(fa, st);
+  }
+  marks.mark(PK_OTHER);
+  HIPCHECK(hipGetLastError());
+
+  std::vector<std::vector<float>> h_frob(nk);
+  std::vector<std::vector<int32_t>> h_iters(nk);
+  for (int q = 0; q < nk; ++q) {
+    const size_t k = (size_t)ks[q];
+    HIPCHECK(hipMemcpyAsync(W_out[q], A + o_Wo[q], sizeof(float) * nruns * k * n, hipMemcpyDefault, st));
+    HIPCHECK(hipMemcpyAsync(H_out[q], A + o_Ho[q], sizeof(float) * nruns * k * m, hipMemcpyDefault, st));
+    HIPCHECK(hipMemcpyAsync(frob_out[q], A + o_frob[q], sizeof(float) * nruns, hipMemcpyDefault, st));
+    if (iters_out && iters_out[q])
+      HIPCHECK(hipMemcpyAsync(iters_out[q], A + o_iters[q], sizeof(int32_t) * nruns, hipMemcpyDefault, st));
+    if (reason_out && reason_out[q])
+      HIPCHECK(hipMemcpyAsync(reason_out[q], A + o_reason[q], sizeof(int32_t) * nruns, hipMemcpyDefault, st));
+    h_frob[q].resize(nruns);
+    h_iters[q].resize(nruns);
+    HIPCHECK(hipMemcpyAsync(h_frob[q].data(), A + o_frob[q], sizeof(float) * nruns, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(h_iters[q].data(), A + o_iters[q], sizeof(int32_t) * nruns, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHECK(hipStreamSynchronize(st));
+  (void)hipEventDestroy(snap_ev[0]);
+  (void)hipEventDestroy(snap_ev[1]);
+
+  // Mult:125: sum(((X - W*H) .* weight)[.!inan].^2) = (weight * normnan(X - W*H))^2 for a scalar weight.
+  // sse_out may be device memory: stage through a host vector.
+  if (sse_out) {
+    std::vector<double> tmp(nruns);
+    for (int q = 0; q < nk; ++q) {
+      if (!sse_out[q]) continue;
+      for (int r = 0; r < nruns; ++r) {
+        const double f = (double)h_frob[q][r] * P.weight;
+        tmp[r] = f * f;
+      }
+      HIPCHECK(hipMemcpy(sse_out[q], tmp.data(), sizeof(double) * nruns, hipMemcpyDefault));
+    }
+  }
+
+  marks.resolve();
+  if (ctx->profiling) {
+    for (int q = 0; q < nk; ++q)
+      for (int r = 0; r < nruns; ++r) {
+        const double step = 4.0 * n * (double)m * ks[q] * (double)h_iters[q][r];  // W*H + the product with the ratio
+        if (!P.Hfixed) ctx->prof_flops[PK_HSTEP] += step;
+        if (!P.Wfixed) ctx->prof_flops[PK_WSTEP] += step;
+        ctx->prof_flops[PK_SSE] += 2.0 * n * (double)m * ks[q] * (double)(h_iters[q][r] / 10);
+      }
+  }
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_mu_batch(nmfk_ctx *ctx, int k, int nruns, const float *Winit, const float *Hinit,
+                              const uint64_t *seeds, const nmfk_mu_params *params, float *W_out, float *H_out,
+                              float *frob_out, double *sse_out, int32_t *iters_out, int32_t *reason_out) {
+  const int32_t ks[1] = {k};
+  const float *wi[1] = {Winit}, *hi[1] = {Hinit};
+  float *wo[1] = {W_out}, *ho[1] = {H_out}, *fo[1] = {frob_out};
+  double *so[1] = {sse_out};
+  int32_t *io[1] = {iters_out}, *ro[1] = {reason_out};
+  return nmfk_mu_sweep(ctx, 1, ks, nruns, wi, hi, seeds, params, wo, ho, fo, so, io, ro);
+}
+
+// --------------------------------------------------------------------------------------------------------
+// robustness
+// --------------------------------------------------------------------------------------------------------
+NMFK_EXPORT int nmfk_cluster_silhouette(nmfk_ctx *ctx, int k, int nsol, int64_t m64, const float *Hstack,
+                                        int32_t *labels, float *centroids, float *point_sil, float *cluster_sil) {
+  if (!ctx || !Hstack || !labels || !centroids || !point_sil || !cluster_sil)
+    return fail(NMFK_ERR_BAD_ARG, "null argument");
+  if (k < 1 || nsol < 1 || m64 < 1) return fail(NMFK_ERR_BAD_ARG, "k, nsol and m must be positive");
+  if (k > NMFK_MAX_K) return fail(NMFK_ERR_UNSUPPORTED, "k exceeds NMFK_MAX_K (64)");
+  HIPCHECK(hipSetDevice(ctx->device));
+  const int m = (int)m64;
+  const size_t nT = (size_t)k * nsol;
+  Bump B;
+  const size_t oH = B.take(sizeof(float) * nT * m);
+  const size_t oCent = B.take(sizeof(float) * (size_t)k * (m + 1));
+  const size_t oLab = B.take(sizeof(int32_t) * nT);
+  const size_t oCen = B.take(sizeof(float) * (size_t)k * m);
+  const size_t oZ = B.take(sizeof(float) * nT * m);
+  const size_t oNorm = B.take(sizeof(float) * nT);
+  const size_t oD = B.take(sizeof(float) * nT * nT);
+  const size_t oPs = B.take(sizeof(float) * nT);
+  const size_t oCs = B.take(sizeof(float) * k);
+  const size_t oFix = B.take(sizeof(int32_t));
+  if (ctx->scratch.ensure(B.off)) return fail(NMFK_ERR_HIP, "out of device memory (cluster workspace)");
+  char *S = ctx->scratch.p;
+  hipStream_t st = ctx->stream;
+  HIPCHECK(hipMemcpyAsync(S + oH, Hstack, sizeof(float) * nT * m, hipMemcpyDefault, st));
+  nmfk_launch_cluster(k, nsol, m, (const float *)(S + oH), (float *)(S + oCent), (int32_t *)(S + oLab),
+                      (float *)(S + oCen), (int32_t *)(S + oFix), st);
+  nmfk_launch_silhouette(k, nsol, m, (const float *)(S + oH), (const int32_t *)(S + oLab), (float *)(S + oZ),
+                         (float *)(S + oNorm), (float *)(S + oD), (float *)(S + oPs), (float *)(S + oCs), st);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(labels, S + oLab, sizeof(int32_t) * nT, hipMemcpyDefault, st));
+  HIPCHECK(hipMemcpyAsync(centroids, S + oCen, sizeof(float) * (size_t)k * m, hipMemcpyDefault, st));
+  HIPCHECK(hipMemcpyAsync(point_sil, S + oPs, sizeof(float) * nT, hipMemcpyDefault, st));
+  HIPCHECK(hipMemcpyAsync(cluster_sil, S + oCs, sizeof(float) * k, hipMemcpyDefault, st));
+  HIPCHECK(hipStreamSynchronize(st));
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_cluster_stats(nmfk_ctx *ctx, int k, int nsol, int64_t n64, int64_t m64, const float *Wstack,
+                                   const float *Hstack, const int32_t *labels, float *Wmean, float *Hmean,
+                                   float *Wvar, float *Hvar) {
+  if (!ctx || !Wstack || !Hstack || !labels || !Wmean || !Hmean || !Wvar || !Hvar)
+    return fail(NMFK_ERR_BAD_ARG, "null argument");
+  if (k < 1 || nsol < 1 || n64 < 1 || m64 < 1) return fail(NMFK_ERR_BAD_ARG, "sizes must be positive");
+  HIPCHECK(hipSetDevice(ctx->device));
+  const int n = (int)n64, m = (int)m64;
+  Bump B;
+  const size_t oW = B.take(sizeof(float) * (size_t)nsol * n * k);
+  const size_t oH = B.take(sizeof(float) * (size_t)nsol * m * k);
+  const size_t oL = B.take(sizeof(int32_t) * (size_t)nsol * k);
+  const size_t oWm = B.take(sizeof(float) * (size_t)n * k), oWv = B.take(sizeof(float) * (size_t)n * k);
+  const size_t oHm = B.take(sizeof(float) * (size_t)m * k), oHv = B.take(sizeof(float) * (size_t)m * k);
+  if (ctx->scratch.ensure(B.off)) return fail(NMFK_ERR_HIP, "out of device memory (stats workspace)");
+  char *S = ctx->scratch.p;
+  hipStream_t st = ctx->stream;
+  HIPCHECK(hipMemcpyAsync(S + oW, Wstack, sizeof(float) * (size_t)nsol * n * k, hipMemcpyDefault, st));
+  HIPCHECK(hipMemcpyAsync(S + oH, Hstack, sizeof(float) * (size_t)nsol * m * k, hipMemcpyDefault, st));
+  HIPCHECK(hipMemcpyAsync(S + oL, labels, sizeof(int32_t) * (size_t)nsol * k, hipMemcpyDefault, st));
+  nmfk_launch_cluster_stats(k, nsol, n, m, (const float *)(S + oW), (const float *)(S + oH), (const int32_t *)(S + oL),
+                            (float *)(S + oWm), (float *)(S + oHm), (float *)(S + oWv), (float *)(S + oHv), st);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(Wmean, S + oWm, sizeof(float) * (size_t)n * k, hipMemcpyDefault, st));
+  HIPCHECK(hipMemcpyAsync(Wvar, S + oWv, sizeof(float) * (size_t)n * k, hipMemcpyDefault, st));
+  HIPCHECK(hipMemcpyAsync(Hmean, S + oHm, sizeof(float) * (size_t)m * k, hipMemcpyDefault, st));
+  HIPCHECK(hipMemcpyAsync(Hvar, S + oHv, sizeof(float) * (size_t)m * k, hipMemcpyDefault, st));
+  HIPCHECK(hipStreamSynchronize(st));
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float *H, double *out) {
+  if (!ctx || !W || !H || !out) return fail(NMFK_ERR_BAD_ARG, "null argument");
+  if (!ctx->Xc) return fail(NMFK_ERR_NO_X, "nmfk_set_X has not been called");
+  if (k < 1) return fail(NMFK_ERR_BAD_ARG, "k must be >= 1");
+  HIPCHECK(hipSetDevice(ctx->device));
+  const int n = (int)ctx->n, m = (int)ctx->m;
+  const int tiles = (n + 255) / 256;
+  Bump B;
+  const size_t oW = B.take(sizeof(float) * (size_t)n * k), oH = B.take(sizeof(float) * (size_t)m * k);
+  const size_t oP = B.take(sizeof(double) * tiles);
+  if (ctx->scratch.ensure(B.off)) return fail(NMFK_ERR_HIP, "out of device memory");
+  char *S = ctx->scratch.p;
+  hipStream_t st = ctx->stream;
+  HIPCHECK(hipMemcpyAsync(S + oW, W, sizeof(float) * (size_t)n * k, hipMemcpyDefault, st));
+  HIPCHECK(hipMemcpyAsync(S + oH, H, sizeof(float) * (size_t)m * k, hipMemcpyDefault, st));
+  nmfk_launch_frob(ctx->Xc, n, m, k, (const float *)(S + oW), (const float *)(S + oH), (double *)(S + oP), st);
+  HIPCHECK(hipGetLastError());
+  std::vector<double> part(tiles);
+  HIPCHECK(hipMemcpyAsync(part.data(), S + oP, sizeof(double) * tiles, hipMemcpyDeviceToHost, st));
+  HIPCHECK(hipStreamSynchronize(st));
+  double s = 0;
+  for (int t = 0; t < tiles; ++t) s += part[t];
+  *out = sqrt(s);
+  return NMFK_OK;
+}

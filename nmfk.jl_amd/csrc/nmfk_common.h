@@ -1,0 +1,164 @@
+// Shared host/device declarations of libnmfk_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// One unit of the flat work list = one restart of one rank k: "a factorization".
+// Internal factor layout (both factors "signal-major", so the two half-steps are the same kernel):
+//   Wt : kp x n   element (a, i) at Wt[a + i*kp]      (W transposed: row i of W contiguous)
+//   H  : kp x m   element (a, j) at H [a + j*kp]      (double-buffered: H0, H1)
+// kp = k for k <= 16, else k padded up to the next instantiated width (padding rows are zero).
+struct NmfkRun {
+  int32_t k;         // true rank
+  int32_t kp;        // padded rank = leading dimension of Wt / H
+  int32_t kidx;      // index of the rank in the caller's ks[]
+  int32_t ridx;      // restart index within the rank
+  // byte offsets into the sweep arena (kernels form `arena + offset`, so the compiler knows the pointers are
+  // global memory and can use scalar loads for wave-uniform reads)
+  int64_t oWt;       // T[kp*n]
+  int64_t oH0, oH1;  // T[kp*m] x2, double-buffered by iteration parity (equal when Hfixed)
+  int64_t opart;     // T[max(Sh*kp*m, Sw*kp*n)] partial numerators of the current half-step
+  int64_t osumW;     // T[kp]   colsum(W)  (denominator of the H half-step, Mult:67)
+  int64_t osumH;     // T[kp]   rowsum(H)  (denominator of the W half-step, Mult:70)
+  int64_t ossepart;  // double[ntile_n] per-workgroup partial objective
+  int64_t ocanon;    // int32[m] canonical co-clustering partition of the previous check (Mult:101-116)
+  uint64_t seed;
+};
+
+// Stop-rule state machine of NMFmultiplicative (Mult:57-63), one per unit, device resident.
+struct NmfkState {
+  double best;       // objvalue_best
+  double last_obj;   // last monitored objective
+  int32_t iters;     // iterations executed (valid once inactive)
+  int32_t baditers;
+  int32_t reattempts;
+  int32_t inc;
+  int32_t have_old;  // consold is not the initial falses(m,m)
+  int32_t active;    // still inside the while loop
+  int32_t reason;    // NMFK_STOP_*
+  int32_t pad;
+};
+
+// Arguments of one half-step over all units.  lane dimension L (contiguous in the X copy used), loop
+// dimension D:  H half-step: L = m, D = n, X copy = row-major (Xr);  W half-step: L = n, D = m, X copy =
+// column-major (Xc).
+struct NmfkStepArgs {
+  char *arena;
+  const float *X;   // element (l, d) at X[l + d*ld]
+  int64_t ld;
+  int32_t L, D;
+  int32_t S;        // splits of the loop dimension (partials reduced by the reduce kernel)
+  int32_t dchunk;   // loop extent per split
+  int32_t which;    // 0 = H half-step, 1 = W half-step
+  int32_t it;       // 0-based iteration index: reads H(it&1), writes H((it+1)&1)
+  int32_t has_nan;  // X holds NaN (missing) entries: EM imputation semantics of Mult:72
+  float lambda;
+  const NmfkRun *runs;
+  NmfkState *state;
+  int32_t nunits;
+  int32_t nlarge;   // units are sorted by k descending: units [0, nlarge) have kp > 16
+  int32_t force;    // ignore the active flags
+};
+
+struct NmfkSseArgs {
+  char *arena;
+  const float *Xc;  // column-major copy, element (i, j) at Xc[i + j*n]
+  int32_t n, m;
+  int32_t hsel;     // which H buffer parity to read; -1 => per-unit final buffer (state.iters&1)
+  double weight;
+  const NmfkRun *runs;
+  NmfkState *state;
+  int32_t nunits;
+  int32_t force;        // finish pass: every unit, NaN residuals skipped (normnan)
+  int32_t total_iters;  // iterations the host loop executed (selects the final H buffer of still-active units)
+};
+
+struct NmfkCheckArgs {
+  char *arena;
+  int32_t n, m;
+  int32_t it;       // index of the iteration just completed (0-based); (it+1) % 10 == 0
+  int32_t ntile_n;  // number of ssepart entries per unit
+  double tol, tolOF;
+  int64_t maxiter;
+  int32_t maxbaditers, maxreattempts, stopconv;
+  const NmfkRun *runs;
+  NmfkState *state;
+  int32_t nunits;
+};
+
+struct NmfkFinishArgs {
+  char *arena;
+  int32_t n, m;
+  int32_t ntile_n;
+  int32_t total_iters;  // iterations the host loop executed
+  int32_t normalize;
+  const NmfkRun *runs;
+  NmfkState *state;
+  int32_t nunits;
+  float *const *Wout;   // per kidx: nruns stacked n x k (device staging)
+  float *const *Hout;   // per kidx: nruns stacked k x m
+  float *const *frob;   // per kidx: nruns
+  int32_t *const *iters;
+  int32_t *const *reason;
+};
+
+struct NmfkInitArgs {
+  char *arena;
+  int32_t n, m;
+  const NmfkRun *runs;
+  NmfkState *state;
+  int32_t nunits;
+  const float *const *Winit;  // per kidx (device staging) or null entries
+  const float *const *Hinit;
+  int32_t *nan_flag;          // set to 1 when an initial value is NaN (Mult:42-44,52-54)
+};
+
+static inline int nmfk_padded_k(int k) {
+  if (k <= 16) return k;
+  static const int w[] = {20, 24, 28, 32, 40, 48, 56, 64};
+  for (int i = 0; i < 8; i++)
+    if (k <= w[i]) return w[i];
+  return -1;
+}
+
+// switch over the instantiated factor widths
+#define NMFK_DISPATCH_KP(kp, CALL)                                                                    \
+  switch (kp) {                                                                                       \
+    case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;   case 4: CALL(4); break;   \
+    case 5: CALL(5); break;   case 6: CALL(6); break;   case 7: CALL(7); break;   case 8: CALL(8); break;   \
+    case 9: CALL(9); break;   case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break; \
+    case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break; \
+    case 20: CALL(20); break; case 24: CALL(24); break; case 28: CALL(28); break; case 32: CALL(32); break; \
+    case 40: CALL(40); break; case 48: CALL(48); break; case 56: CALL(56); break; case 64: CALL(64); break; \
+    default: break;                                                                                   \
+  }
+
+// offset of the H buffer of parity `par`
+#define NMFK_HOFF(rd, par) (((par)&1) ? (rd).oH1 : (rd).oH0)
+
+#define NMFK_TILE 256  // threads per workgroup = lane-tile width of the half-step kernels
+
+// launchers (nmfk_step_f32.hip / nmfk_step_f64.hip)
+#define NMFK_DECLARE_LAUNCHERS(SUF)                                                              \
+  void nmfk_launch_init_##SUF(const NmfkInitArgs &a, hipStream_t s);                             \
+  void nmfk_launch_step_##SUF(const NmfkStepArgs &a, hipStream_t s);                             \
+  void nmfk_launch_reduce_##SUF(const NmfkStepArgs &a, hipStream_t s);                           \
+  void nmfk_launch_sse_##SUF(const NmfkSseArgs &a, hipStream_t s);                               \
+  void nmfk_launch_check_##SUF(const NmfkCheckArgs &a, hipStream_t s);                           \
+  void nmfk_launch_finish_##SUF(const NmfkFinishArgs &a, hipStream_t s);
+NMFK_DECLARE_LAUNCHERS(f32)
+NMFK_DECLARE_LAUNCHERS(f64)
+
+// nmfk_cluster.hip
+void nmfk_launch_preprocess(const float *Xin, int64_t ldx, int64_t n, int64_t m, float lambda, float *Xc, float *Xr,
+                            unsigned long long *counts /* [0]=neg [1]=nan [2]=zero */, hipStream_t s);
+void nmfk_launch_fill_uniform(uint64_t seed, uint64_t offset, int64_t count, float *out, hipStream_t s);
+void nmfk_launch_cluster(int k, int nsol, int m, const float *Hstack, float *work, int32_t *labels, float *centroids,
+                         int32_t *needfix, hipStream_t s);
+void nmfk_launch_silhouette(int k, int nsol, int m, const float *Hstack, const int32_t *labels, float *Z, float *norms,
+                            float *D, float *psil, float *csil, hipStream_t s);
+void nmfk_launch_cluster_stats(int k, int nsol, int n, int m, const float *Wstack, const float *Hstack,
+                               const int32_t *labels, float *Wmean, float *Hmean, float *Wvar, float *Hvar,
+                               hipStream_t s);
+void nmfk_launch_frob(const float *Xc, int n, int m, int k, const float *W, const float *H, double *partial,
+                      hipStream_t s);

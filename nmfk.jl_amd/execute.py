@@ -1,0 +1,333 @@
+"""Host-side mirror of NMFk.jl's `execute` for method=:simple (src/NMFkExecute.jl), driving libnmfk_hip.
+
+    W, H, fitquality, robustness, aic, kopt = execute(X, range(2, 6), 10, save=False, load=False)
+
+Same names, argument meaning, return shapes and error behaviour as the reference path:
+  execute(X, nkrange, nNMF=10; ...)    Exec:178-233  -> (W, H, fitquality, robustness, aic, kopt)
+  execute(X, nk::Integer, nNMF; ...)   Exec:236-329  -> (W, H, fit, robustness, aic)
+  execute_run(X, nk, nNMF; ...)        Exec:483-711  -> (Wa, Ha, phi, minsilhouette, aic)
+  getk / signalorder                   src/NMFkPostprocess.jl:7-41, 148-158
+Julia's 1-based vectors of length maxk become Python sequences indexed by k-1 (W[k-1] is None where the
+reference leaves #undef; fitquality[0] = Inf, robustness[0] = -1 as at Exec:200-201).
+
+Everything numeric runs on the GPU through the C ABI (multiplicative updates, objective, normalisation,
+clustering, silhouettes, fit re-checks); this file is orchestration only (sorting <= nNMF objective values,
+the acceptance filters, k selection).  The reference's serial loops over k and over restarts become one
+flat (k, restart) work list; with torch.distributed initialised the list is sharded by restart over the
+ranks (parallel.py)."""
+import math
+import os
+import warnings
+
+import numpy as np
+
+from . import _lib
+from ._lib import Context, NMFkError
+
+_METHOD_ALIASES = {"multdiv", "multmse", "alspgrad"}  # Exec:138-147 -> method=:nmf (NMF.jl), not this path
+_default_ctx = {}
+
+
+def _context(device=None):
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if _lib.device_count() > 1 else 0
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx
+
+
+def run_seed(seed, nk, run):
+    """Seed of restart `run` (0-based) of rank nk.  The reference gives restart i the seed kwseed+i (Exec:536)
+    and draws W = rand(n,k) then H = rand(k,m) from Julia's RNG (Mult:38,48); Julia's stream cannot be
+    reproduced here, so a restart is identified by this seed in the library's own counter-based generator."""
+    return (int(seed) * 1000003 + int(nk) * 1009 + int(run) + 1) & 0x7FFFFFFFFFFFFFFF
+
+
+def signalorder(W, H):
+    """Post:148-158: sortperm(rev) of sum(W[:,i:i]*H[i:i,:]) = colsum(W)_i * rowsum(H)_i  (0-based permutation)."""
+    s = np.asarray(W, dtype=np.float32).sum(axis=0) * np.asarray(H, dtype=np.float32).sum(axis=1)
+    return np.argsort(-s, kind="stable")
+
+
+def getk(nkrange, robustness, cutoff=0.5, strict=True):
+    """Post:7-41.  robustness: len(nkrange) values, or the full k-indexed vector (element k-1)."""
+    nkrange = [int(k) for k in nkrange]
+    r = np.asarray(robustness, dtype=np.float64)
+    if len(r) != len(nkrange):
+        r = r[[k - 1 for k in nkrange]]
+    if np.all(np.isnan(r)):
+        return 0
+    if len(nkrange) == 1:
+        if strict:
+            return nkrange[-1] if r[-1] > cutoff else None
+        return nkrange[-1]
+    above = [i for i, v in enumerate(r) if v > cutoff]
+    if not above:
+        if strict:
+            return None
+        return nkrange[int(np.argmax(np.where(np.isnan(r), -np.inf, r)))]
+    return nkrange[above[-1]]
+
+
+def input_checks(X, load, save, casefilename, mixture, method, algorithm, clusterWmatrix, quiet=True):
+    """Exec:95-175 for the part of the option space this path serves."""
+    if load and casefilename == "":
+        casefilename = "nmfk"
+    if save and casefilename == "":
+        casefilename = "nmfk"
+    if mixture not in ("null", None):
+        raise NotImplementedError("mixture != :null (MixMatch, Ipopt) is outside the :simple hot path")
+    if np.ndim(X) > 2:
+        raise ValueError("NMFk analysis can be executed for matrices!")  # ArgumentError, Exec:110-112
+    method = str(method).lstrip(":")
+    if method in _METHOD_ALIASES or method in ("nmf", "sparsity", "ipopt", "nlopt"):
+        if np.isnan(np.asarray(X, dtype=np.float32)).any() and method not in ("ipopt", "nlopt"):
+            warnings.warn(f"Analyzed matrix has NaN's! NMF method {method} cannot be used! "
+                          "Simple multiplicative NMF will be performed!")  # Exec:128-130
+            method = "simple"
+        else:
+            raise NotImplementedError(f"method=:{method} is a different solver; libnmfk_hip implements method=:simple")
+    if method != "simple":
+        raise ValueError(f"Unknown method: {method}")  # Exec:777
+    if clusterWmatrix:
+        raise NotImplementedError("clusterWmatrix=true is not implemented yet (SURVEY.md §8f row 2)")
+    X = np.asarray(X)
+    if X.ndim == 2 and X.shape[0] < X.shape[1] and not quiet:
+        warnings.warn(f"Processed matrix size has more columns than rows (matrix size={X.shape})!")
+    return load, save, casefilename, "null", method, algorithm, clusterWmatrix
+
+
+def _mu_params(kw):
+    """Peels the NMFmultiplicative keyword arguments (Mult:24, Exec:729) out of kw."""
+    names = dict(tol="tol", tolOF="tolOF", maxiter="maxiter", maxreattempts="maxreattempts", maxbaditers="maxbaditers",
+                 stopconv="stopconv", Wfixed="Wfixed", Hfixed="Hfixed", weight="weight")
+    args = {}
+    for key in list(kw):
+        if key in names:
+            args[names[key]] = kw.pop(key)
+        elif key == "lambda_" or key == "lambda":
+            args["lambda_"] = kw.pop(key)
+    if "weight" in args and np.ndim(args["weight"]) != 0:
+        raise NotImplementedError("array-valued weight is not implemented yet (SURVEY.md §8f row 1)")
+    compute = kw.pop("compute", "f32")
+    args["compute"] = {"f32": _lib.COMPUTE_F32, "f64": _lib.COMPUTE_F64}[compute]
+    return args
+
+
+def _sweep(ctx, X, ks, nNMF, kw):
+    """All restarts of all ranks in `ks`: dict k -> dict(W (R,n,k), H (R,k,m), objvalue, iters, reason)."""
+    from . import parallel
+
+    kw = dict(kw)
+    seed = kw.pop("seed", None)
+    Winit, Hinit = kw.pop("Winit", None), kw.pop("Hinit", None)
+    mu = _mu_params(kw)
+    for junk in ("quiet", "veryquiet", "serial", "transpose", "scale", "bootstrap", "normalizevector"):
+        if junk in ("transpose", "scale", "bootstrap") and kw.get(junk):
+            raise NotImplementedError(f"{junk}=true is outside the hot path (default off in the reference, Exec:729)")
+        if junk == "normalizevector" and kw.get(junk) is not None and len(kw[junk]):
+            raise NotImplementedError("normalizevector is not implemented yet (SURVEY.md §8f row 1)")
+        kw.pop(junk, None)
+    if kw:
+        # the reference swallows unknown keywords in NMFmultiplicative's kw... (Mult:24); be loud instead
+        raise TypeError(f"unknown keyword arguments: {sorted(kw)}")
+    modifymatrices = not (mu.get("Wfixed") or mu.get("Hfixed"))  # Exec:486-489 (haskey; we use truthiness)
+    mu["normalize"] = int(modifymatrices)
+    if seed is None:  # global-RNG path of the reference (Random.seed!(s) before execute): numpy's global RNG here
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+    n, m = X.shape
+    wi = hi = None
+    if Winit is not None or Hinit is not None:
+        if len(ks) != 1:
+            raise ValueError("Winit/Hinit can only be given for a single rank")
+        k = ks[0]
+        if Winit is not None:
+            Winit = np.asarray(Winit, dtype=np.float32)
+            assert Winit.shape == (n, k), "size(Winit) == (n, k)"  # Mult:40
+            if np.isnan(Winit).any():
+                raise ValueError("Initial values for the W matrix entries include NaNs!")  # Mult:42-44
+            wi = {k: np.broadcast_to(Winit, (nNMF, n, k))}
+        if Hinit is not None:
+            Hinit = np.asarray(Hinit, dtype=np.float32)
+            assert Hinit.shape == (k, m), "size(Hinit) == (k, m)"  # Mult:50
+            if np.isnan(Hinit).any():
+                raise ValueError("Initial values for the H matrix entries include NaNs!")  # Mult:52-54
+            hi = {k: np.broadcast_to(Hinit, (nNMF, k, m))}
+    params = _lib.default_params(**mu)
+    seeds = np.array([[run_seed(seed, k, r) for r in range(nNMF)] for k in ks], dtype=np.uint64)
+    return parallel.sharded_sweep(ctx.mu_sweep, ks, nNMF, seeds, wi, hi, params, n, m), params
+
+
+def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1, acceptfactor=math.inf, best=True,
+                      nanaction="zeroed", quiet=True):
+    """Everything of execute_run after the restart loop (Exec:545-710)."""
+    n, m = X.shape
+    WBig = [np.array(res["W"][i], dtype=np.float32) for i in range(nNMF)]  # Matrix{T} (Exec:529-531)
+    HBig = [np.array(res["H"][i], dtype=np.float32) for i in range(nNMF)]
+    objvalue = np.asarray(res["objvalue"], dtype=np.float32)
+    idxsort = np.argsort(objvalue, kind="stable")  # Exec:545
+    bestIdx = int(idxsort[0])
+    Wbest, Hbest = WBig[bestIdx].copy(), HBig[bestIdx].copy()
+    idxrat = np.ones(nNMF, dtype=bool)
+    if acceptratio < 1:  # Exec:552-558
+        ccc = int(math.ceil(nNMF * acceptratio))
+        idxrat = np.array([True] * ccc + [False] * (nNMF - ccc))
+        warnings.warn(f"NMF solutions removed based on an acceptance ratio: {idxrat.sum()} out of {nNMF} solutions remain")
+    idxcut = np.ones(nNMF, dtype=bool)
+    if acceptfactor < math.inf:  # Exec:559-565
+        idxcut = objvalue[idxsort] < objvalue[bestIdx] * acceptfactor
+        warnings.warn(f"NMF solutions removed based on an acceptance factor: {idxcut.sum()} out of {nNMF} solutions remain")
+    idxnan = np.ones(nNMF, dtype=bool)
+    nanaction = str(nanaction).lstrip(":")
+    if nanaction == "zeroed":  # Exec:567-580
+        zerod = 0
+        for i in idxsort:
+            isnw, isnh = np.isnan(WBig[i]), np.isnan(HBig[i])
+            WBig[i][isnw] = 0
+            HBig[i][isnh] = 0
+            zerod += bool(isnw.any() or isnh.any())
+        if zerod:
+            warnings.warn(f"NMF solutions contain NaN's: {zerod} out of {nNMF} solutions! NaN's have been converted to zeros!")
+    elif nanaction == "removed":  # Exec:581-595
+        for i in idxsort:
+            if np.isnan(WBig[i]).any() or np.isnan(HBig[i]).any():
+                idxnan[i] = False
+    idxsol = idxrat & idxcut & idxnan  # Exec:596
+    sel = idxsort[idxsol]  # WBig[idxsort][idxsol]
+    minsilhouette = 1.0
+    extra = dict(objvalue=objvalue, idxsort=idxsort, iters=np.asarray(res["iters"]), reason=np.asarray(res["reason"]))
+    Wa = Ha = None
+    if nk > 1:
+        Hs = np.stack([HBig[i] for i in sel])
+        labels, centroids, psil, csil = ctx.cluster_silhouette(Hs)  # Exec:623 + silhouettes of Exec:637
+        Wb0, Hb0 = WBig[bestIdx], HBig[bestIdx]
+        for i, c in enumerate(labels[:, 0]):  # Exec:631-635
+            Wbest[:, i] = Wb0[:, c - 1]
+            Hbest[i, :] = Hb0[c - 1, :]
+        minsilhouette = float(np.min(csil))  # Exec:638
+        extra.update(labels=labels, centroids=centroids, psil=psil, csil=csil)
+        if not best:
+            Ws = np.stack([WBig[i] for i in sel])
+            Wa, Ha, Wv, Hv = ctx.cluster_stats(Ws, Hs, labels)  # Fin:64-77
+            extra.update(Wvar=Wv, Hvar=Hv)
+    elif not best:
+        # Exec:648 -> Fin:114-118: mean(Wa[1]; dims=2), mean(Ha[1]; dims=1) of the first solution
+        Wa = WBig[sel[0]].mean(axis=1, keepdims=True)
+        Ha = HBig[sel[0]].mean(axis=0, keepdims=True)
+    if best:
+        Wa, Ha = Wbest, Hbest  # Exec:655-658
+    phi_final = ctx.frobenius(Wa, Ha)  # Exec:664-667 (E[isnan] = 0 then norm == normnan)
+    phi_final = float(np.float32(phi_final))
+    numobservations = int(X.size - ctx.nan_count)  # Exec:697
+    numparameters = Wa.size + Ha.size
+    aic = 2 * numparameters + numobservations * math.log(phi_final / numobservations) if phi_final > 0 else -math.inf
+    extra.update(Wbest=Wbest, Hbest=Hbest)
+    return Wa, Ha, phi_final, minsilhouette, aic, extra
+
+
+def execute_run(X, nk, nNMF, device=None, return_details=False, **kw):
+    """execute_run(X, nk, nNMF; ...) (Exec:483-711) -> (Wa, Ha, phi_final, minsilhouette, aic)."""
+    X = np.asarray(X)
+    if X.size == 0:
+        raise ValueError(f"Input array has a zero dimension! Array size={X.shape}")
+    ctx = _context(device)
+    ctx.set_X(X, kw.get("lambda_", 1e-32))
+    post = {k: kw.pop(k) for k in ("clusterWmatrix", "acceptratio", "acceptfactor", "best", "nanaction") if k in kw}
+    for k in ("mixture", "resultdir", "casefilename", "loadall", "saveall", "method", "algorithm"):
+        kw.pop(k, None)
+    res, _ = _sweep(ctx, X, [int(nk)], int(nNMF), kw)
+    out = _execute_run_post(ctx, X, int(nk), int(nNMF), res[int(nk)], **post)
+    return out if return_details else out[:5]
+
+
+def _result_filename(resultdir, casefilename, n, m, nk, nNMF):
+    # Exec:265, 324: "<case>_<n>_<m>_<nk>_<nNMF>.jld"; the payload here is .npz with the same keys
+    return os.path.join(resultdir, f"{casefilename}_{n}_{m}_{nk}_{nNMF}.npz")
+
+
+def execute(X, nkrange, nNMF=10, *, cutoff=0.5, clusterWmatrix=False, mixture="null", method="simple",
+            algorithm="multdiv", resultdir=".", load=True, save=True, casefilename="", loadonly=False, quiet=False,
+            check_inputs=True, ordersignals=True, device=None, return_details=False, **kw):
+    """NMFk.execute (Exec:178-233 for a range of k, Exec:236-329 for one k).
+
+    nkrange: an int (-> 5-tuple W, H, fit, robustness, aic) or a range/list (-> 6-tuple with kopt)."""
+    X = np.asarray(X)
+    if X.ndim > 2:
+        raise ValueError("NMFk analysis can be executed for matrices!")
+    if X.size == 0:
+        raise ValueError(f"Input array has a zero dimension! Array size={X.shape}")  # Exec:242-244
+    single = isinstance(nkrange, (int, np.integer))
+    ks = [int(nkrange)] if single else [int(k) for k in nkrange]
+    if loadonly:  # Exec:245-251
+        load, save = True, False
+    load, save, casefilename, mixture, method, algorithm, clusterWmatrix = input_checks(
+        X, load, save, casefilename, mixture, method, algorithm, clusterWmatrix, quiet=quiet)
+    n, m = X.shape
+    maxk = max(ks)
+    W, H = [None] * maxk, [None] * maxk
+    fitquality = np.zeros(maxk, dtype=np.float32)
+    robustness = np.zeros(maxk, dtype=np.float32)
+    aic = np.zeros(maxk, dtype=np.float32)
+    fitquality[0], robustness[0] = np.inf, -1  # Exec:200-201
+    details = {}
+    post = {k: kw.pop(k) for k in ("acceptratio", "acceptfactor", "best", "nanaction") if k in kw}
+    if "Wfixed" in kw or "Hfixed" in kw:  # Exec:305-307
+        ordersignals = False
+
+    todo = []
+    for nk in ks:  # Exec:264-303: per-k result cache
+        fn = _result_filename(resultdir, casefilename, n, m, nk, nNMF)
+        if load and os.path.isfile(fn):
+            with np.load(fn) as z:
+                Wl, Hl = z["W"], z["H"]
+                if Wl.shape == (n, nk) and Hl.shape == (nk, m):
+                    W[nk - 1], H[nk - 1] = Wl, Hl
+                    fitquality[nk - 1], robustness[nk - 1], aic[nk - 1] = z["fit"], z["robustness"], z["aic"]
+                    continue
+        if loadonly:  # Exec:291-298 sentinel
+            W[nk - 1], H[nk - 1] = np.zeros((0, 0), np.float32), np.zeros((0, 0), np.float32)
+            fitquality[nk - 1], robustness[nk - 1], aic[nk - 1] = np.inf, -1, -np.inf
+            continue
+        todo.append(nk)
+
+    ctx = None
+    if todo or not all(np.isinf(fitquality[[k - 1 for k in ks]])):
+        ctx = _context(device)
+        ctx.set_X(X, kw.get("lambda_", 1e-32))  # raises "All matrix entries must be nonnegative!" (Mult:4-7)
+    if todo:
+        res, _ = _sweep(ctx, X, todo, int(nNMF), kw)
+        for nk in todo:
+            Wa, Ha, phi, sil, a, extra = _execute_run_post(ctx, X, nk, int(nNMF), res[nk], clusterWmatrix, quiet=quiet,
+                                                           **post)
+            so = signalorder(Wa, Ha) if ordersignals else np.arange(nk)  # Exec:311-318
+            W[nk - 1], H[nk - 1] = Wa[:, so], Ha[so, :]
+            fitquality[nk - 1], robustness[nk - 1], aic[nk - 1] = phi, sil, a
+            extra["signalorder"] = so
+            details[nk] = extra
+            if not quiet:  # Exec:322
+                print("Signals: %2d Fit: %12.7g Silhouette: %12.7g AIC: %12.7g Signal order: %s" % (nk, phi, sil, a, so + 1))
+            if save:  # Exec:323-327
+                os.makedirs(resultdir, exist_ok=True)
+                np.savez(_result_filename(resultdir, casefilename, n, m, nk, nNMF), W=W[nk - 1], H=H[nk - 1],
+                         fit=fitquality[nk - 1], robustness=robustness[nk - 1], aic=aic[nk - 1])
+    if single:
+        nk = ks[0]
+        out = (W[nk - 1], H[nk - 1], fitquality[nk - 1], robustness[nk - 1], aic[nk - 1])
+        return out + (details.get(nk),) if return_details else out
+
+    if np.all(np.isinf(fitquality[[k - 1 for k in ks]])):  # Exec:206-208
+        warnings.warn("No successful NMFk runs!")
+        kopt = 0
+    else:
+        for nk in ks:  # Exec:211-224
+            fit = ctx.frobenius(W[nk - 1], H[nk - 1]) if W[nk - 1].size else np.inf
+            if abs(fit - fitquality[nk - 1]) > np.finfo(np.float16).eps:
+                warnings.warn(f"Fit quality is not consistent: {fit} != {fitquality[nk - 1]}")
+            fitquality[nk - 1] = fit
+            if not quiet:
+                print("Signals: %2d Fit: %12.7g Silhouette: %12.7g AIC: %12.7g" % (nk, fitquality[nk - 1],
+                                                                                   robustness[nk - 1], aic[nk - 1]))
+        kopt = getk(ks, robustness[[k - 1 for k in ks]], cutoff)  # Exec:225
+    out = (W, H, fitquality, robustness, aic, kopt)
+    return out + (details,) if return_details else out

@@ -1,0 +1,103 @@
+"""CPU-only tests of the product's host side: the C-ABI library loads and exports every symbol the header
+declares, fails loudly without a GPU, and the host logic (getk, signalorder, input checks) mirrors the reference."""
+import re
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def NMFk():
+    import nmfk_jl_amd
+
+    nmfk_jl_amd.build()
+    return nmfk_jl_amd
+
+
+def test_library_exports_every_declared_symbol(NMFk):
+    import ctypes
+
+    from importlib import import_module
+
+    _lib = import_module("nmfk_jl_amd._lib")
+    text = open(_lib.HEADER_PATH).read()
+    declared = sorted(set(re.findall(r"^(?:int|const char \*)\s*(nmfk_[a-z_0-9A-Z]+)\s*\(", text, flags=re.M)))
+    assert len(declared) >= 15
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} is declared in include/nmfk_hip.h but not exported"
+    assert NMFk.lib().nmfk_version() >= 100
+
+
+def test_no_cpu_fallback(NMFk):
+    if NMFk.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(NMFk.NMFkError) as e:
+        NMFk.Context(0)
+    assert e.value.code == 7 and "no CPU fallback" in str(e.value)
+    with pytest.raises(NMFk.NMFkError):
+        NMFk.execute(np.ones((4, 3), np.float32), range(2, 3), 2, load=False, save=False)
+
+
+def test_params_struct_matches_header(NMFk):
+    p = NMFk.default_params()
+    assert (p.tol, p.tolOF, p.lambda_, p.weight) == (1e-19, 1e-3, 1e-32, 1.0)
+    assert (p.maxiter, p.maxreattempts, p.maxbaditers, p.stopconv) == (10000, 2, 10, 1000)
+    assert (p.Wfixed, p.Hfixed, p.normalize, p.compute) == (0, 0, 1, 0)
+    with pytest.raises(TypeError):
+        NMFk.default_params(nonsense=1)
+
+
+def test_product_never_imports_the_oracle():
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "nmfk.jl_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().lower().replace(
+                    "cpu oracle", "").replace("oracle's", "").replace("oracle/nmfk_oracle.c", "").replace(
+                    "the oracle", ""), f
+
+
+def test_getk_matches_reference_rules(NMFk, oracle):
+    cases = [(range(2, 6), [0.99, 0.85, -0.57, -0.67], {}), (range(2, 5), [0.1, 0.2, 0.3], {}),
+             (range(2, 5), [0.1, 0.2, 0.3], dict(strict=False)), (range(2, 5), [np.nan] * 3, {}), ([3], [0.6], {}),
+             ([3], [0.4], {}), ([3], [0.4], dict(strict=False)), (range(2, 5), [0.6, 0.5, 0.7], {}),
+             (range(2, 4), [-1, 0.9, 0.2], {}), (range(2, 5), [0.6, np.nan, 0.2], dict(strict=False))]
+    for nkrange, rob, kw in cases:
+        assert NMFk.getk(nkrange, rob, **kw) == oracle.getk(nkrange, rob, **kw)
+    assert NMFk.getk(range(2, 6), [0.99, 0.85, -0.57, -0.67]) == 3
+
+
+def test_signalorder(NMFk, oracle):
+    rng = np.random.default_rng(0)
+    W, H = rng.random((9, 4)), rng.random((4, 6))
+    so = NMFk.signalorder(W, H)
+    assert (so == oracle.signalorder(W, H)).all()
+    contrib = [float((W[:, i:i + 1] @ H[i:i + 1, :]).sum()) for i in range(4)]  # Post:153 literally
+    assert list(so) == list(np.argsort(-np.array(contrib), kind="stable"))
+
+
+def test_input_checks(NMFk):
+    X = np.ones((5, 4), np.float32)
+    # test/test_input_checks.jl family: casefilename defaulting, method aliases are a different solver
+    load, save, case, mixture, method, algorithm, cw = NMFk.input_checks(X, True, False, "", "null", "simple", "multdiv", False)
+    assert case == "nmfk" and method == "simple"
+    for alias in ("multdiv", "multmse", "alspgrad", "nmf", "sparsity", "ipopt"):
+        with pytest.raises(NotImplementedError):
+            NMFk.input_checks(X, False, False, "", "null", alias, "multdiv", False)
+    with pytest.raises(ValueError, match="Unknown method"):
+        NMFk.input_checks(X, False, False, "", "null", "bogus", "multdiv", False)
+    with pytest.raises(ValueError, match="can be executed for matrices"):
+        NMFk.input_checks(np.ones((2, 2, 2)), False, False, "", "null", "simple", "multdiv", False)
+    Xn = X.copy()
+    Xn[0, 0] = np.nan
+    with pytest.warns(UserWarning, match="Simple multiplicative NMF will be performed"):
+        out = NMFk.input_checks(Xn, False, False, "", "null", "multdiv", "multdiv", False)
+    assert out[4] == "simple"
+
+
+def test_run_seed_shared_with_oracle(NMFk, oracle):
+    for args in [(0, 2, 0), (2021, 5, 9), (2 ** 40, 64, 31)]:
+        assert NMFk.run_seed(*args) == oracle.run_seed(*args)

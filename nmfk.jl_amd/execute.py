@@ -248,10 +248,12 @@ def _result_filename(resultdir, casefilename, n, m, nk, nNMF):
 
 def execute(X, nkrange, nNMF=10, *, cutoff=0.5, clusterWmatrix=False, mixture="null", method="simple",
             algorithm="multdiv", resultdir=".", load=True, save=True, casefilename="", loadonly=False, quiet=False,
-            check_inputs=True, ordersignals=True, device=None, return_details=False, **kw):
+            check_inputs=True, ordersignals=True, device=None, ctx=None, return_details=False, **kw):
     """NMFk.execute (Exec:178-233 for a range of k, Exec:236-329 for one k).
 
-    nkrange: an int (-> 5-tuple W, H, fit, robustness, aic) or a range/list (-> 6-tuple with kopt)."""
+    nkrange: an int (-> 5-tuple W, H, fit, robustness, aic) or a range/list (-> 6-tuple with kopt).
+    ctx: an nmfk Context on which set_X(X) has ALREADY been called (X resident in HBM, e.g. for repeated sweeps);
+    by default the per-device context is used and X is uploaded here."""
     X = np.asarray(X)
     if X.ndim > 2:
         raise ValueError("NMFk analysis can be executed for matrices!")
@@ -291,8 +293,7 @@ def execute(X, nkrange, nNMF=10, *, cutoff=0.5, clusterWmatrix=False, mixture="n
             continue
         todo.append(nk)
 
-    ctx = None
-    if todo or not all(np.isinf(fitquality[[k - 1 for k in ks]])):
+    if ctx is None and (todo or not all(np.isinf(fitquality[[k - 1 for k in ks]]))):
         ctx = _context(device)
         ctx.set_X(X, kw.get("lambda_", 1e-32))  # raises "All matrix entries must be nonnegative!" (Mult:4-7)
     if todo:

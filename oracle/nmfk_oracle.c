@@ -132,7 +132,7 @@ EXPORT int nmfk_or_multiplicative(double *X, int64_t n, int64_t m, int64_t k, co
                                   double *H, double *sse_out, int64_t *iters_out, int32_t *reason_out,
                                   int32_t *nchecks_out, double *objtrace /* may be NULL; len maxiter/10 */) {
 #ifdef _OPENMP
-  if (P->nthreads > 0) omp_set_num_threads(P->nthreads);
+  omp_set_num_threads(P->nthreads > 0 ? P->nthreads : 1);
 #endif
   int64_t N = n * m;
   uint8_t *inan = (uint8_t *)malloc(N), *izero = (uint8_t *)malloc(N);

@@ -32,8 +32,9 @@ class Params(C.Structure):
 
 
 def make_params(tol=1e-19, tolOF=1e-3, lambda_=1e-32, weight=1.0, maxiter=10000, maxreattempts=2, maxbaditers=10,
-                stopconv=1000, Wfixed=False, Hfixed=False, tbits=64, nthreads=0):
-    """Defaults: Exec:729 (maxiter, tol) and Mult:24 (the rest)."""
+                stopconv=1000, Wfixed=False, Hfixed=False, tbits=64, nthreads=1):
+    """Defaults: Exec:729 (maxiter, tol) and Mult:24 (the rest).  nthreads: OpenMP threads of the C loops (results do
+    not depend on it); 1 by default because a thread team per tiny loop is ruinous on many-core hosts."""
     return Params(tol, tolOF, lambda_, float(weight), int(maxiter), maxreattempts, maxbaditers, stopconv, int(Wfixed),
                   int(Hfixed), tbits, nthreads)
 

@@ -2,7 +2,8 @@
 Run on the GPU box:  python -m pytest tests -m gpu -x -q
 
 Tolerances: fixed iteration budget from identical initial factors:
-  fp64 compute mode  : ||WH_gpu - WH_oracle||_F / ||X||_F <= 1e-9  (same arithmetic, different summation order)
+  fp64 compute mode  : ||WH_gpu - WH_oracle||_F / ||X||_F <= 3e-7  (same arithmetic; the results are stored as
+                       Float32 like the reference's WBig::Vector{Matrix{T}}, Exec:529-531 => one fp32 rounding)
   fp32 compute mode  : <= 1e-4 on the reconstruction, objective rel. diff <= 1e-4 (the reference's own
                        self-check threshold, Exec:604)
 Cluster silhouettes: abs diff <= 1e-3, labels identical; kopt identical."""
@@ -52,7 +53,7 @@ def test_rng_bit_exact(ctx, oracle):
         assert (g.astype(np.float64) == o).all()
 
 
-@pytest.mark.parametrize("compute,tol", [("f64", 1e-9), ("f32", 1e-4)])
+@pytest.mark.parametrize("compute,tol", [("f64", 3e-7), ("f32", 1e-4)])
 @pytest.mark.parametrize("shape,k", [((64, 32), 3), ((15, 5), 2), ((300, 70), 7), ((257, 129), 16), ((40, 33), 1)])
 def test_fixed_budget_matches_oracle(NMFk, ctx, oracle, compute, tol, shape, k):
     n, m = shape
@@ -84,7 +85,7 @@ def test_padded_ranks(NMFk, ctx, oracle, k):
         W0, H0 = oracle.init_factors(int(seeds[0, r]), n, m, k)
         ref = oracle.singlerun(X, k, W0, H0, maxiter=30, **NOSTOP)
         assert res["W"][r].shape == (n, k) and res["H"][r].shape == (k, m)
-        assert _rel(res["W"][r] @ res["H"][r], ref["W"] @ ref["H"], X) <= 1e-9
+        assert _rel(res["W"][r] @ res["H"][r], ref["W"] @ ref["H"], X) <= 3e-7
 
 
 def test_stop_rule_fp64_identical_iterations(NMFk, ctx, oracle, bss_X):
@@ -120,13 +121,13 @@ def test_stop_by_tolerance_and_maxiter_not_multiple_of_ten(NMFk, ctx, oracle):
     assert (res["iters"] == 37).all() and (res["reason"] == NMFk.STOP_MAXITER).all()
     W0, H0 = oracle.init_factors(int(seeds[0, 0]), n, m, k)
     ref = oracle.singlerun(X, k, W0, H0, maxiter=37)
-    assert _rel(res["W"][0] @ res["H"][0], ref["W"] @ ref["H"], X) <= 1e-9
+    assert _rel(res["W"][0] @ res["H"][0], ref["W"] @ ref["H"], X) <= 3e-7
     # tol stop (Mult:75-78): a huge tol fires at the first check, before the clamp
     res = ctx.mu_sweep([k], 2, seeds=seeds, tol=1e9, compute=NMFk.COMPUTE_F64)[k]
     assert (res["iters"] == 10).all() and (res["reason"] == NMFk.STOP_TOL).all()
     ref = oracle.singlerun(X, k, W0, H0, tol=1e9)
     assert ref["iters"] == 10 and ref["reason"] == oracle.STOP_TOL
-    assert _rel(res["W"][0] @ res["H"][0], ref["W"] @ ref["H"], X) <= 1e-9
+    assert _rel(res["W"][0] @ res["H"][0], ref["W"] @ ref["H"], X) <= 3e-7
 
 
 @pytest.mark.parametrize("compute,tol", [("f64", 1e-7), ("f32", 2e-4)])
@@ -136,7 +137,8 @@ def test_missing_data_imputation(NMFk, ctx, oracle, compute, tol):
     X = oracle.uniform_fill(21, 0, n * m).reshape(n, m).astype(np.float32)
     mask = oracle.uniform_fill(22, 0, n * m).reshape(n, m) < 0.2
     X[mask] = np.nan
-    X[3, 4] = 0.0
+    i0, j0 = np.argwhere(~mask)[7]
+    X[i0, j0] = 0.0
     ctx.set_X(X)
     assert ctx.nan_count == int(mask.sum()) and ctx.zero_count == 1
     seeds = _seeds(NMFk, 7, [k], 2)
@@ -308,7 +310,7 @@ def test_config2_size_fixed_budget(NMFk, ctx, oracle):
     seeds = _seeds(NMFk, 1, [k], 1)
     res = ctx.mu_sweep([k], 1, seeds=seeds, maxiter=20, **NOSTOP)[k]
     W0, H0 = oracle.init_factors(int(seeds[0, 0]), n, m, k)
-    ref = oracle.singlerun(np.asfortranarray(X), k, W0, H0, maxiter=20, **NOSTOP)
+    ref = oracle.singlerun(np.asfortranarray(X), k, W0, H0, maxiter=20, nthreads=8, **NOSTOP)
     assert _rel(res["W"][0] @ res["H"][0], ref["W"] @ ref["H"], X) <= 1e-4
     assert abs(res["objvalue"][0] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
 

@@ -21,6 +21,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # one HW queue per concurrently running rank group (before HIP init)
+
 import numpy as np
 
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
@@ -148,7 +150,8 @@ def main():
                 # algorithmic bytes of one half-step: one pass over X per active restart (2*n*m*4 per iteration)
                 bytes_alg = sum(float(np.sum(iters_by_k[k])) for k in ks) * args.n * args.m * 4.0 * args.steps / max(world, 1)
                 line["roofline"] = {
-                    "kernel": dom + " (step_kernel)", "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
+                    "kernel": dom + " (step_kernel<KP>, sampled launches, rank groups run concurrently)", "bound": "mfma",
+                    "achieved": tf, "peak": PEAK_FP32_TFLOPS,
                     "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS, "traffic": None,
                     "avg_launch_ms": p["ms"] / p["launches"], "launches": p["launches"],
                     "note": "fp32 FMA work 4*n*m*k flop per half-step per active restart; fp32 vector and fp32 MFMA share "

@@ -6,8 +6,13 @@ import subprocess
 
 import numpy as np
 
+# The sweep runs one stream per rank k; ROCm maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4),
+# and kernels that share a queue serialise.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("NMFK_STREAMS", "16")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnmfk_hip.so")
+LIB_PATH = os.environ.get("NMFK_HIP_LIB", os.path.join(_HERE, "libnmfk_hip.so"))  # override: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nmfk_hip.h")
 
 NMFK_OK = 0

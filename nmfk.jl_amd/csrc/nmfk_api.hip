@@ -9,6 +9,7 @@
 // later, so the queue stays full.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -69,6 +70,8 @@ const char *const kProfNames[PK_COUNT] = {"mu_h_numerators", "mu_h_finish", "mu_
 struct nmfk_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  std::vector<hipStream_t> gstreams;  // one per concurrently running rank group of a sweep
+  hipStream_t poll_stream = nullptr;  // copies the unit states back without blocking the compute streams
   hipDeviceProp_t prop;
   // data
   int64_t n = 0, m = 0;
@@ -109,35 +112,39 @@ int ensure_pinned(nmfk_ctx *ctx, size_t bytes) {
   return 0;
 }
 
-struct Marks {
+// HIP-event timing of sampled half-step launches, each on the stream it runs on.
+struct Sample {
+  int kind, group, it;
+  size_t e0, e1;
+};
+struct Sampler {
   nmfk_ctx *ctx;
-  std::vector<int> kinds;
+  std::vector<Sample> samples;
   size_t used = 0;
   bool on;
-  explicit Marks(nmfk_ctx *c) : ctx(c), on(c->profiling) {}
-  // record "a kernel of class `kind` ends here"
-  void mark(int kind) {
-    if (!on) return;
+  explicit Sampler(nmfk_ctx *c) : ctx(c), on(c->profiling) {}
+  size_t event() {
     if (used == ctx->events.size()) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) {
         on = false;
-        return;
+        return 0;
       }
       ctx->events.push_back(e);
     }
-    (void)hipEventRecord(ctx->events[used++], ctx->stream);
-    kinds.push_back(kind);
+    return used++;
   }
-  void resolve() {
-    if (!on || used < 2) return;
-    for (size_t i = 1; i < used; ++i) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ctx->events[i - 1], ctx->events[i]) == hipSuccess) {
-        ctx->prof_ms[kinds[i]] += ms;
-        ctx->prof_launches[kinds[i]] += 1;
-      }
-    }
+  bool want(int it) const { return on && (it % 8) == 0; }
+  size_t begin(hipStream_t s) {
+    const size_t e = event();
+    if (on) (void)hipEventRecord(ctx->events[e], s);
+    return e;
+  }
+  void end(size_t e0, int kind, int group, int it, hipStream_t s) {
+    const size_t e1 = event();
+    if (!on) return;
+    (void)hipEventRecord(ctx->events[e1], s);
+    samples.push_back({kind, group, it, e0, e1});
   }
 };
 
@@ -205,6 +212,8 @@ NMFK_EXPORT int nmfk_destroy(nmfk_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+  for (hipStream_t gs : ctx->gstreams) (void)hipStreamDestroy(gs);
+  if (ctx->poll_stream) (void)hipStreamDestroy(ctx->poll_stream);
   if (ctx->Xc) (void)hipFree(ctx->Xc);
   if (ctx->Xr) (void)hipFree(ctx->Xr);
   ctx->arena.release();
@@ -335,33 +344,51 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   for (int q = 0; q < nk; ++q) order[q] = q;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ks[a] > ks[b]; });
 
-  // loop-dimension splits: aim at >= 4 workgroups per CU per launch
+  // Launch geometry of the two half-steps (see step_body): wsplit = 1 when the lane dimension alone fills the
+  // chip, else the four waves of a workgroup share 64*LB lane elements and split the loop range; grid-level
+  // splits S > 1 (finished by the reduce kernel) only when there are too few units to fill the chip otherwise.
   const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-  const int target = 4 * cus;
-  const int tiles_m = (m + NMFK_TILE - 1) / NMFK_TILE, tiles_n = (n + NMFK_TILE - 1) / NMFK_TILE;
-  auto splits = [&](int tiles, int D) {
-    int64_t have = (int64_t)tiles * nunits;
-    int S = (int)((target + have - 1) / have);
-    int maxS = std::max(1, D / 64);
-    S = std::max(1, std::min(S, maxS));
-    return S;
+  const int target = 2 * cus;
+  struct Geo {
+    int wsplit, S, dchunk, fused, slots;
   };
-  const int Sh = splits(tiles_m, n), Sw = splits(tiles_n, m);
-  const int dchunk_h = (n + Sh - 1) / Sh, dchunk_w = (m + Sw - 1) / Sw;
+  auto geometry = [&](int L, int D) {
+    Geo g;
+    auto tiles = [&](int ws, int lb) { const int per = (ws == 4 ? 64 : NMFK_TILE) * lb; return (L + per - 1) / per; };
+    g.wsplit = ((int64_t)tiles(1, NMFK_LB) * nunits >= target) ? 1 : 4;
+    const int64_t have = (int64_t)tiles(g.wsplit, NMFK_LB) * nunits;
+    int S = (int)((target + have - 1) / have);
+    const int maxS = std::max(1, D / (g.wsplit == 4 ? 256 : 64));
+    g.S = std::max(1, std::min(S, maxS));
+    g.dchunk = (D + g.S - 1) / g.S;
+    g.fused = g.S == 1;
+    g.slots = tiles(g.wsplit, 1);  // units with kp > 16 use one lane element per thread => the most tiles
+    return g;
+  };
+  const Geo gh = geometry(m, n), gw = geometry(n, m);
+  const int Sh = gh.S, Sw = gw.S;
+  const int PH = gh.slots, PW = gw.slots;  // slots of the sum tables: rowsum(H) is produced by the H half-step
+  const int tiles_n = (n + NMFK_TILE - 1) / NMFK_TILE;  // objective kernel tiles
 
   // arena layout
   Bump B;
   const size_t o_runs = B.take(sizeof(NmfkRun) * nunits);
   const size_t o_state = B.take(sizeof(NmfkState) * nunits);
   const size_t o_flag = B.take(256);
+  const size_t o_args = B.take(2 * sizeof(NmfkStepArgs));
   const size_t o_ptrs = B.take(sizeof(void *) * 7 * nk);
   std::vector<NmfkRun> runs(nunits);
   std::vector<size_t> o_Wi(nk, 0), o_Hi(nk, 0), o_Wo(nk), o_Ho(nk), o_frob(nk), o_iters(nk), o_reason(nk);
-  int nlarge = 0;
+  struct Group {
+    int k, kp, begin, count;
+  };
+  std::vector<Group> groups;  // contiguous unit range per rank (units are sorted by k descending)
   {
     int u = 0;
     for (int oi = 0; oi < nk; ++oi) {
       const int q = order[oi], k = ks[q], kp = nmfk_padded_k(k);
+      if (groups.empty() || groups.back().k != k) groups.push_back({k, kp, u, 0});
+      groups.back().count += nruns;
       for (int r = 0; r < nruns; ++r, ++u) {
         NmfkRun &rd = runs[u];
         rd.k = k;
@@ -373,12 +400,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         rd.oH1 = P.Hfixed ? rd.oH0 : (int64_t)B.take(tsz * (size_t)kp * m);
         const size_t pe = std::max((size_t)Sh * kp * m, (size_t)Sw * kp * n);
         rd.opart = (int64_t)B.take(std::max(tsz * pe, sizeof(int32_t) * (size_t)m));
-        rd.osumW = (int64_t)B.take(tsz * kp);
-        rd.osumH = (int64_t)B.take(tsz * kp);
+        rd.osumW = (int64_t)B.take(sizeof(double) * (size_t)PW * kp);
+        rd.osumH = (int64_t)B.take(sizeof(double) * (size_t)PH * kp);
         rd.ossepart = (int64_t)B.take(sizeof(double) * tiles_n);
         rd.ocanon = (int64_t)B.take(sizeof(int32_t) * (size_t)m);
         rd.seed = seeds ? seeds[(size_t)q * nruns + r] : 0;
-        if (kp > 16) nlarge = u + 1;
       }
     }
   }
@@ -424,8 +450,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   NmfkState *d_state = (NmfkState *)(A + o_state);
   void **d_ptrs = (void **)(A + o_ptrs);
 
-  Marks marks(ctx);
-  marks.mark(PK_OTHER);
+  Sampler prof(ctx);
 
   NmfkInitArgs ia;
   ia.arena = A;
@@ -436,13 +461,14 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ia.nunits = nunits;
   ia.Winit = (const float *const *)(d_ptrs + 0 * nk);
   ia.Hinit = (const float *const *)(d_ptrs + 1 * nk);
+  ia.PW = PW;
+  ia.PH = PH;
   ia.nan_flag = (int32_t *)(A + o_flag);
   if (f64)
     nmfk_launch_init_f64(ia, st);
   else
     nmfk_launch_init_f32(ia, st);
   HIPCHECK(hipGetLastError());
-  marks.mark(PK_OTHER);
   {
     int32_t flag = 0;
     HIPCHECK(hipMemcpyAsync(&flag, A + o_flag, sizeof(flag), hipMemcpyDeviceToHost, st));
@@ -457,7 +483,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   hs.L = m;
   hs.D = n;
   hs.S = Sh;
-  hs.dchunk = dchunk_h;
+  hs.dchunk = gh.dchunk;
+  hs.wsplit = gh.wsplit;
+  hs.fused = gh.fused;
+  hs.PW = PW;
+  hs.PH = PH;
   hs.which = 0;
   hs.it = 0;
   hs.has_nan = ctx->nan_count > 0;
@@ -465,7 +495,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   hs.runs = d_runs;
   hs.state = d_state;
   hs.nunits = nunits;
-  hs.nlarge = nlarge;
   hs.force = 0;
   NmfkStepArgs ws = hs;
   ws.X = ctx->Xc;
@@ -473,8 +502,17 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ws.L = n;
   ws.D = m;
   ws.S = Sw;
-  ws.dchunk = dchunk_w;
+  ws.dchunk = gw.dchunk;
+  ws.wsplit = gw.wsplit;
+  ws.fused = gw.fused;
   ws.which = 1;
+
+  // device copies of the two half-step argument blocks (constant over the sweep; `it` is passed by value)
+  const NmfkStepArgs *d_hs = (const NmfkStepArgs *)(A + o_args), *d_ws = d_hs + 1;
+  {
+    NmfkStepArgs both[2] = {hs, ws};
+    HIPCHECK(hipMemcpy(A + o_args, both, sizeof(both), hipMemcpyHostToDevice));
+  }
 
   NmfkSseArgs sa;
   sa.arena = A;
@@ -495,6 +533,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ca.m = m;
   ca.it = 0;
   ca.ntile_n = tiles_n;
+  ca.PW = PW;
+  ca.PH = PH;
   ca.tol = P.tol;
   ca.tolOF = P.tolOF;
   ca.maxiter = P.maxiter;
@@ -505,57 +545,85 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ca.state = d_state;
   ca.nunits = nunits;
 
+  // Rank groups run concurrently: group j owns stream j mod NS.  Inside a group the order H half-step ->
+  // W half-step -> (every 10th iteration) objective + check block is the stream order; different ranks never
+  // exchange data before the clustering step, so no cross-stream synchronisation is needed inside the loop.
+  const int ngroups = (int)groups.size();
+  int max_streams = 8;
+  if (const char *e = getenv("NMFK_STREAMS")) max_streams = std::max(1, std::min(64, atoi(e)));
+  const int NS = std::min(ngroups, max_streams);
+  while ((int)ctx->gstreams.size() < NS) {
+    hipStream_t gs;
+    HIPCHECK(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+    ctx->gstreams.push_back(gs);
+  }
+  if (!ctx->poll_stream) HIPCHECK(hipStreamCreateWithFlags(&ctx->poll_stream, hipStreamNonBlocking));
+  hipStream_t poll = ctx->poll_stream;
+  std::vector<hipEvent_t> gev(2 * (size_t)NS);
+  for (auto &e : gev) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipEvent_t snap_ev[2], start_ev;
+  HIPCHECK(hipEventCreateWithFlags(&snap_ev[0], hipEventDisableTiming));
+  HIPCHECK(hipEventCreateWithFlags(&snap_ev[1], hipEventDisableTiming));
+  HIPCHECK(hipEventCreateWithFlags(&start_ev, hipEventDisableTiming));
+  HIPCHECK(hipEventRecord(start_ev, st));  // init done
+  for (int j = 0; j < NS; ++j) HIPCHECK(hipStreamWaitEvent(ctx->gstreams[j], start_ev, 0));
+
   // Mult:64 guard before the first iteration
   const bool guard0 = P.maxiter > 0 && P.maxbaditers > 0 && P.maxreattempts > 0;
   NmfkState *snap[2] = {(NmfkState *)ctx->pinned, (NmfkState *)ctx->pinned + nunits};
-  hipEvent_t snap_ev[2];
-  HIPCHECK(hipEventCreateWithFlags(&snap_ev[0], hipEventDisableTiming));
-  HIPCHECK(hipEventCreateWithFlags(&snap_ev[1], hipEventDisableTiming));
   int total_iters = 0;
   int nchecks = 0;
   bool all_done = !guard0;
   const int maxiter = guard0 ? (int)P.maxiter : 0;
   for (int it = 0; it < maxiter && !all_done; ++it) {
-    if (!P.Hfixed) {  // Mult:66-68
-      hs.it = it;
-      if (f64) {
-        nmfk_launch_step_f64(hs, st);
-        marks.mark(PK_HSTEP);
-        nmfk_launch_reduce_f64(hs, st);
-      } else {
-        nmfk_launch_step_f32(hs, st);
-        marks.mark(PK_HSTEP);
-        nmfk_launch_reduce_f32(hs, st);
+    const bool check = (it + 1) % 10 == 0;  // Mult:73
+    const bool timed = prof.want(it);
+    hs.it = ws.it = it;
+    sa.hsel = (it + 1) & 1;
+    ca.it = it;
+    for (int j = 0; j < ngroups; ++j) {
+      const Group &G = groups[j];
+      hipStream_t gs = ctx->gstreams[j % NS];
+      if (!P.Hfixed) {  // Mult:66-68
+        const size_t e0 = timed ? prof.begin(gs) : 0;
+        if (f64)
+          nmfk_launch_step_f64(hs, d_hs, G.kp, G.begin, G.count, gs);
+        else
+          nmfk_launch_step_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
+        if (timed) prof.end(e0, PK_HSTEP, j, it, gs);
+        if (!hs.fused) {
+          if (f64)
+            nmfk_launch_reduce_f64(hs, G.begin, G.count, gs);
+          else
+            nmfk_launch_reduce_f32(hs, G.begin, G.count, gs);
+        }
       }
-      marks.mark(PK_HRED);
-    }
-    if (!P.Wfixed) {  // Mult:69-71
-      ws.it = it;
-      if (f64) {
-        nmfk_launch_step_f64(ws, st);
-        marks.mark(PK_WSTEP);
-        nmfk_launch_reduce_f64(ws, st);
-      } else {
-        nmfk_launch_step_f32(ws, st);
-        marks.mark(PK_WSTEP);
-        nmfk_launch_reduce_f32(ws, st);
+      if (!P.Wfixed) {  // Mult:69-71
+        const size_t e0 = timed ? prof.begin(gs) : 0;
+        if (f64)
+          nmfk_launch_step_f64(ws, d_ws, G.kp, G.begin, G.count, gs);
+        else
+          nmfk_launch_step_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
+        if (timed) prof.end(e0, PK_WSTEP, j, it, gs);
+        if (!ws.fused) {
+          if (f64)
+            nmfk_launch_reduce_f64(ws, G.begin, G.count, gs);
+          else
+            nmfk_launch_reduce_f32(ws, G.begin, G.count, gs);
+        }
       }
-      marks.mark(PK_WRED);
+      if (check) {
+        if (f64) {
+          nmfk_launch_sse_f64(sa, G.begin, G.count, gs);
+          nmfk_launch_check_f64(ca, G.begin, G.count, gs);
+        } else {
+          nmfk_launch_sse_f32(sa, G.begin, G.count, gs);
+          nmfk_launch_check_f32(ca, G.begin, G.count, gs);
+        }
+      }
     }
     total_iters = it + 1;
-    if ((it + 1) % 10 == 0) {  // Mult:73
-      sa.hsel = (it + 1) & 1;
-      ca.it = it;
-      if (f64) {
-        nmfk_launch_sse_f64(sa, st);
-        marks.mark(PK_SSE);
-        nmfk_launch_check_f64(ca, st);
-      } else {
-        nmfk_launch_sse_f32(sa, st);
-        marks.mark(PK_SSE);
-        nmfk_launch_check_f32(ca, st);
-      }
-      marks.mark(PK_CHECK);
+    if (check) {
       const int slot = nchecks & 1;
       if (nchecks > 0) {  // inspect the PREVIOUS check while this one is still queued
         HIPCHECK(hipEventSynchronize(snap_ev[slot ^ 1]));
@@ -563,12 +631,22 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         for (int u = 0; u < nunits; ++u) any = any || snap[slot ^ 1][u].active;
         if (!any) all_done = true;
       }
-      HIPCHECK(hipMemcpyAsync(snap[slot], d_state, sizeof(NmfkState) * nunits, hipMemcpyDeviceToHost, st));
-      HIPCHECK(hipEventRecord(snap_ev[slot], st));
+      for (int j = 0; j < NS; ++j) {
+        HIPCHECK(hipEventRecord(gev[slot * NS + j], ctx->gstreams[j]));
+        HIPCHECK(hipStreamWaitEvent(poll, gev[slot * NS + j], 0));
+      }
+      HIPCHECK(hipMemcpyAsync(snap[slot], d_state, sizeof(NmfkState) * nunits, hipMemcpyDeviceToHost, poll));
+      HIPCHECK(hipEventRecord(snap_ev[slot], poll));
       nchecks++;
     }
   }
   HIPCHECK(hipGetLastError());
+  // join: the main stream continues after every group stream (and the poll stream) has drained
+  for (int j = 0; j < NS; ++j) {
+    HIPCHECK(hipEventRecord(gev[j], ctx->gstreams[j]));
+    HIPCHECK(hipStreamWaitEvent(st, gev[j], 0));
+  }
+  HIPCHECK(hipStreamSynchronize(poll));
 
   // objvalue = normnan(X - W*H) on the final factors, normalisation, T-typed outputs (Exec:790-805)
   sa.hsel = -1;
@@ -591,13 +669,12 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   fa.iters = (int32_t *const *)(d_ptrs + 5 * nk);
   fa.reason = (int32_t *const *)(d_ptrs + 6 * nk);
   if (f64) {
-    nmfk_launch_sse_f64(sa, st);
+    nmfk_launch_sse_f64(sa, 0, nunits, st);
     nmfk_launch_finish_f64(fa, st);
   } else {
-    nmfk_launch_sse_f32(sa, st);
+    nmfk_launch_sse_f32(sa, 0, nunits, st);
     nmfk_launch_finish_f32(fa, st);
   }
-  marks.mark(PK_OTHER);
   HIPCHECK(hipGetLastError());
 
   std::vector<std::vector<float>> h_frob(nk);
@@ -619,6 +696,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   HIPCHECK(hipStreamSynchronize(st));
   (void)hipEventDestroy(snap_ev[0]);
   (void)hipEventDestroy(snap_ev[1]);
+  (void)hipEventDestroy(start_ev);
+  for (auto &e : gev) (void)hipEventDestroy(e);
 
   // Mult:125: sum(((X - W*H) .* weight)[.!inan].^2) = (weight * normnan(X - W*H))^2 for a scalar weight.
   // sse_out may be device memory: stage through a host vector.
@@ -634,15 +713,20 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     }
   }
 
-  marks.resolve();
+  // sampled launches: duration on their own stream (other rank groups run concurrently) and the algorithmic
+  // work of exactly the units that were still active at that iteration (lock-step => active iff it < iters)
   if (ctx->profiling) {
-    for (int q = 0; q < nk; ++q)
-      for (int r = 0; r < nruns; ++r) {
-        const double step = 4.0 * n * (double)m * ks[q] * (double)h_iters[q][r];  // W*H + the product with the ratio
-        if (!P.Hfixed) ctx->prof_flops[PK_HSTEP] += step;
-        if (!P.Wfixed) ctx->prof_flops[PK_WSTEP] += step;
-        ctx->prof_flops[PK_SSE] += 2.0 * n * (double)m * ks[q] * (double)(h_iters[q][r] / 10);
-      }
+    for (const Sample &sm : prof.samples) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->events[sm.e0], ctx->events[sm.e1]) != hipSuccess) continue;
+      const Group &G = groups[sm.group];
+      int active = 0;
+      for (int u = G.begin; u < G.begin + G.count; ++u)
+        active += sm.it < h_iters[runs[u].kidx][runs[u].ridx] ? 1 : 0;
+      ctx->prof_ms[sm.kind] += ms;
+      ctx->prof_launches[sm.kind] += 1;
+      ctx->prof_flops[sm.kind] += 4.0 * n * (double)m * G.k * active;  // W*H + the product with the ratio
+    }
   }
   return NMFK_OK;
 }

@@ -18,8 +18,8 @@ struct NmfkRun {
   int64_t oWt;       // T[kp*n]
   int64_t oH0, oH1;  // T[kp*m] x2, double-buffered by iteration parity (equal when Hfixed)
   int64_t opart;     // T[max(Sh*kp*m, Sw*kp*n)] partial numerators of the current half-step
-  int64_t osumW;     // T[kp]   colsum(W)  (denominator of the H half-step, Mult:67)
-  int64_t osumH;     // T[kp]   rowsum(H)  (denominator of the W half-step, Mult:70)
+  int64_t osumW;     // double[PW][kp] colsum(W) as PW partial vectors (denominator of the H half-step, Mult:67)
+  int64_t osumH;     // double[PH][kp] rowsum(H) as PH partial vectors (denominator of the W half-step, Mult:70)
   int64_t ossepart;  // double[ntile_n] per-workgroup partial objective
   int64_t ocanon;    // int32[m] canonical co-clustering partition of the previous check (Mult:101-116)
   uint64_t seed;
@@ -47,7 +47,10 @@ struct NmfkStepArgs {
   const float *X;   // element (l, d) at X[l + d*ld]
   int64_t ld;
   int32_t L, D;
-  int32_t S;        // splits of the loop dimension (partials reduced by the reduce kernel)
+  int32_t S;        // grid-level splits of the loop dimension (S > 1 => fused = 0, reduce kernel finishes)
+  int32_t wsplit;   // 1: each wave owns 64*LB lane elements; 4: the 4 waves share them and split the loop range
+  int32_t fused;    // the step kernel finishes the update itself
+  int32_t PW, PH;   // slots of the sum tables of W and H
   int32_t dchunk;   // loop extent per split
   int32_t which;    // 0 = H half-step, 1 = W half-step
   int32_t it;       // 0-based iteration index: reads H(it&1), writes H((it+1)&1)
@@ -56,7 +59,6 @@ struct NmfkStepArgs {
   const NmfkRun *runs;
   NmfkState *state;
   int32_t nunits;
-  int32_t nlarge;   // units are sorted by k descending: units [0, nlarge) have kp > 16
   int32_t force;    // ignore the active flags
 };
 
@@ -78,6 +80,7 @@ struct NmfkCheckArgs {
   int32_t n, m;
   int32_t it;       // index of the iteration just completed (0-based); (it+1) % 10 == 0
   int32_t ntile_n;  // number of ssepart entries per unit
+  int32_t PW, PH;
   double tol, tolOF;
   int64_t maxiter;
   int32_t maxbaditers, maxreattempts, stopconv;
@@ -110,6 +113,7 @@ struct NmfkInitArgs {
   int32_t nunits;
   const float *const *Winit;  // per kidx (device staging) or null entries
   const float *const *Hinit;
+  int32_t PW, PH;
   int32_t *nan_flag;          // set to 1 when an initial value is NaN (Mult:42-44,52-54)
 };
 
@@ -136,15 +140,28 @@ static inline int nmfk_padded_k(int k) {
 // offset of the H buffer of parity `par`
 #define NMFK_HOFF(rd, par) (((par)&1) ? (rd).oH1 : (rd).oH0)
 
+#ifndef NMFK_LB
+#define NMFK_LB 2  // lane elements per thread for k <= 16
+#endif
+#ifndef NMFK_LB4_MAXK
+#define NMFK_LB4_MAXK 0  // ranks up to this use 4 lane elements per thread
+#endif
+#define NMFK_LB_OF(KP) ((KP) <= NMFK_LB4_MAXK ? 4 : ((KP) <= 16 ? NMFK_LB : 1))
+#ifndef NMFK_FASTDIV
+#define NMFK_FASTDIV 1  // fp32 ratio X/(W*H) by v_rcp_f32 + one Newton step instead of the IEEE divide sequence
+#endif
 #define NMFK_TILE 256  // threads per workgroup = lane-tile width of the half-step kernels
 
 // launchers (nmfk_step_f32.hip / nmfk_step_f64.hip)
-#define NMFK_DECLARE_LAUNCHERS(SUF)                                                              \
-  void nmfk_launch_init_##SUF(const NmfkInitArgs &a, hipStream_t s);                             \
-  void nmfk_launch_step_##SUF(const NmfkStepArgs &a, hipStream_t s);                             \
-  void nmfk_launch_reduce_##SUF(const NmfkStepArgs &a, hipStream_t s);                           \
-  void nmfk_launch_sse_##SUF(const NmfkSseArgs &a, hipStream_t s);                               \
-  void nmfk_launch_check_##SUF(const NmfkCheckArgs &a, hipStream_t s);                           \
+// Units are sorted by k descending; a "group" is the contiguous range of units of one rank.  All per-group
+// launches take (u0, cnt) = that range and the group's stream.
+#define NMFK_DECLARE_LAUNCHERS(SUF)                                                                               \
+  void nmfk_launch_init_##SUF(const NmfkInitArgs &a, hipStream_t s);                                              \
+  void nmfk_launch_step_##SUF(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt,          \
+                              hipStream_t s);                                                                     \
+  void nmfk_launch_reduce_##SUF(const NmfkStepArgs &a, int u0, int cnt, hipStream_t s);                           \
+  void nmfk_launch_sse_##SUF(const NmfkSseArgs &a, int u0, int cnt, hipStream_t s);                               \
+  void nmfk_launch_check_##SUF(const NmfkCheckArgs &a, int u0, int cnt, hipStream_t s);                           \
   void nmfk_launch_finish_##SUF(const NmfkFinishArgs &a, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f32)
 NMFK_DECLARE_LAUNCHERS(f64)

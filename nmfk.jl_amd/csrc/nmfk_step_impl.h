@@ -47,15 +47,17 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
   return sh[4];
 }
 
-// out[c] = sum_l F[c + l*kp], c < k  (colsum(W) / rowsum(H) in the signal-major layout), fp64 accumulation
-__device__ __forceinline__ void block_signal_sums(const T *F, int kp, int k, int len, T *out, double *sh) {
+// sum table of a factor: P slots of kp doubles; consumers add the slots in order.  This writes the complete
+// sums  out[c] = sum_l F[c + l*kp]  (colsum(W) / rowsum(H) in the signal-major layout) to slot 0 and zeroes
+// the other slots.
+__device__ __forceinline__ void block_signal_sums(const T *F, int kp, int k, int len, double *out, int P, double *sh) {
   for (int c = 0; c < k; ++c) {
     double s = 0;
     for (int l = threadIdx.x; l < len; l += NMFK_TILE) s += (double)F[c + (int64_t)l * kp];
     s = block_sum(s, sh);
-    if (threadIdx.x == 0) out[c] = (T)s;
+    if (threadIdx.x == 0) out[c] = s;
   }
-  for (int c = k + threadIdx.x; c < kp; c += NMFK_TILE) out[c] = (T)0;
+  for (int c = k + threadIdx.x; c < P * kp; c += NMFK_TILE) out[c] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(NMFK_TILE) void init_kernel(NmfkInitArgs g) {
   }
   if (bad) atomicOr(g.nan_flag, 1);
   __syncthreads();
-  block_signal_sums(Wt, kp, k, n, NMFK_PTR(T, g, rd.osumW), sh);
-  block_signal_sums(H, kp, k, m, NMFK_PTR(T, g, rd.osumH), sh);
+  block_signal_sums(Wt, kp, k, n, NMFK_PTR(double, g, rd.osumW), g.PW, sh);
+  block_signal_sums(H, kp, k, m, NMFK_PTR(double, g, rd.osumH), g.PH, sh);
   if (threadIdx.x == 0) {
     NmfkState s;
     s.best = __builtin_inf();
@@ -111,158 +113,400 @@ __global__ __launch_bounds__(NMFK_TILE) void init_kernel(NmfkInitArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// half-step numerators (the hot kernel)
+// half-step (the hot kernel)
+//
+// Thread layout: a workgroup owns LPW*LB consecutive lane elements (columns of X for the H half-step, rows
+// for the W half-step); LPW = 256 lane slots (wsplit = 1: every wave owns its own 64*LB elements and walks
+// the whole loop range) or 64 (wsplit = 4: the four waves share 64*LB elements and each walks a quarter of
+// the loop range; their numerators are summed through LDS in a fixed order).  LB elements per thread share
+// every wave-uniform loop-factor row (SGPRs), so scalar traffic and loop overhead are paid once per LB
+// elements.  Loads run one group of U loop steps ahead of the arithmetic (two register buffers).
+//
+// fused = 1 (grid-level S == 1): the workgroup finishes the update itself,
+//     A_new = A .* numerator ./ sumB           (Mult:67 / Mult:70, same operation order)
+// and publishes its partial sum of A_new (one slot per tile) for the other half-step's denominators.
+// fused = 0: partial numerators go to `part` and reduce_kernel finishes.
 // ------------------------------------------------------------------------------------------------------
-template <int KP, bool NANS>
-__device__ __forceinline__ void step_body(const NmfkStepArgs &g, const NmfkRun &rd) {
+__device__ __forceinline__ float div_t(float x, float p) {
+#if NMFK_FASTDIV == 2
+  return x * __builtin_amdgcn_rcpf(p);      // v_rcp_f32: 1 ulp
+#elif NMFK_FASTDIV
+  float r = __builtin_amdgcn_rcpf(p);       // 1 ulp
+  r = fmaf(fmaf(-p, r, 1.0f), r, r);        // one Newton step: 1/p to ~0.5 ulp
+  return x * r;
+#else
+  return x / p;
+#endif
+}
+__device__ __forceinline__ double div_t(double x, double p) { return x / p; }
+
+// Two-wide vectors: on gfx950 fp32 pairs map to the packed VALU ops (v_pk_fma_f32 ...).  A lone wave issues one
+// VALU instruction per 4 cycles, which a packed op fills completely and a scalar fp32 op only half, so the
+// inner loop is written on pairs: the two lane elements of a thread (LB = 2) or adjacent signals (LB = 1).
+typedef T T2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ T2 fma2(T2 a, T2 b, T2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ T2 splat2(T v) { return (T2)(v); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 div2(f32x2 x, f32x2 p) {
+#if NMFK_FASTDIV
+  f32x2 r = {__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
+#if NMFK_FASTDIV != 2
+  r = __builtin_elementwise_fma(__builtin_elementwise_fma(-p, r, (f32x2)(1.0f)), r, r);
+#endif
+  return x * r;
+#else
+  return x / p;
+#endif
+}
+__device__ __forceinline__ f64x2 div2(f64x2 x, f64x2 p) { return x / p; }
+
+template <int KP, int LB, bool NANS>
+__device__ __forceinline__ void step_body(char *arena, const float *__restrict__ X, const NmfkStepArgs *__restrict__ gp,
+                                          const NmfkRun *__restrict__ rdp, const int it, double *lds) {
+  // loop steps per group: the loop-factor rows of TWO groups live in SGPRs (about 100 available)
+  constexpr int U = (KP <= 4) ? 4 : (KP <= 8) ? 2 : 1;
+  constexpr bool PIPE = KP <= 24;  // wider factors: single buffer, no run-ahead loads
+  // Only the pointers are by-value kernel arguments (the compiler must know they are global memory to use
+  // scalar loads); the rest of the argument block and the unit descriptor live in device memory and are read
+  // field by field where they are needed, so that they do not occupy SGPRs across the main loop.
+  struct {
+    char *arena;
+    const float *X;
+    int64_t ld;
+    int L, D, S, dchunk, which, wsplit, it, lambda_bits;
+  } g;
+  g.arena = arena;
+  g.X = X;
+  g.ld = gp->ld;
+  g.L = gp->L;
+  g.D = gp->D;
+  g.S = gp->S;
+  g.dchunk = gp->dchunk;
+  g.which = gp->which;
+  g.wsplit = gp->wsplit;
+  g.it = it;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ws = g.wsplit;
+  const int lpw = (ws == 4) ? 64 : NMFK_TILE;
   const int tile = blockIdx.x / g.S;
   const int s = blockIdx.x - tile * g.S;
-  const int l = tile * NMFK_TILE + threadIdx.x;
-  const bool valid = l < g.L;
-  const int lc = valid ? l : 0;
+  if (tile * lpw * LB >= g.L) return;  // the grid is sized for the smallest LB of the launch
+  const int lbase = tile * lpw * LB + ((ws == 4) ? lane : tid);
 
-  const T *__restrict__ Hcur = NMFK_PTR(const T, g, NMFK_HOFF(rd, g.it));
-  const T *__restrict__ Hnew = NMFK_PTR(const T, g, NMFK_HOFF(rd, g.it + 1));
-  const T *__restrict__ Wt = NMFK_PTR(const T, g, rd.oWt);
-  const T *__restrict__ A = g.which == 0 ? Hcur : Wt;     // lane factor
-  const T *__restrict__ B = g.which == 0 ? Wt : Hnew;     // loop factor (wave-uniform rows)
-  const T *__restrict__ Bold = Hcur;                      // W half-step, missing data: H before this iteration
+  const T *__restrict__ Hcur = NMFK_PTR(const T, g, NMFK_HOFF(*rdp, g.it));
+  const T *__restrict__ Hnew = NMFK_PTR(const T, g, NMFK_HOFF(*rdp, g.it + 1));
+  const T *__restrict__ Wt = NMFK_PTR(const T, g, rdp->oWt);
+  const T *__restrict__ A = g.which == 0 ? Hcur : Wt;  // lane factor
+  const T *__restrict__ B = g.which == 0 ? Wt : Hnew;  // loop factor (wave-uniform rows)
+  const T *__restrict__ Bold = Hcur;                   // W half-step, missing data: H before this iteration
 
-  T a[KP], acc[KP];
+  // Pairs of adjacent signals (c = 2j, 2j+1) are the packed lanes: the loop-factor row then supplies natural,
+  // aligned SGPR pairs (b[2j], b[2j+1]) and nothing has to be broadcast or realigned.  Odd KP: one scalar tail.
+  constexpr int NP = KP / 2, NPA = NP > 0 ? NP : 1;
+  constexpr bool TAIL = (KP & 1) != 0;
+  bool valid[LB];
+  int lc[LB];
+  T2 a2[LB][NPA], acc2[LB][NPA];
+  T at[LB], acct[LB];
+#define A_(e, c) ((TAIL && (c) == KP - 1) ? at[(e)] : a2[(e)][(c) / 2][(c) & 1])
+#define ACC_(e, c) ((TAIL && (c) == KP - 1) ? acct[(e)] : acc2[(e)][(c) / 2][(c) & 1])
 #pragma unroll
-  for (int c = 0; c < KP; ++c) {
-    a[c] = valid ? A[c + (int64_t)lc * KP] : (T)1;
-    acc[c] = (T)0;
+  for (int e = 0; e < LB; ++e) {
+    const int l = lbase + e * lpw;
+    valid[e] = l < g.L;
+    lc[e] = valid[e] ? l : 0;
+    at[e] = (T)0;
+    acct[e] = (T)0;
+#pragma unroll
+    for (int c = 0; c < KP; ++c) {
+      const T v = valid[e] ? A[c + (int64_t)lc[e] * KP] : (T)1;
+      if (TAIL && c == KP - 1)
+        at[e] = v;
+      else
+        a2[e][c / 2][c & 1] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) acc2[e][j] = splat2((T)0);
   }
-  const float *__restrict__ xp = g.X + lc;
-  const int d0 = s * g.dchunk;
-  const int d1 = min(g.D, d0 + g.dchunk);
+  int d0 = s * g.dchunk;
+  int d1 = min(g.D, d0 + g.dchunk);
+  if (ws == 4) {  // quarter of the range per wave
+    const int q = (d1 - d0 + 3) >> 2;
+    d0 = min(d0 + wave * q, d1);
+    d1 = min(d0 + q, d1);
+  }
+  d0 = __builtin_amdgcn_readfirstlane(d0);
+  d1 = __builtin_amdgcn_readfirstlane(d1);
 
-  auto one = [&](int d) __attribute__((always_inline)) {
-    const T *__restrict__ b = B + (int64_t)d * KP;
-    T bv[KP];
+  // running, wave-uniform row pointers (SGPR pairs); the per-lane part of the X address is a 32-bit offset
+  unsigned lofs[LB];
 #pragma unroll
-    for (int c = 0; c < KP; ++c) bv[c] = b[c];
-    const float xf = xp[(int64_t)d * g.ld];
-    T p = (T)0;
+  for (int e = 0; e < LB; ++e) lofs[e] = (unsigned)lc[e];
+  const float *__restrict__ xnext = g.X + (int64_t)d0 * g.ld;  // row of the next group to LOAD
+  const T *__restrict__ bnext = B + (int64_t)d0 * KP;
+  const int64_t ld = g.ld;
+
+  auto load = [&](T (&bufv)[U][KP], float (&bufx)[U][LB]) __attribute__((always_inline)) {
+    const float *__restrict__ xr = xnext;
 #pragma unroll
-    for (int c = 0; c < KP; ++c) p = fma_t(a[c], bv[c], p);
-    T x = (T)xf;
-    if (NANS) {
-      // EM imputation (Mult:72): a missing entry holds fl32(W*H) of the previous iteration's result, lambda
-      // on the first iteration (Mult:20).  H half-step: that IS p.  W half-step: <w_old, h_old>.
-      const bool isn = xf != xf;
-      if (__any(isn)) {
-        T xi;
-        if (g.it == 0) {
-          xi = (T)g.lambda;
-        } else if (g.which == 0) {
-          xi = (T)(float)p;
-        } else {
-          const T *__restrict__ bo = Bold + (int64_t)d * KP;
-          T po = (T)0;
+    for (int uu = 0; uu < U; ++uu) {
 #pragma unroll
-          for (int c = 0; c < KP; ++c) po = fma_t(a[c], bo[c], po);
-          xi = (T)(float)po;
+      for (int c = 0; c < KP; ++c) bufv[uu][c] = bnext[uu * KP + c];
+#pragma unroll
+      for (int e = 0; e < LB; ++e) bufx[uu][e] = xr[lofs[e]];
+      xr += ld;
+    }
+    xnext = xr;
+    bnext += U * KP;
+  };
+  // imputed value of a missing entry (EM imputation, Mult:72): fl32(W*H) of the previous iteration's result,
+  // lambda on the first iteration (Mult:20).  H half-step: that IS p.  W half-step: <w_old, h_old>.
+  auto impute = [&](int d, int e, T p) __attribute__((always_inline)) -> T {
+    if (g.it == 0) return (T)gp->lambda;
+    if (g.which == 0) return (T)(float)p;
+    const T *__restrict__ bo = Bold + (int64_t)d * KP;
+    T po = (T)0;
+#pragma unroll
+    for (int c = 0; c < KP; ++c) po = fma_t(A_(e, c), bo[c], po);
+    return (T)(float)po;
+  };
+  auto row = [&](int d, const T *bv, const float *xf) __attribute__((always_inline)) {
+    T p[LB], q[LB], x[LB];
+#pragma unroll
+    for (int e = 0; e < LB; ++e) {
+      T2 s2 = splat2((T)0);
+#pragma unroll
+      for (int j = 0; j < NP; ++j) s2 = fma2(a2[e][j], (T2){bv[2 * j], bv[2 * j + 1]}, s2);
+      T pe = s2.x + s2.y;
+      if (TAIL) pe = fma_t(at[e], bv[KP - 1], pe);
+      p[e] = pe;
+      x[e] = (T)xf[e];
+      if (NANS) {
+        const bool isn = xf[e] != xf[e];
+        if (__any(isn)) {
+          const T xi = impute(d, e, pe);
+          x[e] = isn ? xi : x[e];
         }
-        x = isn ? xi : x;
       }
     }
-    const T q = x / p;
+    if (LB == 2) {
+      const T2 q2 = div2((T2){x[0], x[LB - 1]}, (T2){p[0], p[LB - 1]});
+      q[0] = q2.x;
+      q[LB - 1] = q2.y;
+    } else {
+      q[0] = div_t(x[0], p[0]);
+    }
 #pragma unroll
-    for (int c = 0; c < KP; ++c) acc[c] = fma_t(bv[c], q, acc[c]);
+    for (int e = 0; e < LB; ++e) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) acc2[e][j] = fma2((T2){bv[2 * j], bv[2 * j + 1]}, splat2(q[e]), acc2[e][j]);
+      if (TAIL) acct[e] = fma_t(bv[KP - 1], q[e], acct[e]);
+    }
   };
-  constexpr int U = (KP <= 8) ? 4 : 2;
+  auto compute = [&](int d, const T (&bufv)[U][KP], const float (&bufx)[U][LB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu) row(d + uu, bufv[uu], bufx[uu]);
+  };
+
+  const int nfull = (d1 - d0) / U;
   int d = d0;
-  for (; d + U <= d1; d += U) {
-#pragma unroll
-    for (int uu = 0; uu < U; ++uu) one(d + uu);
+  if (nfull > 0) {
+    T v0[U][KP], v1[U][KP];  // the two register buffers: loop-factor rows (SGPRs) ...
+    float x0[U][LB], x1[U][LB];  // ... and X entries (VGPRs)
+    load(v0, x0);
+    if (PIPE) {
+      // steady state: two groups per trip, loads one group ahead, buffers alternate without copies
+      // (sched_barrier: keep the loads where they are written -- the scheduler would sink them to their uses.
+      //  Scalar loads return out of order, so the only wait is lgkmcnt(0); it lands at the top of each
+      //  compute phase, one whole phase after the load was issued.)
+      for (int pairs = (nfull - 1) >> 1; pairs > 0; --pairs) {
+        load(v1, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(d, v0, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        load(v0, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(d + U, v1, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        d += 2 * U;
+      }
+      if (((nfull - 1) & 1) != 0) {  // two groups left, the first already loaded
+        load(v1, x1);
+        compute(d, v0, x0);
+        compute(d + U, v1, x1);
+        d += 2 * U;
+      } else {
+        compute(d, v0, x0);
+        d += U;
+      }
+    } else {
+      compute(d, v0, x0);
+      d += U;
+      for (int gi = 1; gi < nfull; ++gi, d += U) {
+        load(v0, x0);
+        compute(d, v0, x0);
+      }
+    }
   }
-  for (; d < d1; ++d) one(d);
-  if (valid) {
-    T *__restrict__ part = NMFK_PTR(T, g, rd.opart) + ((int64_t)s * g.L + l) * KP;
+  for (; d < d1; ++d) {  // remainder rows
+    const T *__restrict__ b = B + (int64_t)d * KP;
+    T bv[KP];
+    float xf[LB];
 #pragma unroll
-    for (int c = 0; c < KP; ++c) part[c] = acc[c];
+    for (int c = 0; c < KP; ++c) bv[c] = b[c];
+#pragma unroll
+    for (int e = 0; e < LB; ++e) xf[e] = g.X[(int64_t)d * g.ld + lc[e]];
+    row(d, bv, xf);
+  }
+
+  // wsplit = 4: numerators of waves 1..3 are added to wave 0's in wave order (deterministic)
+  T *ldsT = (T *)(lds + 5 * NMFK_MAX_K);  // cross-wave scratch behind den[64] and red[4*64]
+  if (ws == 4) {
+    if (wave > 0) {
+#pragma unroll
+      for (int e = 0; e < LB; ++e)
+#pragma unroll
+        for (int c = 0; c < KP; ++c) ldsT[(((wave - 1) * LB + e) * KP + c) * 64 + lane] = ACC_(e, c);
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int e = 0; e < LB; ++e)
+#pragma unroll
+          for (int c = 0; c < KP; ++c) {
+            const T v = ldsT[((w * LB + e) * KP + c) * 64 + lane];
+            if (TAIL && c == KP - 1)
+              acct[e] += v;
+            else
+              acc2[e][c / 2][c & 1] += v;
+          }
+    }
+    __syncthreads();
+  }
+  const bool owner = (ws == 1) || (wave == 0);
+
+  if (!gp->fused) {
+    if (owner) {
+#pragma unroll
+      for (int e = 0; e < LB; ++e)
+        if (valid[e]) {
+          T *__restrict__ part = NMFK_PTR(T, g, rdp->opart) + ((int64_t)s * g.L + lc[e]) * KP;
+#pragma unroll
+          for (int c = 0; c < KP; ++c) part[c] = ACC_(e, c);
+        }
+    }
+    return;
+  }
+
+  // fused finish.  denominators: sum of the other factor's per-tile partial sums (fp64, fixed order)
+  const double *sumB = NMFK_PTR(const double, g, g.which == 0 ? rdp->osumW : rdp->osumH);
+  const int PB = g.which == 0 ? gp->PW : gp->PH;
+  double *den = lds;
+  if (tid < KP) {
+    double sd = 0;
+    for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * KP + tid];
+    den[tid] = sd;
+  }
+  __syncthreads();
+  T *__restrict__ Anew = g.which == 0 ? NMFK_PTR(T, g, NMFK_HOFF(*rdp, g.it + 1)) : NMFK_PTR(T, g, rdp->oWt);
+  const int k = rdp->k;
+  T vsum[KP];
+#pragma unroll
+  for (int c = 0; c < KP; ++c) vsum[c] = (T)0;
+  if (owner) {
+#pragma unroll
+    for (int e = 0; e < LB; ++e) {
+#pragma unroll
+      for (int c = 0; c < KP; ++c) {
+        T v = A_(e, c) * ACC_(e, c) / (T)den[c];
+        if (c >= k || !valid[e]) v = (T)0;
+        if (valid[e]) Anew[c + (int64_t)lc[e] * KP] = v;
+        vsum[c] += v;
+      }
+    }
+  }
+  // per-workgroup partial sums of A_new -> slot `tile` of the sum table of this factor
+  double *sumA = NMFK_PTR(double, g, g.which == 0 ? rdp->osumH : rdp->osumW) + (int64_t)tile * KP;
+  double *red = den + NMFK_MAX_K;  // [4][KP]
+#pragma unroll
+  for (int c = 0; c < KP; ++c) {
+    const double v = wave_sum((double)vsum[c]);
+    if (lane == 0) red[wave * KP + c] = v;
+  }
+  __syncthreads();
+  if (tid < KP) {
+    const double t = (ws == 4) ? red[tid] : ((red[tid] + red[KP + tid]) + (red[2 * KP + tid] + red[3 * KP + tid]));
+    sumA[tid] = t;
   }
 }
 
-#define NMFK_STEP_CASE(KP) step_body<KP, NANS>(g, rd)
-template <bool NANS, bool LARGE>
-__global__ __launch_bounds__(NMFK_TILE) void step_kernel(NmfkStepArgs g, int u0) {
+// One kernel per rank width KP: the register allocation (hence occupancy) of a kernel is the maximum over
+// everything it can dispatch to, and a switch over ranks inside one kernel inflates it well beyond the widest
+// case.  Units of equal rank are contiguous (sorted by k), so a launch covers the unit range [u0, u0 + gridDim.y).
+// LDS: den[64], red[4*64], then the cross-wave scratch of 3*LB*KP*64 elements of T.
+template <bool NANS, int KP>
+__global__ __launch_bounds__(NMFK_TILE) void step_kernel(char *arena, const float *__restrict__ X,
+                                                         const NmfkRun *__restrict__ runs,
+                                                         const NmfkState *__restrict__ state,
+                                                         const NmfkStepArgs *__restrict__ gp, int it, int u0) {
+  constexpr int LB = NMFK_LB_OF(KP);
+  __shared__ double lds[5 * NMFK_MAX_K + 3 * KP * LB * (sizeof(T) == 8 ? 64 : 32)];
   const int u = u0 + blockIdx.y;
-  if (!g.force && !g.state[u].active) return;
-  const NmfkRun rd = g.runs[u];
-  if (LARGE) {
-    switch (rd.kp) {
-      case 20: NMFK_STEP_CASE(20); break;
-      case 24: NMFK_STEP_CASE(24); break;
-      case 28: NMFK_STEP_CASE(28); break;
-      case 32: NMFK_STEP_CASE(32); break;
-      case 40: NMFK_STEP_CASE(40); break;
-      case 48: NMFK_STEP_CASE(48); break;
-      case 56: NMFK_STEP_CASE(56); break;
-      case 64: NMFK_STEP_CASE(64); break;
-      default: break;
-    }
-  } else {
-    switch (rd.kp) {
-      case 1: NMFK_STEP_CASE(1); break;
-      case 2: NMFK_STEP_CASE(2); break;
-      case 3: NMFK_STEP_CASE(3); break;
-      case 4: NMFK_STEP_CASE(4); break;
-      case 5: NMFK_STEP_CASE(5); break;
-      case 6: NMFK_STEP_CASE(6); break;
-      case 7: NMFK_STEP_CASE(7); break;
-      case 8: NMFK_STEP_CASE(8); break;
-      case 9: NMFK_STEP_CASE(9); break;
-      case 10: NMFK_STEP_CASE(10); break;
-      case 11: NMFK_STEP_CASE(11); break;
-      case 12: NMFK_STEP_CASE(12); break;
-      case 13: NMFK_STEP_CASE(13); break;
-      case 14: NMFK_STEP_CASE(14); break;
-      case 15: NMFK_STEP_CASE(15); break;
-      case 16: NMFK_STEP_CASE(16); break;
-      default: break;
-    }
-  }
+  if (!gp->force && !state[u].active) return;
+  step_body<KP, LB, NANS>(arena, X, gp, runs + u, it, lds);
 }
 
 // ------------------------------------------------------------------------------------------------------
 // half-step finish: A_new = A .* (sum of partial numerators) ./ sumB ;  sumA_new   (one workgroup per unit)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NMFK_TILE) void reduce_kernel(NmfkStepArgs g) {
+__global__ __launch_bounds__(NMFK_TILE) void reduce_kernel(NmfkStepArgs g, int u0) {
   __shared__ double sh[8];
-  const int u = blockIdx.x;
+  __shared__ double den[NMFK_MAX_K];
+  const int u = u0 + blockIdx.x;
   if (!g.force && !g.state[u].active) return;
   const NmfkRun rd = g.runs[u];
   const T *Aold;
   T *Anew;
-  const T *sumB;
-  T *sumA;
+  const double *sumB;
+  double *sumA;
+  int PA, PB;
   if (g.which == 0) {
     Aold = NMFK_PTR(const T, g, NMFK_HOFF(rd, g.it));
     Anew = NMFK_PTR(T, g, NMFK_HOFF(rd, g.it + 1));
-    sumB = NMFK_PTR(const T, g, rd.osumW);
-    sumA = NMFK_PTR(T, g, rd.osumH);
+    sumB = NMFK_PTR(const double, g, rd.osumW);
+    sumA = NMFK_PTR(double, g, rd.osumH);
+    PB = g.PW;
+    PA = g.PH;
   } else {
     Aold = NMFK_PTR(const T, g, rd.oWt);
     Anew = NMFK_PTR(T, g, rd.oWt);
-    sumB = NMFK_PTR(const T, g, rd.osumH);
-    sumA = NMFK_PTR(T, g, rd.osumW);
+    sumB = NMFK_PTR(const double, g, rd.osumH);
+    sumA = NMFK_PTR(double, g, rd.osumW);
+    PB = g.PH;
+    PA = g.PW;
   }
   const int k = rd.k, kp = rd.kp;
+  if (threadIdx.x < kp) {
+    double sd = 0;
+    for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * kp + threadIdx.x];
+    den[threadIdx.x] = sd;
+  }
+  __syncthreads();
   const T *part = NMFK_PTR(const T, g, rd.opart);
   const int64_t LK = (int64_t)g.L * kp;
   for (int64_t e = threadIdx.x; e < LK; e += NMFK_TILE) {
     const int c = (int)(e % kp);
     T num = (T)0;
     for (int s = 0; s < g.S; ++s) num += part[(int64_t)s * LK + e];
-    T v = Aold[e] * num / sumB[c];  // same operation order as Mult:67,70
+    T v = Aold[e] * num / (T)den[c];  // same operation order as Mult:67,70
     if (c >= k) v = (T)0;
     Anew[e] = v;
   }
   __syncthreads();
-  block_signal_sums(Anew, kp, k, g.L, sumA, sh);
+  block_signal_sums(Anew, kp, k, g.L, sumA, PA, sh);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -299,9 +543,9 @@ __device__ __forceinline__ void sse_body(const NmfkSseArgs &g, const NmfkRun &rd
 }
 
 #define NMFK_SSE_CASE(KP) sse_body<KP>(g, rd, H, sh)
-__global__ __launch_bounds__(NMFK_TILE) void sse_kernel(NmfkSseArgs g) {
+__global__ __launch_bounds__(NMFK_TILE) void sse_kernel(NmfkSseArgs g, int u0) {
   __shared__ double sh[8];
-  const int u = blockIdx.y;
+  const int u = u0 + blockIdx.y;
   const NmfkState st = g.state[u];
   if (!g.force && !st.active) return;
   const NmfkRun rd = g.runs[u];
@@ -314,11 +558,11 @@ __global__ __launch_bounds__(NMFK_TILE) void sse_kernel(NmfkSseArgs g) {
 // check block, every 10th iteration (Mult:73-117): objective -> tol test -> bad-iteration bookkeeping ->
 // clamp at eps(Float64) -> co-clustering consistency -> loop guard (Mult:64).  One workgroup per unit.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NMFK_TILE) void check_kernel(NmfkCheckArgs g) {
+__global__ __launch_bounds__(NMFK_TILE) void check_kernel(NmfkCheckArgs g, int u0) {
   __shared__ double sh[8];
   __shared__ int sh_action, sh_diff;
   __shared__ int sh_first[NMFK_MAX_K];
-  const int u = blockIdx.x;
+  const int u = u0 + blockIdx.x;
   NmfkState *st = g.state + u;
   if (!st->active) return;
   const NmfkRun rd = g.runs[u];
@@ -373,8 +617,8 @@ __global__ __launch_bounds__(NMFK_TILE) void check_kernel(NmfkCheckArgs g) {
     if ((int)(e % kp) < k && v < eps) H[e] = eps;
   }
   __syncthreads();
-  block_signal_sums(Wt, kp, k, n, NMFK_PTR(T, g, rd.osumW), sh);
-  block_signal_sums(H, kp, k, m, NMFK_PTR(T, g, rd.osumH), sh);
+  block_signal_sums(Wt, kp, k, n, NMFK_PTR(double, g, rd.osumW), g.PW, sh);
+  block_signal_sums(H, kp, k, m, NMFK_PTR(double, g, rd.osumH), g.PH, sh);
 
   // index[q] = argmin(H[:,q]) (first minimum; a NaN wins, as in Julia); cons[i,j] = index[i]==index[j];
   // consdiff == 0  <=>  the partition of the columns is unchanged.  Canonical form of a partition: every
@@ -490,37 +734,37 @@ void NMFK_NAME(nmfk_launch_init)(const NmfkInitArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(init_kernel, dim3(a.nunits), dim3(NMFK_TILE), 0, s, a);
 }
 
-void NMFK_NAME(nmfk_launch_step)(const NmfkStepArgs &a, hipStream_t s) {
-  const int ntile = (a.L + NMFK_TILE - 1) / NMFK_TILE;
-  const int nlarge = a.nlarge;
-  const dim3 blk(NMFK_TILE);
-  if (nlarge > 0) {
-    const dim3 grid(ntile * a.S, nlarge);
-    if (a.has_nan)
-      hipLaunchKernelGGL((step_kernel<true, true>), grid, blk, 0, s, a, 0);
-    else
-      hipLaunchKernelGGL((step_kernel<false, true>), grid, blk, 0, s, a, 0);
-  }
-  if (a.nunits - nlarge > 0) {
-    const dim3 grid(ntile * a.S, a.nunits - nlarge);
-    if (a.has_nan)
-      hipLaunchKernelGGL((step_kernel<true, false>), grid, blk, 0, s, a, nlarge);
-    else
-      hipLaunchKernelGGL((step_kernel<false, false>), grid, blk, 0, s, a, nlarge);
-  }
+// `dargs`: device copy of `a` (constant over the sweep except `it`, which is passed by value).
+// Launches the half-step of the `cnt` units [u0, u0 + cnt), which all have padded rank kp.
+template <int KP>
+static void launch_step_kp(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int u0, int cnt, hipStream_t s) {
+  constexpr int LB = NMFK_LB_OF(KP);
+  const int lpw = a.wsplit == 4 ? 64 : NMFK_TILE;
+  const int ntile = (a.L + lpw * LB - 1) / (lpw * LB);
+  const dim3 grid(ntile * a.S, cnt), blk(NMFK_TILE);
+  if (a.has_nan)
+    hipLaunchKernelGGL((step_kernel<true, KP>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
+  else
+    hipLaunchKernelGGL((step_kernel<false, KP>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
 }
 
-void NMFK_NAME(nmfk_launch_reduce)(const NmfkStepArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(reduce_kernel, dim3(a.nunits), dim3(NMFK_TILE), 0, s, a);
+#define NMFK_LAUNCH_CASE(KP) launch_step_kp<KP>(a, dargs, u0, cnt, s)
+void NMFK_NAME(nmfk_launch_step)(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt,
+                                 hipStream_t s) {
+  NMFK_DISPATCH_KP(kp, NMFK_LAUNCH_CASE)
 }
 
-void NMFK_NAME(nmfk_launch_sse)(const NmfkSseArgs &a, hipStream_t s) {
+void NMFK_NAME(nmfk_launch_reduce)(const NmfkStepArgs &a, int u0, int cnt, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, u0);
+}
+
+void NMFK_NAME(nmfk_launch_sse)(const NmfkSseArgs &a, int u0, int cnt, hipStream_t s) {
   const int ntile = (a.n + NMFK_TILE - 1) / NMFK_TILE;
-  hipLaunchKernelGGL(sse_kernel, dim3(ntile, a.nunits), dim3(NMFK_TILE), 0, s, a);
+  hipLaunchKernelGGL(sse_kernel, dim3(ntile, cnt), dim3(NMFK_TILE), 0, s, a, u0);
 }
 
-void NMFK_NAME(nmfk_launch_check)(const NmfkCheckArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(check_kernel, dim3(a.nunits), dim3(NMFK_TILE), 0, s, a);
+void NMFK_NAME(nmfk_launch_check)(const NmfkCheckArgs &a, int u0, int cnt, hipStream_t s) {
+  hipLaunchKernelGGL(check_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, u0);
 }
 
 void NMFK_NAME(nmfk_launch_finish)(const NmfkFinishArgs &a, hipStream_t s) {

@@ -138,9 +138,12 @@ int nmfk_cluster_stats(nmfk_ctx *ctx, int k, int nsol, int64_t n, int64_t m, con
 int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float *H, double *out);
 
 /* measurement ----------------------------------------------------------------------------------------------- */
-/* HIP-event timing of the MU kernels on the stream they are launched on (bench.py's roofline leg).
- * After a sweep with profiling enabled: names[i] / total_ms[i] / launches[i] / flops[i] for i < *count
- * (flops = algorithmic 4*n*m*k per half-step per ACTIVE restart, summed over the launches). */
+/* HIP-event timing of the MU kernels on the streams they are launched on (bench.py's roofline leg).
+ * After a sweep with profiling enabled: names[i] / total_ms[i] / launches[i] / flops[i] for i < *count:
+ *   "mu_loop"                     GPU wall time of the whole MU loop (all rank groups run concurrently) and the
+ *                                 algorithmic flops of every half-step in it (4*n*m*k per ACTIVE restart)
+ *   "h_step<kp>" / "w_step<kp>"   sampled launches (every 8th iteration) of the half-step kernel of one rank,
+ *                                 each timed on its own stream, with the flops of the restarts active in them */
 int nmfk_set_profiling(nmfk_ctx *ctx, int enabled);
 int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *total_ms, int64_t *launches,
                      double *flops, int *count);

@@ -253,7 +253,7 @@ class Context:
         _check(lib().nmfk_set_profiling(self._h, int(on)))
 
     def get_profile(self):
-        nmax = 16
+        nmax = 80
         names = ((C.c_char * 64) * nmax)()
         ms = (C.c_double * nmax)()
         launches = (C.c_int64 * nmax)()

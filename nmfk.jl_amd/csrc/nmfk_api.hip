@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -61,9 +62,7 @@ struct DevBuf {
   }
 };
 
-enum { PK_HSTEP = 0, PK_HRED, PK_WSTEP, PK_WRED, PK_SSE, PK_CHECK, PK_OTHER, PK_COUNT };
-const char *const kProfNames[PK_COUNT] = {"mu_h_numerators", "mu_h_finish", "mu_w_numerators", "mu_w_finish",
-                                          "mu_objective",    "mu_check",    "mu_init_finish"};
+enum { PK_HSTEP = 0, PK_WSTEP = 1 };
 
 }  // namespace
 
@@ -86,9 +85,11 @@ struct nmfk_ctx {
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> events;
-  double prof_ms[PK_COUNT] = {0};
-  int64_t prof_launches[PK_COUNT] = {0};
-  double prof_flops[PK_COUNT] = {0};
+  struct ProfEntry {
+    double ms = 0, flops = 0;
+    int64_t launches = 0;
+  };
+  std::map<std::string, ProfEntry> prof;
 };
 
 namespace {
@@ -289,11 +290,7 @@ NMFK_EXPORT int nmfk_fill_uniform(nmfk_ctx *ctx, uint64_t seed, uint64_t offset,
 NMFK_EXPORT int nmfk_set_profiling(nmfk_ctx *ctx, int enabled) {
   if (!ctx) return fail(NMFK_ERR_BAD_ARG, "ctx is null");
   ctx->profiling = enabled != 0;
-  for (int i = 0; i < PK_COUNT; ++i) {
-    ctx->prof_ms[i] = 0;
-    ctx->prof_launches[i] = 0;
-    ctx->prof_flops[i] = 0;
-  }
+  ctx->prof.clear();
   return NMFK_OK;
 }
 
@@ -301,11 +298,12 @@ NMFK_EXPORT int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[6
                                  double *flops, int *count) {
   if (!ctx || !count) return fail(NMFK_ERR_BAD_ARG, "bad argument");
   int c = 0;
-  for (int i = 0; i < PK_COUNT && c < max_entries; ++i) {
-    if (names) snprintf(names[c], 64, "%s", kProfNames[i]);
-    if (total_ms) total_ms[c] = ctx->prof_ms[i];
-    if (launches) launches[c] = ctx->prof_launches[i];
-    if (flops) flops[c] = ctx->prof_flops[i];
+  for (const auto &kv : ctx->prof) {
+    if (c >= max_entries) break;
+    if (names) snprintf(names[c], 64, "%s", kv.first.c_str());
+    if (total_ms) total_ms[c] = kv.second.ms;
+    if (launches) launches[c] = kv.second.launches;
+    if (flops) flops[c] = kv.second.flops;
     ++c;
   }
   *count = c;
@@ -565,6 +563,12 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   HIPCHECK(hipEventCreateWithFlags(&snap_ev[0], hipEventDisableTiming));
   HIPCHECK(hipEventCreateWithFlags(&snap_ev[1], hipEventDisableTiming));
   HIPCHECK(hipEventCreateWithFlags(&start_ev, hipEventDisableTiming));
+  hipEvent_t loop_t0 = nullptr, loop_t1 = nullptr;
+  if (ctx->profiling) {
+    HIPCHECK(hipEventCreate(&loop_t0));
+    HIPCHECK(hipEventCreate(&loop_t1));
+    HIPCHECK(hipEventRecord(loop_t0, st));
+  }
   HIPCHECK(hipEventRecord(start_ev, st));  // init done
   for (int j = 0; j < NS; ++j) HIPCHECK(hipStreamWaitEvent(ctx->gstreams[j], start_ev, 0));
 
@@ -647,6 +651,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     HIPCHECK(hipStreamWaitEvent(st, gev[j], 0));
   }
   HIPCHECK(hipStreamSynchronize(poll));
+  if (ctx->profiling) HIPCHECK(hipEventRecord(loop_t1, st));
 
   // objvalue = normnan(X - W*H) on the final factors, normalisation, T-typed outputs (Exec:790-805)
   sa.hsel = -1;
@@ -713,9 +718,23 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     }
   }
 
-  // sampled launches: duration on their own stream (other rank groups run concurrently) and the algorithmic
-  // work of exactly the units that were still active at that iteration (lock-step => active iff it < iters)
+  // Profile (nmfk_get_profile):
+  //  "mu_loop"            wall time of the whole MU loop on the GPU (all rank groups, concurrent streams) and the
+  //                        algorithmic flops of every half-step executed in it: 4*n*m*k per active unit per half-step
+  //  "h_step<kp>" / "w_step<kp>"  sampled launches (every 8th iteration) of one rank group, timed on their own
+  //                        stream while the other groups keep running; flops of exactly the units still active
   if (ctx->profiling) {
+    float loop_ms = 0.f;
+    if (hipEventElapsedTime(&loop_ms, loop_t0, loop_t1) == hipSuccess) {
+      auto &E = ctx->prof["mu_loop"];
+      E.ms += loop_ms;
+      E.launches += 1;
+      for (int q = 0; q < nk; ++q)
+        for (int r = 0; r < nruns; ++r)
+          E.flops += 4.0 * n * (double)m * ks[q] * (double)h_iters[q][r] * ((P.Hfixed ? 0 : 1) + (P.Wfixed ? 0 : 1));
+    }
+    (void)hipEventDestroy(loop_t0);
+    (void)hipEventDestroy(loop_t1);
     for (const Sample &sm : prof.samples) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, ctx->events[sm.e0], ctx->events[sm.e1]) != hipSuccess) continue;
@@ -723,9 +742,12 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       int active = 0;
       for (int u = G.begin; u < G.begin + G.count; ++u)
         active += sm.it < h_iters[runs[u].kidx][runs[u].ridx] ? 1 : 0;
-      ctx->prof_ms[sm.kind] += ms;
-      ctx->prof_launches[sm.kind] += 1;
-      ctx->prof_flops[sm.kind] += 4.0 * n * (double)m * G.k * active;  // W*H + the product with the ratio
+      char name[64];
+      snprintf(name, sizeof(name), "%s<%d>", sm.kind == PK_HSTEP ? "h_step" : "w_step", G.kp);
+      auto &E = ctx->prof[name];
+      E.ms += ms;
+      E.launches += 1;
+      E.flops += 4.0 * n * (double)m * G.k * active;  // W*H + the product with the ratio
     }
   }
   return NMFK_OK;

@@ -1,0 +1,108 @@
+"""N > 1 path on CPU: two gloo ranks shard the restarts of every k (nmfk.jl_amd/parallel.py) and all-gather the
+results.  The compute function is injected (here: the CPU oracle, which only tests may use) so that the
+partition / padding / gather logic is exercised without a GPU; on the GPU box the same code path runs with
+Context.mu_sweep and the nccl (RCCL) backend."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_sweep(X):
+    import nmfk_oracle as oracle
+
+    def sweep(ks, nruns, seeds=None, Winit=None, Hinit=None, params=None):
+        n, m = X.shape
+        out = {}
+        for qi, k in enumerate(ks):
+            W, H, obj, it, rs = [], [], [], [], []
+            for r in range(nruns):
+                W0, H0 = oracle.init_factors(int(seeds[qi][r]), n, m, k)
+                res = oracle.singlerun(X, k, W0, H0, maxiter=int(params.maxiter), maxbaditers=int(params.maxbaditers))
+                W.append(res["W"].astype(np.float32))
+                H.append(res["H"].astype(np.float32))
+                obj.append(np.float32(res["objvalue"]))
+                it.append(res["iters"])
+                rs.append(res["reason"])
+            out[k] = dict(W=np.stack(W), H=np.stack(H), objvalue=np.array(obj, np.float32),
+                          sse=np.array(obj, np.float64) ** 2, iters=np.array(it, np.int32), reason=np.array(rs, np.int32))
+        return out
+
+    return sweep
+
+
+def _worker(rank, world, port, nruns, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import nmfk_jl_amd as NMFk
+    import nmfk_oracle as oracle
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        n, m, ks = 12, 7, [2, 3]
+        X0 = oracle.uniform_fill(3, 0, n * m).reshape(n, m).astype(np.float32) if rank == 0 else None
+        X = NMFk.parallel.broadcast_X(X0)  # rank 0 owns X; everybody else receives it
+        assert X.shape == (n, m)
+        seeds = np.array([[NMFk.run_seed(5, k, r) for r in range(nruns)] for k in ks], dtype=np.uint64)
+        params = NMFk.default_params(maxiter=30, maxbaditers=10 ** 9)
+        res = NMFk.parallel.sharded_sweep(_oracle_sweep(X), ks, nruns, seeds, None, None, params, n, m)
+        q.put((rank, X, {k: {kk: np.asarray(v) for kk, v in res[k].items()} for k in ks}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nruns", [4, 5])  # 5: uneven shards (rank 0 gets 3 restarts, rank 1 gets 2 + one padding run)
+def test_sharded_sweep_two_ranks(oracle, nruns):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nruns, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    (_, X0, r0), (_, X1, r1) = got
+    np.testing.assert_array_equal(X0, X1)
+    # every rank holds the complete, identically ordered result ...
+    for k in r0:
+        for key in r0[k]:
+            np.testing.assert_array_equal(r0[k][key], r1[k][key])
+            assert r0[k][key].shape[0] == nruns
+    # ... equal to the unsharded computation
+    import nmfk_jl_amd as NMFk
+
+    ks = [2, 3]
+    seeds = np.array([[NMFk.run_seed(5, k, r) for r in range(nruns)] for k in ks], dtype=np.uint64)
+    params = NMFk.default_params(maxiter=30, maxbaditers=10 ** 9)
+    ref = _oracle_sweep(X0)(ks, nruns, seeds=seeds, params=params)
+    for k in ks:
+        for key in ("W", "H", "objvalue", "iters", "reason"):
+            np.testing.assert_array_equal(r0[k][key], ref[k][key])
+
+
+def test_single_process_passthrough(oracle):
+    import nmfk_jl_amd as NMFk
+
+    assert NMFk.parallel.world() == (0, 1)
+    X = oracle.uniform_fill(1, 0, 20).reshape(5, 4).astype(np.float32)
+    np.testing.assert_array_equal(NMFk.parallel.broadcast_X(X), X)
+    seeds = np.array([[1, 2]], dtype=np.uint64)
+    params = NMFk.default_params(maxiter=10)
+    res = NMFk.parallel.sharded_sweep(_oracle_sweep(X), [2], 2, seeds, None, None, params, 5, 4)
+    assert res[2]["W"].shape == (2, 5, 2)

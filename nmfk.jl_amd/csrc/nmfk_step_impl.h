@@ -165,7 +165,13 @@ template <int KP, int LB, bool NANS>
 __device__ __forceinline__ void step_body(char *arena, const float *__restrict__ X, const NmfkStepArgs *__restrict__ gp,
                                           const NmfkRun *__restrict__ rdp, const int it, double *lds) {
   // loop steps per group: the loop-factor rows of TWO groups live in SGPRs (about 100 available)
+#if NMFK_UPOL == 1
+  constexpr int U = (KP <= 4) ? 4 : (KP <= 12) ? 2 : 1;
+#elif NMFK_UPOL == 2
+  constexpr int U = (KP <= 6) ? 4 : (KP <= 12) ? 2 : 1;
+#else
   constexpr int U = (KP <= 4) ? 4 : (KP <= 8) ? 2 : 1;
+#endif
   constexpr bool PIPE = KP <= 24;  // wider factors: single buffer, no run-ahead loads
   // Only the pointers are by-value kernel arguments (the compiler must know they are global memory to use
   // scalar loads); the rest of the argument block and the unit descriptor live in device memory and are read
@@ -290,13 +296,13 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
         }
       }
     }
-    if (LB == 2) {
-      const T2 q2 = div2((T2){x[0], x[LB - 1]}, (T2){p[0], p[LB - 1]});
-      q[0] = q2.x;
-      q[LB - 1] = q2.y;
-    } else {
-      q[0] = div_t(x[0], p[0]);
+#pragma unroll
+    for (int e = 0; e + 1 < LB; e += 2) {  // ratios two at a time (packed Newton step)
+      const T2 q2 = div2((T2){x[e], x[e + 1]}, (T2){p[e], p[e + 1]});
+      q[e] = q2.x;
+      q[e + 1] = q2.y;
     }
+    if (LB & 1) q[LB - 1] = div_t(x[LB - 1], p[LB - 1]);
 #pragma unroll
     for (int e = 0; e < LB; ++e) {
 #pragma unroll
@@ -371,8 +377,8 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
     }
     __syncthreads();
     if (wave == 0) {
-#pragma unroll
-      for (int w = 0; w < 3; ++w)
+#pragma unroll 1
+      for (int w = 0; w < 3; ++w) {  // not unrolled: one wave's worth of temporaries at a time
 #pragma unroll
         for (int e = 0; e < LB; ++e)
 #pragma unroll
@@ -383,6 +389,7 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
             else
               acc2[e][c / 2][c & 1] += v;
           }
+      }
     }
     __syncthreads();
   }
@@ -413,27 +420,22 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   __syncthreads();
   T *__restrict__ Anew = g.which == 0 ? NMFK_PTR(T, g, NMFK_HOFF(*rdp, g.it + 1)) : NMFK_PTR(T, g, rdp->oWt);
   const int k = rdp->k;
-  T vsum[KP];
-#pragma unroll
-  for (int c = 0; c < KP; ++c) vsum[c] = (T)0;
-  if (owner) {
-#pragma unroll
-    for (int e = 0; e < LB; ++e) {
-#pragma unroll
-      for (int c = 0; c < KP; ++c) {
-        T v = A_(e, c) * ACC_(e, c) / (T)den[c];
-        if (c >= k || !valid[e]) v = (T)0;
-        if (valid[e]) Anew[c + (int64_t)lc[e] * KP] = v;
-        vsum[c] += v;
-      }
-    }
-  }
   // per-workgroup partial sums of A_new -> slot `tile` of the sum table of this factor
   double *sumA = NMFK_PTR(double, g, g.which == 0 ? rdp->osumH : rdp->osumW) + (int64_t)tile * KP;
   double *red = den + NMFK_MAX_K;  // [4][KP]
 #pragma unroll
   for (int c = 0; c < KP; ++c) {
-    const double v = wave_sum((double)vsum[c]);
+    T vs = (T)0;
+    if (owner) {
+#pragma unroll
+      for (int e = 0; e < LB; ++e) {
+        T v = A_(e, c) * ACC_(e, c) / (T)den[c];
+        if (c >= k || !valid[e]) v = (T)0;
+        if (valid[e]) Anew[c + (int64_t)lc[e] * KP] = v;
+        vs += v;
+      }
+    }
+    const double v = wave_sum((double)vs);
     if (lane == 0) red[wave * KP + c] = v;
   }
   __syncthreads();
@@ -447,8 +449,12 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
 // everything it can dispatch to, and a switch over ranks inside one kernel inflates it well beyond the widest
 // case.  Units of equal rank are contiguous (sorted by k), so a launch covers the unit range [u0, u0 + gridDim.y).
 // LDS: den[64], red[4*64], then the cross-wave scratch of 3*LB*KP*64 elements of T.
+// min waves per SIMD requested from the register allocator (2nd __launch_bounds__ argument = waves per EU)
+#ifndef NMFK_MINWAVES
+#define NMFK_MINWAVES(KP) ((KP) <= 16 ? 4 : 1)
+#endif
 template <bool NANS, int KP>
-__global__ __launch_bounds__(NMFK_TILE) void step_kernel(char *arena, const float *__restrict__ X,
+__global__ __launch_bounds__(NMFK_TILE, NMFK_MINWAVES(KP)) void step_kernel(char *arena, const float *__restrict__ X,
                                                          const NmfkRun *__restrict__ runs,
                                                          const NmfkState *__restrict__ state,
                                                          const NmfkStepArgs *__restrict__ gp, int it, int u0) {

@@ -16,7 +16,7 @@ for sub in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row.get("Kernel_Name", "?")
-                short = name.split("(")[0][-60:]
+                short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
                 c = row.get("Counter_Name")
                 v = float(row.get("Counter_Value", 0) or 0)
                 a = agg[short][c]

@@ -29,6 +29,17 @@ PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 
 
+def _pmc_traffic():
+    """HBM bytes per launch of the dominant per-rank kernel from the committed PMC passes (collected in separate
+    rocprofv3 --pmc runs of this command, profiles/<round>/traffic.json); None when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as fh:
+            t = json.load(fh)
+        return {"hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "kernel": t["kernel"], "source": t["source"]}
+    except Exception:
+        return None
+
+
 def cpu_baseline(X, ks, nruns, iters_by_k, threads):
     """Times the CPU oracle (C + OpenMP port of the reference's Float64 loop; oracle/nmfk_oracle.c) on this host
     for a bounded sample -- a fixed budget of MU iterations at k = min, mid, max -- and extrapolates to the whole
@@ -160,7 +171,7 @@ def main():
             line["roofline"] = {
                 "kernel": "step_kernel<KP> (half-step numerators + fused finish; all ranks, concurrent streams)",
                 "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
-                "traffic": None, "mu_loop_gpu_ms": loop["ms"], "dominant_rank_kernel": dom, "per_rank_kernel": per_kp,
+                "traffic": _pmc_traffic(), "mu_loop_gpu_ms": loop["ms"], "dominant_rank_kernel": dom, "per_rank_kernel": per_kp,
                 "note": "flops = 4*n*m*k per half-step per ACTIVE restart (W*H and the product with the ratio; SURVEY 8d: "
                         "8*n*m*k per iteration). fp32 vector and fp32 MFMA share the 157.3 TFLOP/s peak on gfx950; the "
                         "kernel issues packed fp32 FMAs (v_pk_fma_f32). HBM view: X is L2/Infinity-Cache resident "

@@ -13,6 +13,7 @@ cd /tmp
 REPO=$GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py ${BENCH_ARGS:-} > $OUT/bench_traced.json 2> $OUT/trace.err
 find $OUT/trace -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
+python3 $REPO/scripts/trace_overlap.py $OUT/trace > $OUT/trace_overlap.txt 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU \
   --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py $SHORT > /dev/null 2> $OUT/pmc_sq.err
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_tcc -- python3 $REPO/bench.py $SHORT > /dev/null 2> $OUT/pmc_tcc.err

@@ -30,12 +30,12 @@ PEAK_HBM_GBPS = 8000.0
 
 
 def _pmc_traffic():
-    """HBM bytes per launch of the dominant per-rank kernel from the committed PMC passes (collected in separate
-    rocprofv3 --pmc runs of this command, profiles/<round>/traffic.json); None when absent."""
+    """HBM bytes per launch of the dominant per-rank kernel, step_kernel<16> with 32 restarts (FETCH_SIZE x 2 +
+    WRITE_SIZE, collected in separate rocprofv3 --pmc runs of this command: profiles/r01/traffic.json); None if absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as fh:
             t = json.load(fh)
-        return {"hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "kernel": t["kernel"], "source": t["source"]}
+        return float(t["hbm_bytes_per_launch"])
     except Exception:
         return None
 

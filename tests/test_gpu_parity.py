@@ -337,3 +337,80 @@ def test_full_size_properties(NMFk, ctx):
     assert _rel(solo["W"][0] @ solo["H"][0], a[5]["W"][1] @ a[5]["H"][1], X) <= 1e-5
     un = ctx.mu_sweep([5], 1, seeds=seeds[1:2, 1:2], maxiter=30, normalize=0, **NOSTOP)[5]
     assert _rel(un["W"][0] @ un["H"][0], solo["W"][0] @ solo["H"][0], X) <= 1e-6
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "mu_golden.npz"))
+
+
+def test_golden_fixture_fixed_budget(NMFk, ctx, golden):
+    """Committed oracle outputs (tests/golden/make_golden.py): dense case A and missing-data case B."""
+    for case, tol in (("A", 1e-4), ("B", 2e-4)):
+        X, k, iters = golden[case + "_X"], int(golden[case + "_k"]), int(golden[case + "_iters"])
+        ctx.set_X(X)
+        seeds = golden[case + "_seeds"].reshape(1, -1)
+        for compute, t in ((NMFk.COMPUTE_F64, 3e-7), (NMFk.COMPUTE_F32, tol)):
+            res = ctx.mu_sweep([k], seeds.shape[1], seeds=seeds, maxiter=iters, compute=compute, **NOSTOP)[k]
+            for r in range(seeds.shape[1]):
+                ref = golden[case + "_W"][r] @ golden[case + "_H"][r]
+                assert _rel(res["W"][r] @ res["H"][r], ref, X) <= t
+                assert abs(res["objvalue"][r] - golden[case + "_obj"][r]) <= max(t, 3e-7) * golden[case + "_obj"][r]
+
+
+def test_golden_fixture_execute_and_clustering(NMFk, ctx, golden):
+    X = golden["C_X"]
+    W, H, fit, rob, aic, kopt, det = NMFk.execute(X, range(2, 6), int(golden["C_nNMF"]), load=False, save=False,
+                                                  quiet=True, seed=int(golden["C_seed"]), compute="f64",
+                                                  return_details=True)
+    assert kopt == int(golden["C_kopt"]) == 3
+    # fp64 compute from the same seeds: same iteration counts, fit and robustness as the oracle's execute()
+    same = sum(int((det[k]["iters"] == golden["C_iters"][k - 2]).sum()) for k in range(2, 6))
+    assert same >= 4 * int(golden["C_nNMF"]) - 3
+    np.testing.assert_allclose(fit[1:5], golden["C_fit"][1:5], rtol=2e-2, atol=1e-4)
+    np.testing.assert_allclose(rob[1:3], golden["C_rob"][1:3], atol=2e-2)
+    assert (np.argsort(-np.asarray(rob[1:5])) == np.argsort(-golden["C_rob"][1:5])).all()
+    labels, cent, psil, csil = ctx.cluster_silhouette(golden["D_H"])
+    assert (labels == golden["D_labels"]).all()
+    np.testing.assert_allclose(cent, golden["D_centroids"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(psil, golden["D_psil"], atol=1e-3)
+    np.testing.assert_allclose(csil, golden["D_csil"], atol=1e-3)
+
+
+def test_sparse_zeros_as_lambda(NMFk, ctx, oracle):
+    """BASELINE configs[3] semantics at a small size: 0.5%-fill X, zeros become lambda (Mult:17-18), so only the
+    non-zeros contribute to the ratio; dense kernels against the oracle."""
+    n, m, k = 400, 96, 4
+    pos = oracle.uniform_fill(61, 0, n * m).reshape(n, m) < 0.03
+    X = np.where(pos, 1 + 4 * oracle.uniform_fill(62, 0, n * m).reshape(n, m), 0.0).astype(np.float32)
+    X[:, 0] = np.maximum(X[:, 0], 0.5)  # no all-zero row (the reference only warns, Mult:9-14)
+    X[0, :] = np.maximum(X[0, :], 0.5)
+    ctx.set_X(X)
+    assert ctx.zero_count == int((X == 0).sum())
+    seeds = _seeds(NMFk, 8, [k], 2)
+    res = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=25, compute=NMFk.COMPUTE_F64, **NOSTOP)[k]
+    for r in range(2):
+        W0, H0 = oracle.init_factors(int(seeds[0, r]), n, m, k)
+        ref = oracle.singlerun(X, k, W0, H0, maxiter=25, **NOSTOP)
+        assert _rel(res["W"][r] @ res["H"][r], ref["W"] @ ref["H"], X) <= 1e-6
+        assert np.isfinite(res["W"][r]).all() and np.isfinite(res["H"][r]).all()
+
+
+def test_config5_shape_properties(NMFk, ctx):
+    """BASELINE configs[4] shape (65536 x 2048, k = 64), two restarts, a few iterations: the wide-rank kernel path at
+    full size.  Properties: finite, non-negative, H rows sum to 1, the monitored objective decreases on planted data,
+    bitwise reproducible."""
+    n, m, k = 65536, 2048, 64
+    W0 = ctx.fill_uniform(4, 0, n * 48).reshape(48, n).T
+    H0 = ctx.fill_uniform(5, 0, 48 * m).reshape(m, 48).T
+    X = (W0 @ H0 + 0.01 * ctx.fill_uniform(6, 0, n * m).reshape(m, n).T).astype(np.float32)
+    ctx.set_X(X)
+    seeds = _seeds(NMFk, 4, [k], 2)
+    a = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=3, **NOSTOP)[k]
+    b = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=6, **NOSTOP)[k]
+    c = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=6, **NOSTOP)[k]
+    assert np.isfinite(b["W"]).all() and (b["W"] >= 0).all() and (b["H"] >= 0).all()
+    np.testing.assert_allclose(b["H"].sum(axis=2), 1.0, atol=1e-3)
+    assert (b["objvalue"] < a["objvalue"]).all()
+    assert (b["W"] == c["W"]).all() and (b["objvalue"] == c["objvalue"]).all()
+    assert abs(ctx.frobenius(b["W"][0], b["H"][0]) - b["objvalue"][0]) <= 1e-4 * b["objvalue"][0]

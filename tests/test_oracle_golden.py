@@ -129,3 +129,20 @@ def test_readme_construction_kopt(oracle):
     W, H, fit, rob, aic, kopt, det = oracle.execute(X, range(2, 6), 10, seed=11)
     assert kopt == 3
     assert rob[1] > 0.9 and rob[2] > 0.5 and rob[3] < 0.5
+
+
+def test_committed_fixture_is_reproducible(oracle):
+    """tests/golden/mu_golden.npz (made by tests/golden/make_golden.py) is what the oracle computes today."""
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mu_golden.npz"))
+    k, iters = int(z["A_k"]), int(z["A_iters"])
+    n, m = z["A_X"].shape
+    for r, seed in enumerate(z["A_seeds"]):
+        W0, H0 = oracle.init_factors(int(seed), n, m, k)
+        res = oracle.singlerun(z["A_X"], k, W0, H0, maxiter=iters, maxbaditers=10 ** 9)
+        np.testing.assert_allclose(res["W"], z["A_W"][r], rtol=1e-12)
+        np.testing.assert_allclose(res["objvalue"], z["A_obj"][r], rtol=1e-12)
+    labels, cent = oracle.clustersolutions(list(z["D_H"]), tbits=32)
+    assert (labels == z["D_labels"]).all()
+    assert int(z["C_kopt"]) == 3

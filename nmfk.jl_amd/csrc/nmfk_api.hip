@@ -477,6 +477,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   NmfkStepArgs hs;
   hs.arena = A;
   hs.X = ctx->Xr;
+  hs.Xalt = ctx->Xc;
   hs.ld = m;
   hs.L = m;
   hs.D = n;
@@ -496,6 +497,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   hs.force = 0;
   NmfkStepArgs ws = hs;
   ws.X = ctx->Xc;
+  ws.Xalt = ctx->Xr;
   ws.ld = n;
   ws.L = n;
   ws.D = m;
@@ -547,6 +549,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // W half-step -> (every 10th iteration) objective + check block is the stream order; different ranks never
   // exchange data before the clustering step, so no cross-stream synchronisation is needed inside the loop.
   const int ngroups = (int)groups.size();
+  // ranks in [mfma_mink, 16] use the MFMA variant of the half-step (fp32 compute, no missing data): it keeps the
+  // matrix pipe busy while the packed-VALU kernels of the smaller ranks run on the vector pipe of the same CUs
+  int mfma_mink = 0;  // experimental, off by default: enable with NMFK_MFMA_MINK=<k>
+  if (const char *e = getenv("NMFK_MFMA_MINK")) mfma_mink = atoi(e);
+  auto use_mfma = [&](const Group &G) { return !f64 && ctx->nan_count == 0 && G.k <= 16 && mfma_mink > 0 && G.k >= mfma_mink; };
   int max_streams = 8;
   if (const char *e = getenv("NMFK_STREAMS")) max_streams = std::max(1, std::min(64, atoi(e)));
   const int NS = std::min(ngroups, max_streams);
@@ -592,6 +599,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         const size_t e0 = timed ? prof.begin(gs) : 0;
         if (f64)
           nmfk_launch_step_f64(hs, d_hs, G.kp, G.begin, G.count, gs);
+        else if (use_mfma(G))
+          nmfk_launch_step_mfma_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         else
           nmfk_launch_step_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         if (timed) prof.end(e0, PK_HSTEP, j, it, gs);
@@ -606,6 +615,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         const size_t e0 = timed ? prof.begin(gs) : 0;
         if (f64)
           nmfk_launch_step_f64(ws, d_ws, G.kp, G.begin, G.count, gs);
+        else if (use_mfma(G))
+          nmfk_launch_step_mfma_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         else
           nmfk_launch_step_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         if (timed) prof.end(e0, PK_WSTEP, j, it, gs);

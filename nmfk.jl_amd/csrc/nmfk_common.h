@@ -45,6 +45,7 @@ struct NmfkState {
 struct NmfkStepArgs {
   char *arena;
   const float *X;   // element (l, d) at X[l + d*ld]
+  const float *Xalt;  // the other copy: element (l, d) at Xalt[d + l*D] (loop dimension contiguous; MFMA variant)
   int64_t ld;
   int32_t L, D;
   int32_t S;        // grid-level splits of the loop dimension (S > 1 => fused = 0, reduce kernel finishes)
@@ -151,7 +152,7 @@ static inline int nmfk_padded_k(int k) {
 #define NMFK_UPOL 2
 #endif
 #ifndef NMFK_FASTDIV
-#define NMFK_FASTDIV 1  // fp32 ratio X/(W*H) by v_rcp_f32 + one Newton step instead of the IEEE divide sequence
+#define NMFK_FASTDIV 2  // 2: v_rcp_f32 (1 ulp) * x; 1: + one Newton step; 0: IEEE divide.  fp32 ratio X/(W*H) by v_rcp_f32 + one Newton step instead of the IEEE divide sequence
 #endif
 #define NMFK_TILE 256  // threads per workgroup = lane-tile width of the half-step kernels
 
@@ -167,6 +168,7 @@ static inline int nmfk_padded_k(int k) {
   void nmfk_launch_check_##SUF(const NmfkCheckArgs &a, int u0, int cnt, hipStream_t s);                           \
   void nmfk_launch_finish_##SUF(const NmfkFinishArgs &a, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f32)
+void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f64)
 
 // nmfk_cluster.hip

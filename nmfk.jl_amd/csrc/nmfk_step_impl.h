@@ -466,6 +466,260 @@ __global__ __launch_bounds__(NMFK_TILE, NMFK_MINWAVES(KP)) void step_kernel(char
 }
 
 // ------------------------------------------------------------------------------------------------------
+// MFMA variant of the half-step (fp32, no missing data, k <= 16), v_mfma_f32_16x16x4_f32.
+//
+// On gfx950 the fp32 MFMA rate equals the fp32 vector rate, so this kernel is not faster per se -- but it runs on
+// the MATRIX pipe while the VALU kernels of the small ranks run on the vector pipe of the same CUs (different
+// streams), and it needs ~1/3 of the VALU instructions per element (only the ratio).  Both products of a
+// 16 (loop) x 16 (lane) tile are MFMAs:
+//     P[d][l]  = sum_c B[c][d] * A[c][l]            ceil(k/4) MFMAs   (A-operand rows = loop steps d)
+//     N[c][l] += sum_d B[c][d] * Q[d][l]            4 MFMAs           (Q = X ./ P is already in B-operand layout:
+//                                                                      C/D register r of lane (g, j) = row 4g+r, col j)
+// A wave owns 64 lane elements = 4 tiles (numerators: 4 x 4 VGPRs) and walks its loop range in chunks of 16.
+// ------------------------------------------------------------------------------------------------------
+#ifdef NMFK_IS_F32
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-byte global access
+
+template <int KQ>  // KQ = ceil(kp / 4): MFMAs of the first product
+__global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const float *__restrict__ X,
+                                                              const NmfkRun *__restrict__ runs,
+                                                              const NmfkState *__restrict__ state,
+                                                              const NmfkStepArgs *__restrict__ gp, int it, int u0) {
+  __shared__ double lds[5 * NMFK_MAX_K + 3 * 16 * 32];  // den[64], red[4*64], cross-wave scratch 3 x 16 x 64 floats
+  const int u = u0 + blockIdx.y;
+  if (!gp->force && !state[u].active) return;
+  const NmfkRun *__restrict__ rdp = runs + u;
+  const int kp = rdp->kp, k = rdp->k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int which = gp->which, ws = gp->wsplit, S = gp->S, L = gp->L, D = gp->D;
+  const int64_t ld = gp->ld;
+  const int lpw = (ws == 4) ? 64 : NMFK_TILE;
+  const int tile = blockIdx.x / S, s = blockIdx.x - tile * S;
+  const int l0 = tile * lpw + ((ws == 4) ? 0 : wave * 64);
+
+  const float *__restrict__ Hcur = (const float *)(arena + NMFK_HOFF(*rdp, it));
+  const float *__restrict__ Hnew = (const float *)(arena + NMFK_HOFF(*rdp, it + 1));
+  const float *__restrict__ Wt = (const float *)(arena + rdp->oWt);
+  const float *__restrict__ A = which == 0 ? Hcur : Wt;  // lane factor
+  const float *__restrict__ B = which == 0 ? Wt : Hnew;  // loop factor
+
+  int d0 = s * gp->dchunk;
+  int d1 = min(D, d0 + gp->dchunk);
+  if (ws == 4) {
+    const int q = (((d1 - d0 + 3) >> 2) + 15) & ~15;  // quarter of the range per wave, in whole chunks
+    d0 = min(d0 + wave * q, d1);
+    d1 = min(d0 + q, d1);
+  }
+
+  // Signal index of the first product's contraction: MFMA step sq, k-lane g  <->  c = KQ*g + sq, so that the KQ
+  // values a lane needs from one loop-factor row are contiguous and KQ = ceil(k/4) steps cover all signals.
+  // B-operand fragments of the first product, persistent: A[c = KQ*g + sq][l = l0 + 16t + c16]
+  float afrag[4][KQ];
+  int lt[4];
+  bool lv[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int l = l0 + 16 * t + c16;
+    lv[t] = l < L;
+    lt[t] = lv[t] ? l : 0;
+#pragma unroll
+    for (int sq = 0; sq < KQ; ++sq) {
+      const int c = KQ * g + sq;
+      afrag[t][sq] = (lv[t] && c < k) ? A[c + (int64_t)lt[t] * kp] : 0.0f;
+    }
+  }
+  f32x4_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // X is read from the copy in which the LOOP dimension is contiguous (Xalt: element (l, d) at d + l*D), so the
+  // four rows 4g..4g+3 of a lane are one 16-byte load; the 16 x kp chunk of the loop factor is staged through a
+  // per-wave LDS buffer (one 16-byte load per lane) and read back as fragments.  Loads run one chunk ahead.
+  const float *__restrict__ Xa = gp->Xalt;
+  float *stage = (float *)(lds + 5 * NMFK_MAX_K) + wave * (16 * 16 + 16);  // 16 rows x kp (<= 16) floats
+  const int nload = 4 * kp;  // 16-byte pieces of a chunk (16 rows x kp floats), one per lane
+  const int nch = (d1 - d0 + 15) >> 4;
+
+  auto load_x = [&](int dch, f32x4_t (&xv)[4]) __attribute__((always_inline)) {
+    // rows dch + 4g .. +3 of lane element lt[t]; rows past d1 are masked later, keep the address in range
+    int dx = dch + 4 * g;
+    dx = min(dx, D - 4);
+    dx = max(dx, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float *px = Xa + (int64_t)lt[t] * D + dx;
+      if (D >= 4) {
+        xv[t] = *(const f32x4_u *)px;  // dword-aligned 16-byte load
+      } else {
+        xv[t] = (f32x4_t){px[0], D > 1 ? px[1] : 0.f, D > 2 ? px[2] : 0.f, 0.f};
+      }
+    }
+  };
+  auto load_b = [&](int dch) __attribute__((always_inline)) -> f32x4_t {
+    f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (lane < nload) {
+      const int64_t o = (int64_t)dch * kp + 4 * lane;  // floats
+      const int64_t end = (int64_t)D * kp;             // the factor ends here; pieces beyond it are zero
+      if (o + 4 <= end) {
+        v = *(const f32x4_u *)(B + o);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (o + e < end) v[e] = B[o + e];
+      }
+    }
+    return v;
+  };
+
+  f32x4_t xcur[4], xnxt[4];
+  f32x4_t bcur, bnxt;
+  if (nch > 0) {
+    load_x(d0, xcur);
+    bcur = load_b(d0);
+  }
+  for (int ci = 0; ci < nch; ++ci) {
+    const int dch = d0 + 16 * ci;
+    // stage this chunk of the loop factor, then start the next chunk's loads
+    if (lane < nload) *(f32x4_t *)(stage + 4 * lane) = bcur;
+    if (ci + 1 < nch) {
+      load_x(dch + 16, xnxt);
+      bnxt = load_b(dch + 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // fragments: first product rows on c16 (KQ contiguous signals), second product signals on c16
+    const int rowP = min(c16, d1 - 1 - dch);  // rows past d1: any valid row (their q is zeroed)
+    float bP[KQ];
+    {
+      const float *pr = stage + rowP * kp + KQ * g;
+#pragma unroll
+      for (int sq = 0; sq < KQ; ++sq) bP[sq] = (KQ * g + sq < k) ? pr[sq] : 0.0f;
+    }
+    float bN[4];
+    bool rv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int dl = 4 * g + r;
+      rv[r] = dch + dl < d1;
+      bN[r] = (rv[r] && c16 < k) ? stage[dl * kp + c16] : 0.0f;
+    }
+    // x rows: the 16-byte load started at min(dch + 4g, D - 4); shift when it was clamped
+    const int shift = (dch + 4 * g) - max(min(dch + 4 * g, D - 4), 0);
+    f32x4_t p[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sq = 0; sq < KQ; ++sq)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bP[sq], afrag[t][sq], p[t], 0, 0, 0);
+    f32x4_t q[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float xx = xcur[t][r];
+        if (shift != 0) {  // only the last chunk of a range that is not a multiple of 4 rows long
+          const int rr = r + shift;
+          xx = rr == 0 ? xcur[t][0] : rr == 1 ? xcur[t][1] : rr == 2 ? xcur[t][2] : xcur[t][3];
+        }
+        q[t][r] = rv[r] ? div_t(xx, p[t][r]) : 0.0f;
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bN[r], q[t][r], acc[t], 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xcur[t] = xnxt[t];
+    bcur = bnxt;
+  }
+  // acc[t][r] = numerator of signal c = 4g + r at lane element l0 + 16t + c16
+
+  float *ldsF = (float *)(lds + 5 * NMFK_MAX_K);
+  if (ws == 4) {  // add the four waves' numerators in wave order
+    __syncthreads();  // the scratch overlays the waves' staging buffers: everybody must have left the loop
+    if (wave > 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ldsF[(((wave - 1) * 4 + t) * 4 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll 1
+      for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][r] += ldsF[((w * 4 + t) * 4 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  const bool owner = (ws == 1) || (wave == 0);
+
+  if (!gp->fused) {
+    if (owner) {
+      float *__restrict__ part = (float *)(arena + rdp->opart);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (lv[t]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 4 * g + r;
+            if (c < kp) part[((int64_t)s * L + lt[t]) * kp + c] = acc[t][r];
+          }
+        }
+    }
+    return;
+  }
+
+  const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
+  const int PB = which == 0 ? gp->PW : gp->PH;
+  double *den = lds;
+  if (tid < kp) {
+    double sd = 0;
+    for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * kp + tid];
+    den[tid] = sd;
+  }
+  __syncthreads();
+  float *__restrict__ Anew = which == 0 ? (float *)(arena + NMFK_HOFF(*rdp, it + 1)) : (float *)(arena + rdp->oWt);
+  float vs[4] = {0.f, 0.f, 0.f, 0.f};  // per signal c = 4g + r: sum over this lane's elements
+  if (owner) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 4 * g + r;
+        float v = 0.f;
+        if (lv[t] && c < k) {
+          v = A[c + (int64_t)lt[t] * kp] * acc[t][r] / (float)den[c];  // Mult:67 / Mult:70 operation order
+          Anew[c + (int64_t)lt[t] * kp] = v;
+        } else if (lv[t] && c < kp) {
+          Anew[c + (int64_t)lt[t] * kp] = 0.f;
+        }
+        vs[r] += v;
+      }
+  }
+  // partial sums of A_new: over the 16 lanes of a group, then over waves -> slot `tile`
+  double *sumA = (double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)) + (int64_t)tile * kp;
+  double *red = den + NMFK_MAX_K;  // [4][16]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double v = (double)vs[r];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (c16 == 0) red[wave * 16 + 4 * g + r] = v;
+  }
+  __syncthreads();
+  if (tid < kp) {
+    const double t = (ws == 4) ? red[tid] : ((red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]));
+    sumA[tid] = (tid < k) ? t : 0.0;
+  }
+}
+
+#endif
+
+// ------------------------------------------------------------------------------------------------------
 // half-step finish: A_new = A .* (sum of partial numerators) ./ sumB ;  sumA_new   (one workgroup per unit)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NMFK_TILE) void reduce_kernel(NmfkStepArgs g, int u0) {
@@ -759,6 +1013,21 @@ void NMFK_NAME(nmfk_launch_step)(const NmfkStepArgs &a, const NmfkStepArgs *darg
                                  hipStream_t s) {
   NMFK_DISPATCH_KP(kp, NMFK_LAUNCH_CASE)
 }
+
+#ifdef NMFK_IS_F32
+void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s) {
+  const int lpw = a.wsplit == 4 ? 64 : NMFK_TILE;
+  const int ntile = (a.L + lpw - 1) / lpw;
+  const dim3 grid(ntile * a.S, cnt), blk(NMFK_TILE);
+  switch ((kp + 3) / 4) {
+    case 1: hipLaunchKernelGGL((mfma_step_kernel<1>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0); break;
+    case 2: hipLaunchKernelGGL((mfma_step_kernel<2>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0); break;
+    case 3: hipLaunchKernelGGL((mfma_step_kernel<3>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0); break;
+    case 4: hipLaunchKernelGGL((mfma_step_kernel<4>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0); break;
+    default: break;
+  }
+}
+#endif
 
 void NMFK_NAME(nmfk_launch_reduce)(const NmfkStepArgs &a, int u0, int cnt, hipStream_t s) {
   hipLaunchKernelGGL(reduce_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, u0);

@@ -86,6 +86,11 @@ int nmfk_mu_default_params(nmfk_mu_params *p);
 int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, int64_t ldx, double lambda, int64_t *nan_count,
                int64_t *zero_count);
 
+/* Array-valued `weight` of the monitored objective sum((((X - W*H) .* weight)[.!inan]).^2) (Mult:74,125; the
+ * assertion on its shape is Exec:484).  weight: n x m column-major (the host layer broadcasts vector forms), or NULL
+ * to clear.  It multiplies the scalar nmfk_mu_params.weight.  Cleared by nmfk_set_X. */
+int nmfk_set_weight(nmfk_ctx *ctx, const float *weight, int64_t n, int64_t m);
+
 /* Portable counter-based U(0,1) generator standing in for Julia's rand (Mult:38,48); bit-identical to the
  * oracle's (oracle/nmfk_oracle.c).  out[i] = u(seed, offset + i), i < count. */
 int nmfk_fill_uniform(nmfk_ctx *ctx, uint64_t seed, uint64_t offset, int64_t count, float *out);
@@ -128,6 +133,13 @@ int nmfk_mu_batch(nmfk_ctx *ctx, int k, int nruns, const float *Winit, const flo
  *  cluster_sil k      mean silhouette per cluster (Fin:66); robustness = minimum (Exec:638) is the caller's */
 int nmfk_cluster_silhouette(nmfk_ctx *ctx, int k, int nsol, int64_t m, const float *Hstack, int32_t *labels,
                             float *centroids, float *point_sil, float *cluster_sil);
+
+/* Silhouettes for GIVEN labels (the second half of nmfk_cluster_silhouette on its own).  Needed by the
+ * clusterWmatrix=true path, where the reference clusters the W matrices in place -- the first solution's W becomes
+ * the centroid (Clus:453-455, 484, 512) -- and `finalize` (Fin:45-50) then computes the silhouettes on the MUTATED
+ * stack with the labels found before.  stack: nsol x (k x len) signal-major, labels k x nsol. */
+int nmfk_silhouette(nmfk_ctx *ctx, int k, int nsol, int64_t m, const float *stack, const int32_t *labels,
+                    float *point_sil, float *cluster_sil);
 
 /* Cluster means and corrected variances of W and H (Fin:64-77; used when best=false, Exec:655-658).
  *  Wstack nsol x (n x k), Hstack nsol x (k x m), labels k x nsol  ->  Wmean, Wvar (n x k), Hmean, Hvar (k x m) */

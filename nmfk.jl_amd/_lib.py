@@ -76,6 +76,8 @@ def lib():
     L.nmfk_mu_batch.argtypes = [vp, C.c_int, C.c_int, fp, fp, C.POINTER(C.c_uint64), C.POINTER(MuParams), fp, fp, fp,
                                 dp, ip, ip]
     L.nmfk_cluster_silhouette.argtypes = [vp, C.c_int, C.c_int, C.c_int64, fp, ip, fp, fp, fp]
+    L.nmfk_silhouette.argtypes = [vp, C.c_int, C.c_int, C.c_int64, fp, ip, fp, fp]
+    L.nmfk_set_weight.argtypes = [vp, fp, C.c_int64, C.c_int64]
     L.nmfk_cluster_stats.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int64, fp, fp, ip, fp, fp, fp, fp]
     L.nmfk_frobenius.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_double)]
     L.nmfk_set_profiling.argtypes = [vp, C.c_int]
@@ -224,6 +226,32 @@ class Context:
         _check(lib().nmfk_cluster_silhouette(self._h, k, nsol, m, stack.ctypes.data, labels.ctypes.data,
                                              cent.ctypes.data, psil.ctypes.data, csil.ctypes.data))
         return labels.T, cent.T, psil.T, csil
+
+    def silhouette(self, Hs, labels):
+        """nmfk_silhouette: silhouettes of the stack Hs (nsol, k, len) for GIVEN labels (k, nsol)."""
+        Hs = np.asarray(Hs, dtype=np.float32)
+        nsol, k, m = Hs.shape
+        stack = np.ascontiguousarray(np.transpose(Hs, (0, 2, 1)))
+        lab = np.ascontiguousarray(np.asarray(labels, dtype=np.int32).T)
+        psil = np.empty((nsol, k), dtype=np.float32)
+        csil = np.empty(k, dtype=np.float32)
+        _check(lib().nmfk_silhouette(self._h, k, nsol, m, stack.ctypes.data, lab.ctypes.data, psil.ctypes.data,
+                                     csil.ctypes.data))
+        return psil.T, csil
+
+    def set_weight(self, weight):
+        """Array-valued `weight` of the monitored objective (Mult:74): scalar handled by MuParams.weight; a vector of
+        length n or an (n, m) / (1, m) array is broadcast like Julia's `.*` against the residual.  None clears."""
+        if weight is None:
+            _check(lib().nmfk_set_weight(self._h, None, 0, 0))
+            return
+        w = np.asarray(weight, dtype=np.float32)
+        if w.ndim == 1:
+            if w.shape[0] != self.n:
+                raise NMFkError(ERR_BAD_ARG, "length(weight) == size(X, 1)")  # Exec:484
+            w = w[:, None]
+        w = np.asfortranarray(np.broadcast_to(w, (self.n, self.m)))
+        _check(lib().nmfk_set_weight(self._h, w.ctypes.data, self.n, self.m))
 
     def cluster_stats(self, Ws, Hs, labels):
         """nmfk_cluster_stats (Fin:64-77).  Ws (nsol, n, k), Hs (nsol, k, m), labels (k, nsol)."""

@@ -75,6 +75,7 @@ struct nmfk_ctx {
   // data
   int64_t n = 0, m = 0;
   float *Xc = nullptr, *Xr = nullptr;
+  float *Wgt = nullptr;  // optional n x m weight array of the monitored objective
   int64_t nan_count = 0, zero_count = 0;
   double lambda = 1e-32;
   // workspaces
@@ -217,6 +218,7 @@ NMFK_EXPORT int nmfk_destroy(nmfk_ctx *ctx) {
   if (ctx->poll_stream) (void)hipStreamDestroy(ctx->poll_stream);
   if (ctx->Xc) (void)hipFree(ctx->Xc);
   if (ctx->Xr) (void)hipFree(ctx->Xr);
+  if (ctx->Wgt) (void)hipFree(ctx->Wgt);
   ctx->arena.release();
   ctx->scratch.release();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -245,6 +247,8 @@ NMFK_EXPORT int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, 
   if (ctx->Xr) (void)hipFree(ctx->Xr);
   ctx->Xc = ctx->Xr = nullptr;
   ctx->n = ctx->m = 0;
+  if (ctx->Wgt) (void)hipFree(ctx->Wgt);
+  ctx->Wgt = nullptr;
   HIPCHECK(hipMalloc((void **)&ctx->Xc, bytes));
   HIPCHECK(hipMalloc((void **)&ctx->Xr, bytes));
   const size_t inbytes = (size_t)ldx * (size_t)m * sizeof(float);
@@ -272,6 +276,20 @@ NMFK_EXPORT int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, 
   ctx->zero_count = (int64_t)h[2];
   if (nan_count) *nan_count = ctx->nan_count;
   if (zero_count) *zero_count = ctx->zero_count;
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_set_weight(nmfk_ctx *ctx, const float *weight, int64_t n, int64_t m) {
+  if (!ctx) return fail(NMFK_ERR_BAD_ARG, "ctx is null");
+  if (!ctx->Xc) return fail(NMFK_ERR_NO_X, "nmfk_set_X has not been called");
+  HIPCHECK(hipSetDevice(ctx->device));
+  if (ctx->Wgt) (void)hipFree(ctx->Wgt);
+  ctx->Wgt = nullptr;
+  if (!weight) return NMFK_OK;
+  if (n != ctx->n || m != ctx->m) return fail(NMFK_ERR_BAD_ARG, "weight must have the size of X");
+  HIPCHECK(hipMalloc((void **)&ctx->Wgt, sizeof(float) * (size_t)n * (size_t)m));
+  HIPCHECK(hipMemcpyAsync(ctx->Wgt, weight, sizeof(float) * (size_t)n * (size_t)m, hipMemcpyDefault, ctx->stream));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
   return NMFK_OK;
 }
 
@@ -517,6 +535,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   NmfkSseArgs sa;
   sa.arena = A;
   sa.Xc = ctx->Xc;
+  sa.Wgt = ctx->Wgt;
   sa.n = n;
   sa.m = m;
   sa.hsel = 0;
@@ -553,7 +572,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // matrix pipe busy while the packed-VALU kernels of the smaller ranks run on the vector pipe of the same CUs
   int mfma_mink = 0;  // experimental, off by default: enable with NMFK_MFMA_MINK=<k>
   if (const char *e = getenv("NMFK_MFMA_MINK")) mfma_mink = atoi(e);
-  auto use_mfma = [&](const Group &G) { return !f64 && ctx->nan_count == 0 && G.k <= 16 && mfma_mink > 0 && G.k >= mfma_mink; };
+  auto use_mfma = [&](const Group &G) { return !f64 && ctx->nan_count == 0 && n >= 16 && m >= 16 && G.k <= 16 && mfma_mink > 0 && G.k >= mfma_mink; };
   int max_streams = 8;
   if (const char *e = getenv("NMFK_STREAMS")) max_streams = std::max(1, std::min(64, atoi(e)));
   const int NS = std::min(ngroups, max_streams);
@@ -666,9 +685,23 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
 
   // objvalue = normnan(X - W*H) on the final factors, normalisation, T-typed outputs (Exec:790-805)
   sa.hsel = -1;
-  sa.weight = 1.0;
   sa.force = 1;
   sa.total_iters = total_iters;
+  // Mult:125: sum(((X - W*H) .* weight)[.!inan].^2) on the final factors (only needed when a weight is in play)
+  const size_t o_sse = 0;
+  const bool weighted = ctx->Wgt != nullptr || P.weight != 1.0;
+  if (weighted && sse_out) {
+    if (ctx->scratch.ensure(sizeof(double) * (size_t)nunits)) return fail(NMFK_ERR_HIP, "out of device memory");
+    if (f64) {
+      nmfk_launch_sse_f64(sa, 0, nunits, st);
+      nmfk_launch_sum_parts_f64(A, d_runs, nunits, tiles_n, (double *)(ctx->scratch.p + o_sse), st);
+    } else {
+      nmfk_launch_sse_f32(sa, 0, nunits, st);
+      nmfk_launch_sum_parts_f32(A, d_runs, nunits, tiles_n, (double *)(ctx->scratch.p + o_sse), st);
+    }
+  }
+  sa.weight = 1.0;
+  sa.Wgt = nullptr;
   NmfkFinishArgs fa;
   fa.arena = A;
   fa.n = n;
@@ -715,16 +748,16 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   (void)hipEventDestroy(start_ev);
   for (auto &e : gev) (void)hipEventDestroy(e);
 
-  // Mult:125: sum(((X - W*H) .* weight)[.!inan].^2) = (weight * normnan(X - W*H))^2 for a scalar weight.
-  // sse_out may be device memory: stage through a host vector.
+  // sse_out (Mult:125); it may be device memory: stage through a host vector.  Unweighted: normnan(X - W*H)^2.
   if (sse_out) {
-    std::vector<double> tmp(nruns);
+    std::vector<double> all(nunits), tmp(nruns);
+    if (weighted) HIPCHECK(hipMemcpy(all.data(), ctx->scratch.p + o_sse, sizeof(double) * nunits, hipMemcpyDeviceToHost));
     for (int q = 0; q < nk; ++q) {
       if (!sse_out[q]) continue;
-      for (int r = 0; r < nruns; ++r) {
-        const double f = (double)h_frob[q][r] * P.weight;
-        tmp[r] = f * f;
-      }
+      for (int r = 0; r < nruns; ++r) tmp[r] = (double)h_frob[q][r] * (double)h_frob[q][r];
+      if (weighted)
+        for (int u = 0; u < nunits; ++u)
+          if (runs[u].kidx == q) tmp[runs[u].ridx] = all[u];
       HIPCHECK(hipMemcpy(sse_out[q], tmp.data(), sizeof(double) * nruns, hipMemcpyDefault));
     }
   }
@@ -809,6 +842,32 @@ NMFK_EXPORT int nmfk_cluster_silhouette(nmfk_ctx *ctx, int k, int nsol, int64_t 
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipMemcpyAsync(labels, S + oLab, sizeof(int32_t) * nT, hipMemcpyDefault, st));
   HIPCHECK(hipMemcpyAsync(centroids, S + oCen, sizeof(float) * (size_t)k * m, hipMemcpyDefault, st));
+  HIPCHECK(hipMemcpyAsync(point_sil, S + oPs, sizeof(float) * nT, hipMemcpyDefault, st));
+  HIPCHECK(hipMemcpyAsync(cluster_sil, S + oCs, sizeof(float) * k, hipMemcpyDefault, st));
+  HIPCHECK(hipStreamSynchronize(st));
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_silhouette(nmfk_ctx *ctx, int k, int nsol, int64_t m64, const float *stack, const int32_t *labels,
+                                float *point_sil, float *cluster_sil) {
+  if (!ctx || !stack || !labels || !point_sil || !cluster_sil) return fail(NMFK_ERR_BAD_ARG, "null argument");
+  if (k < 1 || nsol < 1 || m64 < 1) return fail(NMFK_ERR_BAD_ARG, "k, nsol and m must be positive");
+  if (k > NMFK_MAX_K) return fail(NMFK_ERR_UNSUPPORTED, "k exceeds NMFK_MAX_K (64)");
+  HIPCHECK(hipSetDevice(ctx->device));
+  const int m = (int)m64;
+  const size_t nT = (size_t)k * nsol;
+  Bump B;
+  const size_t oH = B.take(sizeof(float) * nT * m), oLab = B.take(sizeof(int32_t) * nT);
+  const size_t oZ = B.take(sizeof(float) * nT * m), oNorm = B.take(sizeof(float) * nT);
+  const size_t oD = B.take(sizeof(float) * nT * nT), oPs = B.take(sizeof(float) * nT), oCs = B.take(sizeof(float) * k);
+  if (ctx->scratch.ensure(B.off)) return fail(NMFK_ERR_HIP, "out of device memory (silhouette workspace)");
+  char *S = ctx->scratch.p;
+  hipStream_t st = ctx->stream;
+  HIPCHECK(hipMemcpyAsync(S + oH, stack, sizeof(float) * nT * m, hipMemcpyDefault, st));
+  HIPCHECK(hipMemcpyAsync(S + oLab, labels, sizeof(int32_t) * nT, hipMemcpyDefault, st));
+  nmfk_launch_silhouette(k, nsol, m, (const float *)(S + oH), (const int32_t *)(S + oLab), (float *)(S + oZ),
+                         (float *)(S + oNorm), (float *)(S + oD), (float *)(S + oPs), (float *)(S + oCs), st);
+  HIPCHECK(hipGetLastError());
   HIPCHECK(hipMemcpyAsync(point_sil, S + oPs, sizeof(float) * nT, hipMemcpyDefault, st));
   HIPCHECK(hipMemcpyAsync(cluster_sil, S + oCs, sizeof(float) * k, hipMemcpyDefault, st));
   HIPCHECK(hipStreamSynchronize(st));

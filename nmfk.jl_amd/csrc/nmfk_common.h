@@ -66,6 +66,7 @@ struct NmfkStepArgs {
 struct NmfkSseArgs {
   char *arena;
   const float *Xc;  // column-major copy, element (i, j) at Xc[i + j*n]
+  const float *Wgt; // optional n x m weight array (column-major) of the monitored objective (Mult:74), or null
   int32_t n, m;
   int32_t hsel;     // which H buffer parity to read; -1 => per-unit final buffer (state.iters&1)
   double weight;
@@ -166,6 +167,8 @@ static inline int nmfk_padded_k(int k) {
   void nmfk_launch_reduce_##SUF(const NmfkStepArgs &a, int u0, int cnt, hipStream_t s);                           \
   void nmfk_launch_sse_##SUF(const NmfkSseArgs &a, int u0, int cnt, hipStream_t s);                               \
   void nmfk_launch_check_##SUF(const NmfkCheckArgs &a, int u0, int cnt, hipStream_t s);                           \
+  void nmfk_launch_sum_parts_##SUF(char *arena, const NmfkRun *runs, int nunits, int ntile, double *out,           \
+                                   hipStream_t s);                                                                \
   void nmfk_launch_finish_##SUF(const NmfkFinishArgs &a, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f32)
 void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s);

@@ -15,6 +15,7 @@
 #include "nmfk_common.h"
 #include "../../include/nmfk_hip.h"
 #include "nmfk_rng.h"
+#include <type_traits>
 
 #define NMFK_CAT2(a, b) a##b
 #define NMFK_CAT(a, b) NMFK_CAT2(a, b)
@@ -511,6 +512,8 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
     d0 = min(d0 + wave * q, d1);
     d1 = min(d0 + q, d1);
   }
+  d0 = __builtin_amdgcn_readfirstlane(d0);  // wave-uniform: keeps the chunk loop and its fast-path test scalar
+  d1 = __builtin_amdgcn_readfirstlane(d1);
 
   // Signal index of the first product's contraction: MFMA step sq, k-lane g  <->  c = KQ*g + sq, so that the KQ
   // values a lane needs from one loop-factor row are contiguous and KQ = ceil(k/4) steps cover all signals.
@@ -541,34 +544,17 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
   const int nload = 4 * kp;  // 16-byte pieces of a chunk (16 rows x kp floats), one per lane
   const int nch = (d1 - d0 + 15) >> 4;
 
+  // (the host only selects this kernel when D >= 16; the arena leaves > 1 KB of readable slack behind every factor)
   auto load_x = [&](int dch, f32x4_t (&xv)[4]) __attribute__((always_inline)) {
-    // rows dch + 4g .. +3 of lane element lt[t]; rows past d1 are masked later, keep the address in range
-    int dx = dch + 4 * g;
-    dx = min(dx, D - 4);
-    dx = max(dx, 0);
+    // rows dch + 4g .. +3 of lane element lt[t]; rows past D are masked in the tail path, keep the address in range
+    const int dx = min(dch + 4 * g, D - 4);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float *px = Xa + (int64_t)lt[t] * D + dx;
-      if (D >= 4) {
-        xv[t] = *(const f32x4_u *)px;  // dword-aligned 16-byte load
-      } else {
-        xv[t] = (f32x4_t){px[0], D > 1 ? px[1] : 0.f, D > 2 ? px[2] : 0.f, 0.f};
-      }
-    }
+    for (int t = 0; t < 4; ++t) xv[t] = *(const f32x4_u *)(Xa + (int64_t)lt[t] * D + dx);
   };
   auto load_b = [&](int dch) __attribute__((always_inline)) -> f32x4_t {
+    // piece `lane` of the 16 x kp chunk; pieces that reach past the end of the factor only feed masked rows
     f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if (lane < nload) {
-      const int64_t o = (int64_t)dch * kp + 4 * lane;  // floats
-      const int64_t end = (int64_t)D * kp;             // the factor ends here; pieces beyond it are zero
-      if (o + 4 <= end) {
-        v = *(const f32x4_u *)(B + o);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (o + e < end) v[e] = B[o + e];
-      }
-    }
+    if (lane < nload) v = *(const f32x4_u *)(B + (int64_t)dch * kp + 4 * lane);
     return v;
   };
 
@@ -578,17 +564,11 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
     load_x(d0, xcur);
     bcur = load_b(d0);
   }
-  for (int ci = 0; ci < nch; ++ci) {
-    const int dch = d0 + 16 * ci;
-    // stage this chunk of the loop factor, then start the next chunk's loads
-    if (lane < nload) *(f32x4_t *)(stage + 4 * lane) = bcur;
-    if (ci + 1 < nch) {
-      load_x(dch + 16, xnxt);
-      bnxt = load_b(dch + 16);
-    }
-    __builtin_amdgcn_wave_barrier();
-    // fragments: first product rows on c16 (KQ contiguous signals), second product signals on c16
-    const int rowP = min(c16, d1 - 1 - dch);  // rows past d1: any valid row (their q is zeroed)
+  // one chunk of 16 loop steps.  FULL: all 16 rows are inside [d0, d1) and the 16-byte X loads were not clamped
+  // (every chunk but possibly the last): no row masks, no realignment of the X registers.
+  auto chunk = [&](int dch, auto full_tag) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const int rowP = FULL ? c16 : min(c16, d1 - 1 - dch);  // rows past d1: any valid row (their q is zeroed)
     float bP[KQ];
     {
       const float *pr = stage + rowP * kp + KQ * g;
@@ -600,11 +580,9 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int dl = 4 * g + r;
-      rv[r] = dch + dl < d1;
+      rv[r] = FULL || (dch + dl < d1);
       bN[r] = (rv[r] && c16 < k) ? stage[dl * kp + c16] : 0.0f;
     }
-    // x rows: the 16-byte load started at min(dch + 4g, D - 4); shift when it was clamped
-    const int shift = (dch + 4 * g) - max(min(dch + 4 * g, D - 4), 0);
     f32x4_t p[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -613,21 +591,41 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
 #pragma unroll
       for (int t = 0; t < 4; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bP[sq], afrag[t][sq], p[t], 0, 0, 0);
     f32x4_t q[4];
+    if (FULL) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float xx = xcur[t][r];
-        if (shift != 0) {  // only the last chunk of a range that is not a multiple of 4 rows long
+        for (int r = 0; r < 4; ++r) q[t][r] = div_t(xcur[t][r], p[t][r]);
+    } else {
+      // the 16-byte X load started at min(dch + 4g, D - 4): shift the registers when it was clamped
+      const int shift = (dch + 4 * g) - min(dch + 4 * g, D - 4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
           const int rr = r + shift;
-          xx = rr == 0 ? xcur[t][0] : rr == 1 ? xcur[t][1] : rr == 2 ? xcur[t][2] : xcur[t][3];
+          const float xx = rr <= 0 ? xcur[t][0] : rr == 1 ? xcur[t][1] : rr == 2 ? xcur[t][2] : xcur[t][3];
+          q[t][r] = rv[r] ? div_t(xx, p[t][r]) : 0.0f;
         }
-        q[t][r] = rv[r] ? div_t(xx, p[t][r]) : 0.0f;
-      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bN[r], q[t][r], acc[t], 0, 0, 0);
+  };
+  for (int ci = 0; ci < nch; ++ci) {
+    const int dch = d0 + 16 * ci;
+    // stage this chunk of the loop factor, then start the next chunk's loads
+    if (lane < nload) *(f32x4_t *)(stage + 4 * lane) = bcur;
+    if (ci + 1 < nch) {
+      load_x(dch + 16, xnxt);
+      bnxt = load_b(dch + 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (dch + 16 <= d1 && dch + 16 <= D)
+      chunk(dch, std::true_type());
+    else
+      chunk(dch, std::false_type());
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int t = 0; t < 4; ++t) xcur[t] = xnxt[t];
@@ -792,7 +790,8 @@ __device__ __forceinline__ void sse_body(const NmfkSseArgs &g, const NmfkRun &rd
 #pragma unroll
     for (int c = 0; c < KP; ++c) p = fma_t(a[c], b[c], p);
     const float xf = xp[(int64_t)j * g.n];
-    const T e = ((T)xf - p) * wgt;
+    const T wij = g.Wgt ? wgt * (T)g.Wgt[ic + (int64_t)j * g.n] : wgt;
+    const T e = ((T)xf - p) * wij;
     const double e2 = (double)e * (double)e;
     bool use = valid && (xf == xf);
     if (g.force) use = use && (e == e);  // normnan skips NaN residuals too (Help:226-228)
@@ -812,6 +811,16 @@ __global__ __launch_bounds__(NMFK_TILE) void sse_kernel(NmfkSseArgs g, int u0) {
   const int sel = g.hsel >= 0 ? g.hsel : ((st.active ? g.total_iters : st.iters) & 1);
   const T *H = NMFK_PTR(const T, g, NMFK_HOFF(rd, sel));
   NMFK_DISPATCH_KP(rd.kp, NMFK_SSE_CASE)
+}
+
+// out[u] = sum of the objective partials of unit u (fixed order)
+__global__ void sum_parts_kernel(char *arena, const NmfkRun *runs, int nunits, int ntile, double *out) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nunits) return;
+  const double *part = (const double *)(arena + runs[u].ossepart);
+  double s = 0;
+  for (int t = 0; t < ntile; ++t) s += part[t];
+  out[u] = s;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1036,6 +1045,10 @@ void NMFK_NAME(nmfk_launch_reduce)(const NmfkStepArgs &a, int u0, int cnt, hipSt
 void NMFK_NAME(nmfk_launch_sse)(const NmfkSseArgs &a, int u0, int cnt, hipStream_t s) {
   const int ntile = (a.n + NMFK_TILE - 1) / NMFK_TILE;
   hipLaunchKernelGGL(sse_kernel, dim3(ntile, cnt), dim3(NMFK_TILE), 0, s, a, u0);
+}
+
+void NMFK_NAME(nmfk_launch_sum_parts)(char *arena, const NmfkRun *runs, int nunits, int ntile, double *out, hipStream_t s) {
+  hipLaunchKernelGGL(sum_parts_kernel, dim3((nunits + 63) / 64), dim3(64), 0, s, arena, runs, nunits, ntile, out);
 }
 
 void NMFK_NAME(nmfk_launch_check)(const NmfkCheckArgs &a, int u0, int cnt, hipStream_t s) {

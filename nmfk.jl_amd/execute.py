@@ -90,8 +90,6 @@ def input_checks(X, load, save, casefilename, mixture, method, algorithm, cluste
             raise NotImplementedError(f"method=:{method} is a different solver; libnmfk_hip implements method=:simple")
     if method != "simple":
         raise ValueError(f"Unknown method: {method}")  # Exec:777
-    if clusterWmatrix:
-        raise NotImplementedError("clusterWmatrix=true is not implemented yet (SURVEY.md §8f row 2)")
     X = np.asarray(X)
     if X.ndim == 2 and X.shape[0] < X.shape[1] and not quiet:
         warnings.warn(f"Processed matrix size has more columns than rows (matrix size={X.shape})!")
@@ -108,8 +106,10 @@ def _mu_params(kw):
             args[names[key]] = kw.pop(key)
         elif key == "lambda_" or key == "lambda":
             args["lambda_"] = kw.pop(key)
+    weight_array = None
     if "weight" in args and np.ndim(args["weight"]) != 0:
-        raise NotImplementedError("array-valued weight is not implemented yet (SURVEY.md §8f row 1)")
+        weight_array = np.asarray(args.pop("weight"), dtype=np.float32)  # Mult:74 broadcast; shapes of Exec:484
+    args["_weight_array"] = weight_array
     compute = kw.pop("compute", "f32")
     args["compute"] = {"f32": _lib.COMPUTE_F32, "f64": _lib.COMPUTE_F64}[compute]
     return args
@@ -123,11 +123,13 @@ def _sweep(ctx, X, ks, nNMF, kw):
     seed = kw.pop("seed", None)
     Winit, Hinit = kw.pop("Winit", None), kw.pop("Hinit", None)
     mu = _mu_params(kw)
-    for junk in ("quiet", "veryquiet", "serial", "transpose", "scale", "bootstrap", "normalizevector"):
+    weight_array = mu.pop("_weight_array")
+    normalizevector = kw.pop("normalizevector", None)
+    if normalizevector is not None and len(normalizevector) == 0:
+        normalizevector = None
+    for junk in ("quiet", "veryquiet", "serial", "transpose", "scale", "bootstrap"):
         if junk in ("transpose", "scale", "bootstrap") and kw.get(junk):
             raise NotImplementedError(f"{junk}=true is outside the hot path (default off in the reference, Exec:729)")
-        if junk == "normalizevector" and kw.get(junk) is not None and len(kw[junk]):
-            raise NotImplementedError("normalizevector is not implemented yet (SURVEY.md §8f row 1)")
         kw.pop(junk, None)
     if kw:
         # the reference swallows unknown keywords in NMFmultiplicative's kw... (Mult:24); be loud instead
@@ -156,7 +158,20 @@ def _sweep(ctx, X, ks, nNMF, kw):
             hi = {k: np.broadcast_to(Hinit, (nNMF, k, m))}
     params = _lib.default_params(**mu)
     seeds = np.array([[run_seed(seed, k, r) for r in range(nNMF)] for k in ks], dtype=np.uint64)
-    return parallel.sharded_sweep(ctx.mu_sweep, ks, nNMF, seeds, wi, hi, params, n, m), params
+    if normalizevector is not None:  # Mult:27-31: X ./= normalizevector (rows) for the duration of the loop
+        v = np.asarray(normalizevector, dtype=np.float32)
+        if v.shape != (n,):
+            raise ValueError(f"Length of normalizing vector does not match: {v.size} vs {n}")
+        ctx.set_X((np.asarray(X, dtype=np.float32) / v[:, None]).astype(np.float32), mu.get("lambda_", 1e-32))
+    ctx.set_weight(weight_array)
+    res = parallel.sharded_sweep(ctx.mu_sweep, ks, nNMF, seeds, wi, hi, params, n, m)
+    if normalizevector is not None:  # Mult:119-122: X .*= normalizevector; W .*= normalizevector, then Exec:791-792
+        ctx.set_X(X, mu.get("lambda_", 1e-32))
+        for k in ks:
+            res[k]["W"] = np.ascontiguousarray(res[k]["W"] * v[None, :, None])
+            res[k]["objvalue"] = np.array([ctx.frobenius(res[k]["W"][r], res[k]["H"][r]) for r in range(nNMF)],
+                                          dtype=np.float32)
+    return res, params
 
 
 def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1, acceptfactor=math.inf, best=True,
@@ -200,7 +215,17 @@ def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1
     Wa = Ha = None
     if nk > 1:
         Hs = np.stack([HBig[i] for i in sel])
-        labels, centroids, psil, csil = ctx.cluster_silhouette(Hs)  # Exec:623 + silhouettes of Exec:637
+        if clusterWmatrix:
+            # Exec:621: clustersolutions(WBig[idxsort][idxsol], true) works on the W matrices THEMSELVES (Clus:426-428
+            # makes no copies): the first solution's W is the running sum and ends up as the centroids (Clus:453-455,
+            # 484, 512); everything downstream (Exec:633, finalize Fin:45-50) sees the mutated array.
+            Wst = np.stack([WBig[i].T for i in sel])  # (nsol, k, n): signals as vectors of length n
+            labels, centroids, _, _ = ctx.cluster_silhouette(Wst)
+            WBig[sel[0]] = np.ascontiguousarray(centroids.T)
+            Wst[0] = centroids
+            psil, csil = ctx.silhouette(Wst, labels)
+        else:
+            labels, centroids, psil, csil = ctx.cluster_silhouette(Hs)  # Exec:623 + silhouettes of Exec:637
         Wb0, Hb0 = WBig[bestIdx], HBig[bestIdx]
         for i, c in enumerate(labels[:, 0]):  # Exec:631-635
             Wbest[:, i] = Wb0[:, c - 1]

@@ -104,7 +104,8 @@ EXPORT int nmfk_or_preprocess(double *X, int64_t n, int64_t m, double lambda, ui
 
 /* sum((((X - W*H) .* weight)[.!inan]).^2)   Mult:74,125.  Per-column partials summed in column order. */
 static double sse_masked(const double *X, const uint8_t *inan, const double *Wt /*k x n*/, const double *H,
-                         int64_t n, int64_t m, int64_t k, double weight, double *colpart) {
+                         int64_t n, int64_t m, int64_t k, double weight, const double *warr /* n x m or NULL */,
+                         double *colpart) {
 #pragma omp parallel for schedule(static)
   for (int64_t j = 0; j < m; j++) {
     const double *h = H + j * k;
@@ -114,7 +115,7 @@ static double sse_masked(const double *X, const uint8_t *inan, const double *Wt 
       const double *w = Wt + i * k;
       double p = 0;
       for (int64_t a = 0; a < k; a++) p += w[a] * h[a];
-      double e = (X[i + j * n] - p) * weight;
+      double e = (X[i + j * n] - p) * (warr ? weight * warr[i + j * n] : weight);
       s += e * e;
     }
     colpart[j] = s;
@@ -128,9 +129,11 @@ static double sse_masked(const double *X, const uint8_t *inan, const double *Wt 
  * X: n x m col-major, values of type T held in doubles; mutated during the loop and restored on exit
  * (Mult:123-124).  W (n x k), H (k x m): initial values in, final values out.  Returns 0, or -1 for a
  * negative entry.  The state machine is §3.2 of SURVEY.md, line by line. */
-EXPORT int nmfk_or_multiplicative(double *X, int64_t n, int64_t m, int64_t k, const nmfk_or_params *P, double *W,
-                                  double *H, double *sse_out, int64_t *iters_out, int32_t *reason_out,
-                                  int32_t *nchecks_out, double *objtrace /* may be NULL; len maxiter/10 */) {
+EXPORT int nmfk_or_multiplicative_ex(double *X, int64_t n, int64_t m, int64_t k, const nmfk_or_params *P, double *W,
+                                     double *H, double *sse_out, int64_t *iters_out, int32_t *reason_out,
+                                     int32_t *nchecks_out, double *objtrace /* may be NULL; len maxiter/10 */,
+                                     const double *warr /* weight array n x m (Mult:74) or NULL */,
+                                     const double *normvec /* normalizevector, length n (Mult:27-31) or NULL */) {
 #ifdef _OPENMP
   omp_set_num_threads(P->nthreads > 0 ? P->nthreads : 1);
 #endif
@@ -143,6 +146,9 @@ EXPORT int nmfk_or_multiplicative(double *X, int64_t n, int64_t m, int64_t k, co
   }
   int64_t nnan = 0;
   for (int64_t i = 0; i < N; i++) nnan += inan[i];
+  if (normvec) /* Mult:27-28  X ./= normalizevector (rows) */
+    for (int64_t j = 0; j < m; j++)
+      for (int64_t i = 0; i < n; i++) X[i + j * n] = round_T(X[i + j * n] / normvec[i], P->tbits);
 
   double *Wt = (double *)malloc(sizeof(double) * n * k);   /* k x n: row i of W contiguous */
   double *Xt = (double *)malloc(sizeof(double) * N);        /* m x n: row i of X contiguous */
@@ -222,7 +228,7 @@ EXPORT int nmfk_or_multiplicative(double *X, int64_t n, int64_t m, int64_t k, co
           }
     }
     if (iters % 10 == 0) { /* Mult:73-117 */
-      double obj = sse_masked(X, inan, Wt, H, n, m, k, P->weight, colpart);
+      double obj = sse_masked(X, inan, Wt, H, n, m, k, P->weight, warr, colpart);
       if (objtrace) objtrace[nchecks] = obj;
       nchecks++;
       if (obj < P->tol) { /* Mult:75-78 */
@@ -282,18 +288,33 @@ EXPORT int nmfk_or_multiplicative(double *X, int64_t n, int64_t m, int64_t k, co
   if (reason == 0) /* the loop guard failed (Mult:64) */
     reason = (reattempts >= P->maxreattempts || baditers >= P->maxbaditers) ? STOP_STAGNATION : STOP_MAXITER;
 
+  if (normvec) { /* Mult:119-122  X .*= normalizevector; W .*= normalizevector */
+    for (int64_t j = 0; j < m; j++)
+      for (int64_t i = 0; i < n; i++) X[i + j * n] = round_T(X[i + j * n] * normvec[i], P->tbits);
+    for (int64_t a = 0; a < k; a++)
+      for (int64_t i = 0; i < n; i++) {
+        W[i + a * n] *= normvec[i];
+        Wt[a + i * k] = W[i + a * n];
+      }
+  }
   /* Mult:123-126: restore X, final SSE on the restored X */
   for (int64_t i = 0; i < N; i++) {
     if (izero[i]) X[i] = 0;
     if (inan[i]) X[i] = NAN;
   }
-  *sse_out = sse_masked(X, inan, Wt, H, n, m, k, P->weight, colpart);
+  *sse_out = sse_masked(X, inan, Wt, H, n, m, k, P->weight, warr, colpart);
   *iters_out = iters;
   *reason_out = reason;
   if (nchecks_out) *nchecks_out = nchecks;
   free(inan); free(izero); free(Wt); free(Xt); free(Hn); free(cs); free(rs); free(colpart);
   free(index); free(canon); free(canon_old); free(first);
   return 0;
+}
+
+EXPORT int nmfk_or_multiplicative(double *X, int64_t n, int64_t m, int64_t k, const nmfk_or_params *P, double *W,
+                                  double *H, double *sse_out, int64_t *iters_out, int32_t *reason_out,
+                                  int32_t *nchecks_out, double *objtrace) {
+  return nmfk_or_multiplicative_ex(X, n, m, k, P, W, H, sse_out, iters_out, reason_out, nchecks_out, objtrace, NULL, NULL);
 }
 
 /* normnan(X - W*H)  (src/NMFkHelpers.jl:226-228 via Exec:791-792): Frobenius norm over non-NaN entries. */
@@ -319,8 +340,8 @@ EXPORT double nmfk_or_frobenius(const double *X, int64_t n, int64_t m, int64_t k
  * skipped when modifymatrices=false i.e. Wfixed/Hfixed given, Exec:486-489). */
 EXPORT int nmfk_or_singlerun(double *X, int64_t n, int64_t m, int64_t k, const nmfk_or_params *P, int32_t modifymatrices,
                              double *W, double *H, double *objvalue, double *sse_out, int64_t *iters_out,
-                             int32_t *reason_out) {
-  int rc = nmfk_or_multiplicative(X, n, m, k, P, W, H, sse_out, iters_out, reason_out, NULL, NULL);
+                             int32_t *reason_out, const double *warr, const double *normvec) {
+  int rc = nmfk_or_multiplicative_ex(X, n, m, k, P, W, H, sse_out, iters_out, reason_out, NULL, NULL, warr, normvec);
   if (rc) return rc;
   *objvalue = nmfk_or_frobenius(X, n, m, k, W, H);
   if (modifymatrices) {

@@ -63,7 +63,7 @@ def lib():
         L.nmfk_or_frobenius.argtypes = [dp, C.c_int64, C.c_int64, C.c_int64, dp, dp]
         L.nmfk_or_frobenius.restype = C.c_double
         L.nmfk_or_singlerun.argtypes = [dp, C.c_int64, C.c_int64, C.c_int64, C.POINTER(Params), C.c_int32, dp, dp, dp,
-                                        dp, C.POINTER(C.c_int64), ip]
+                                        dp, C.POINTER(C.c_int64), ip, dp, dp]
         for suf, ct in (("f32", C.c_float), ("f64", C.c_double)):
             tp = C.POINTER(ct)
             getattr(L, "nmfk_or_clustersolutions_" + suf).argtypes = [tp, C.c_int64, C.c_int64, C.c_int64, ip, tp]
@@ -128,15 +128,28 @@ def frobenius(X, W, H):
     return lib().nmfk_or_frobenius(_dp(X), n, m, W.shape[1], _dp(_f64(W)), _dp(_f64(H)))
 
 
-def singlerun(X, k, Winit, Hinit, modifymatrices=True, params=None, **kw):
-    """execute_singlerun_compute, :simple branch (Exec:729-807): (W, H, objvalue) + diagnostics."""
+def broadcast_weight(weight, n, m):
+    """Julia broadcasting of `weight` against the n x m residual (Mult:74; shapes allowed by Exec:484)."""
+    w = np.asarray(weight, dtype=np.float64)
+    if w.ndim == 1:
+        assert w.shape[0] == n
+        w = w[:, None]
+    return np.asfortranarray(np.broadcast_to(w, (n, m)))
+
+
+def singlerun(X, k, Winit, Hinit, modifymatrices=True, params=None, weight_array=None, normalizevector=None, **kw):
+    """execute_singlerun_compute, :simple branch (Exec:729-807): (W, H, objvalue) + diagnostics.
+    weight_array: array-valued `weight` (Mult:74); normalizevector: Mult:27-31, 119-122."""
     X = np.asarray(X)
     P = params or make_params(tbits=tbits_of(X), **kw)
     n, m = X.shape
     Xd, W, H = _f64(X), _f64(Winit), _f64(Hinit)
     obj, sse, iters, reason = C.c_double(), C.c_double(), C.c_int64(), C.c_int32()
+    wa = None if weight_array is None else broadcast_weight(weight_array, n, m)
+    nv = None if normalizevector is None else np.ascontiguousarray(normalizevector, dtype=np.float64)
     rc = lib().nmfk_or_singlerun(_dp(Xd), n, m, k, C.byref(P), int(modifymatrices), _dp(W), _dp(H), C.byref(obj),
-                                 C.byref(sse), C.byref(iters), C.byref(reason))
+                                 C.byref(sse), C.byref(iters), C.byref(reason), None if wa is None else _dp(wa),
+                                 None if nv is None else _dp(nv))
     if rc != 0:
         raise ValueError("All matrix entries must be nonnegative!")
     return dict(W=W, H=H, objvalue=obj.value, sse=sse.value, iters=iters.value, reason=reason.value)
@@ -286,7 +299,7 @@ def clustersolutions_np(Hs):
 
 
 def execute_run(X, nk, nNMF, inits, acceptratio=1, acceptfactor=math.inf, best=True, nanaction="zeroed", params=None,
-                **kw):
+                clusterWmatrix=False, weight_array=None, normalizevector=None, **kw):
     """execute_run (Exec:483-711), serial branch, clusterWmatrix=false, mixture=:null.
 
     inits: list of (Winit, Hinit) per run (the oracle is RNG-free; see init_factors).
@@ -299,7 +312,8 @@ def execute_run(X, nk, nNMF, inits, acceptratio=1, acceptfactor=math.inf, best=T
     modifymatrices = not (P.Wfixed or P.Hfixed)  # Exec:486-489
     WBig, HBig, objvalue, iters, reasons = [], [], [], [], []
     for i in range(nNMF):
-        r = singlerun(X, nk, inits[i][0], inits[i][1], modifymatrices=modifymatrices, params=P)
+        r = singlerun(X, nk, inits[i][0], inits[i][1], modifymatrices=modifymatrices, params=P,
+                      weight_array=weight_array, normalizevector=normalizevector)
         WBig.append(r["W"].astype(npT))  # Exec:529-531: stored as Matrix{T}
         HBig.append(r["H"].astype(npT))
         objvalue.append(npT(r["objvalue"]))
@@ -331,13 +345,17 @@ def execute_run(X, nk, nNMF, inits, acceptratio=1, acceptfactor=math.inf, best=T
     out = dict(objvalue=objvalue, idxsort=idxsort, iters=iters, reasons=reasons, WBig=WBig, HBig=HBig)
     minsil = 1.0
     if nk > 1:
-        labels, cent = clustersolutions(Hs, tbits=tb)  # Exec:623
+        if clusterWmatrix:  # Exec:621; in-place mutation of the first solution's W (Clus:453-455, 484, 512)
+            labels, cent = clustersolutions([w.T for w in Ws], tbits=tb)
+            Ws[0][...] = cent.T
+        else:
+            labels, cent = clustersolutions(Hs, tbits=tb)  # Exec:623
         ci = labels[:, 0]
         Wb0, Hb0 = WBig[bestIdx], HBig[bestIdx]
         for i, c in enumerate(ci):  # Exec:631-635
             Wbest[:, i] = Wb0[:, c - 1]
             Hbest[i, :] = Hb0[c - 1, :]
-        D, psil, csil = finalize_silhouettes(Hs, labels, tbits=tb)  # Exec:637
+        D, psil, csil = finalize_silhouettes([w.T for w in Ws] if clusterWmatrix else Hs, labels, tbits=tb)  # Exec:637
         minsil = float(np.min(csil))  # Exec:638
         out.update(labels=labels, centroids=cent, psil=psil, csil=csil, D=D)
         if not best:

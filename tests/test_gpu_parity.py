@@ -414,3 +414,62 @@ def test_config5_shape_properties(NMFk, ctx):
     assert (b["objvalue"] < a["objvalue"]).all()
     assert (b["W"] == c["W"]).all() and (b["objvalue"] == c["objvalue"]).all()
     assert abs(ctx.frobenius(b["W"][0], b["H"][0]) - b["objvalue"][0]) <= 1e-4 * b["objvalue"][0]
+
+
+def _inits_from_seeds(oracle, NMFk, seed, n, m, k, R):
+    return [oracle.init_factors(NMFk.run_seed(seed, k, r), n, m, k) for r in range(R)]
+
+
+def test_cluster_w_matrix_path(NMFk, oracle):
+    """clusterWmatrix=true (Exec:620-621, Fin:45-50) incl. the in-place mutation of the first solution's W."""
+    n, m, k0, R = 60, 18, 3, 6
+    W0 = oracle.uniform_fill(71, 0, n * k0).reshape(n, k0) ** 2
+    H0 = oracle.uniform_fill(72, 0, k0 * m).reshape(k0, m) ** 2
+    X = (W0 @ H0 + 0.01 * oracle.uniform_fill(73, 0, n * m).reshape(n, m)).astype(np.float32)
+    for k in (2, 3):
+        Wa, Ha, phi, sil, aic, ex = NMFk.execute_run(X, k, R, seed=5, maxiter=200, compute="f64", clusterWmatrix=True,
+                                                     return_details=True, **NOSTOP)
+        ref = oracle.execute_run(X, k, R, _inits_from_seeds(oracle, NMFk, 5, n, m, k, R), maxiter=200,
+                                 clusterWmatrix=True, **NOSTOP)
+        assert (ex["labels"] == ref["labels"]).all()
+        np.testing.assert_allclose(ex["csil"], ref["csil"], atol=2e-3)
+        assert abs(sil - ref["minsilhouette"]) <= 2e-3
+        np.testing.assert_allclose(Wa, ref["Wa"], rtol=2e-4, atol=1e-6)  # = cluster centroids of W (mutated best W)
+        np.testing.assert_allclose(Ha, ref["Ha"], rtol=2e-4, atol=1e-6)
+        assert abs(phi - ref["phi"]) <= 1e-3 * ref["phi"]
+
+
+def test_array_weight_and_normalizevector(NMFk, ctx, oracle):
+    """Array-valued weight of the monitored objective (Mult:74) and normalizevector (Mult:27-31, 119-122)."""
+    n, m, k, R = 40, 16, 3, 2
+    X = oracle.uniform_fill(81, 0, n * m).reshape(n, m).astype(np.float32)
+    wrow = (0.5 + oracle.uniform_fill(82, 0, n)).astype(np.float32)           # length-n vector: weights rows
+    wmat = (0.5 + oracle.uniform_fill(83, 0, n * m).reshape(n, m)).astype(np.float32)
+    for warr in (wrow, wmat):
+        # the weight only enters the monitored objective: make the stop rule depend on it (default tolOF, few checks)
+        W, H, fit, rob, aic, det = NMFk.execute(X, k, R, load=False, save=False, quiet=True, seed=3, compute="f64",
+                                                weight=warr, maxiter=400, return_details=True)
+        inits = _inits_from_seeds(oracle, NMFk, 3, n, m, k, R)
+        ref = oracle.execute_run(X, k, R, inits, maxiter=400, weight_array=warr)
+        assert list(det["iters"]) == list(ref["iters"])
+        assert abs(fit - ref["phi"]) <= 1e-5 * ref["phi"]
+    # weighted final SSE (Mult:125) straight from the C ABI
+    ctx.set_X(X)
+    ctx.set_weight(wmat)
+    seeds = _seeds(NMFk, 3, [k], R)
+    res = ctx.mu_sweep([k], R, seeds=seeds, maxiter=30, weight=2.0, compute=NMFk.COMPUTE_F64, **NOSTOP)[k]
+    ctx.set_weight(None)
+    for r in range(R):
+        Wd, Hd = res["W"][r].astype(np.float64), res["H"][r].astype(np.float64)
+        expect = float((((X - Wd @ Hd) * wmat * 2.0) ** 2).sum())
+        assert abs(res["sse"][r] - expect) <= 1e-5 * expect
+    # normalizevector
+    v = (0.5 + 2 * oracle.uniform_fill(84, 0, n)).astype(np.float32)
+    W, H, fit, rob, aic, det = NMFk.execute(X, k, R, load=False, save=False, quiet=True, seed=4, compute="f64",
+                                            normalizevector=v, maxiter=60, return_details=True, **NOSTOP)
+    inits = _inits_from_seeds(oracle, NMFk, 4, n, m, k, R)
+    ref = oracle.execute_run(X, k, R, inits, maxiter=60, normalizevector=v, **NOSTOP)
+    np.testing.assert_allclose(det["objvalue"], ref["objvalue"], rtol=1e-5)
+    assert abs(fit - ref["phi"]) <= 1e-5 * ref["phi"]
+    so = oracle.signalorder(ref["Wa"], ref["Ha"])
+    np.testing.assert_allclose(W, ref["Wa"][:, so], rtol=1e-4, atol=1e-6)

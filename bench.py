@@ -93,11 +93,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libnmfk_hip has no CPU fallback")
+    backend = os.environ.get("NMFK_DIST_BACKEND", "nccl")  # "gloo" only to rehearse the N>1 path on a 1-GPU box
+    if os.environ.get("NMFK_FORCE_DEVICE"):
+        local = int(os.environ["NMFK_FORCE_DEVICE"])
+        os.environ["LOCAL_RANK"] = str(local)
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     ks = list(range(args.kmin, args.kmax + 1))
@@ -131,7 +138,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = ctx.get_profile() if not args.no_profile else {}

@@ -149,6 +149,9 @@ static inline int nmfk_padded_k(int k) {
 #define NMFK_LB4_MAXK 0  // ranks up to this use 4 lane elements per thread
 #endif
 #define NMFK_LB_OF(KP) ((KP) <= NMFK_LB4_MAXK ? 4 : ((KP) <= 16 ? NMFK_LB : 1))
+#ifndef NMFK_MFMA_EXP
+#define NMFK_MFMA_EXP 0
+#endif
 #ifndef NMFK_UPOL
 #define NMFK_UPOL 2
 #endif

@@ -549,7 +549,11 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
     // rows dch + 4g .. +3 of lane element lt[t]; rows past D are masked in the tail path, keep the address in range
     const int dx = min(dch + 4 * g, D - 4);
 #pragma unroll
+#if NMFK_MFMA_EXP == 1  // timing experiment: no X traffic
+    for (int t = 0; t < 4; ++t) xv[t] = (f32x4_t){1.f + dx, 2.f, 3.f, 4.f};
+#else
     for (int t = 0; t < 4; ++t) xv[t] = *(const f32x4_u *)(Xa + (int64_t)lt[t] * D + dx);
+#endif
   };
   auto load_b = [&](int dch) __attribute__((always_inline)) -> f32x4_t {
     // piece `lane` of the 16 x kp chunk; pieces that reach past the end of the factor only feed masked rows
@@ -595,7 +599,11 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
+#if NMFK_MFMA_EXP == 2  // timing experiment: no reciprocal
+        for (int r = 0; r < 4; ++r) q[t][r] = xcur[t][r] * p[t][r];
+#else
         for (int r = 0; r < 4; ++r) q[t][r] = div_t(xcur[t][r], p[t][r]);
+#endif
     } else {
       // the 16-byte X load started at min(dch + 4g, D - 4): shift the registers when it was clamped
       const int shift = (dch + 4 * g) - min(dch + 4 * g, D - 4);

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(NMFK_TILE, NMFK_MINWAVES(KP)) void step_kernel(char
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-byte global access
 
-template <int KQ>  // KQ = ceil(kp / 4): MFMAs of the first product
+template <int KQ, bool FULLK>  // KQ = ceil(k / 4): MFMAs of the first product; FULLK: k == 4*KQ (no signal masks)
 __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const float *__restrict__ X,
                                                               const NmfkRun *__restrict__ runs,
                                                               const NmfkState *__restrict__ state,
@@ -494,7 +494,6 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
   const int kp = rdp->kp, k = rdp->k;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
   const int which = gp->which, ws = gp->wsplit, S = gp->S, L = gp->L, D = gp->D;
-  const int64_t ld = gp->ld;
   const int lpw = (ws == 4) ? 64 : NMFK_TILE;
   const int tile = blockIdx.x / S, s = blockIdx.x - tile * S;
   const int l0 = tile * lpw + ((ws == 4) ? 0 : wave * 64);
@@ -538,54 +537,55 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
 
   // X is read from the copy in which the LOOP dimension is contiguous (Xalt: element (l, d) at d + l*D), so the
   // four rows 4g..4g+3 of a lane are one 16-byte load; the 16 x kp chunk of the loop factor is staged through a
-  // per-wave LDS buffer (one 16-byte load per lane) and read back as fragments.  Loads run one chunk ahead.
+  // per-wave LDS buffer (one 16-byte load per lane, row stride 17 floats against bank conflicts) and read back
+  // as fragments.  Loads run one chunk ahead in two register sets (no copies).
+  // (the host only selects this kernel when D >= 16; the arena leaves > 1 KB of readable slack behind every factor)
   const float *__restrict__ Xa = gp->Xalt;
-  float *stage = (float *)(lds + 5 * NMFK_MAX_K) + wave * (16 * 16 + 16);  // 16 rows x kp (<= 16) floats
+  float *stage = (float *)(lds + 5 * NMFK_MAX_K) + wave * (16 * 17 + 4);
   const int nload = 4 * kp;  // 16-byte pieces of a chunk (16 rows x kp floats), one per lane
   const int nch = (d1 - d0 + 15) >> 4;
-
-  // (the host only selects this kernel when D >= 16; the arena leaves > 1 KB of readable slack behind every factor)
-  auto load_x = [&](int dch, f32x4_t (&xv)[4]) __attribute__((always_inline)) {
-    // rows dch + 4g .. +3 of lane element lt[t]; rows past D are masked in the tail path, keep the address in range
-    const int dx = min(dch + 4 * g, D - 4);
+  const float *xbase[4];
 #pragma unroll
-#if NMFK_MFMA_EXP == 1  // timing experiment: no X traffic
-    for (int t = 0; t < 4; ++t) xv[t] = (f32x4_t){1.f + dx, 2.f, 3.f, 4.f};
-#else
-    for (int t = 0; t < 4; ++t) xv[t] = *(const f32x4_u *)(Xa + (int64_t)lt[t] * D + dx);
-#endif
-  };
-  auto load_b = [&](int dch) __attribute__((always_inline)) -> f32x4_t {
-    // piece `lane` of the 16 x kp chunk; pieces that reach past the end of the factor only feed masked rows
-    f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if (lane < nload) v = *(const f32x4_u *)(B + (int64_t)dch * kp + 4 * lane);
-    return v;
+  for (int t = 0; t < 4; ++t) xbase[t] = Xa + (int64_t)lt[t] * D + 4 * g;
+  const float *bbase = B + 4 * lane;
+  int wofs[4];  // LDS slots of this lane's four staged floats
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int f = 4 * lane + e;
+    wofs[e] = (f / kp) * 17 + (f % kp);
+  }
+  const int pofs = c16 * 17 + KQ * g;  // first product: row c16, signals KQ*g ..
+  const int nofs = 4 * g * 17 + c16;   // second product: rows 4g + r, signal c16
+
+  auto load = [&](int dch, f32x4_t (&xv)[4], f32x4_t &bv) __attribute__((always_inline)) {
+    if (dch + 16 <= D) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xv[t] = *(const f32x4_u *)(xbase[t] + dch);
+    } else {  // rows past D are masked in the tail path; keep the address in range
+      const int dx = min(dch + 4 * g, D - 4) - 4 * g;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xv[t] = *(const f32x4_u *)(xbase[t] + dx);
+    }
+    bv = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (lane < nload) bv = *(const f32x4_u *)(bbase + (int64_t)dch * kp);
   };
 
-  f32x4_t xcur[4], xnxt[4];
-  f32x4_t bcur, bnxt;
-  if (nch > 0) {
-    load_x(d0, xcur);
-    bcur = load_b(d0);
-  }
   // one chunk of 16 loop steps.  FULL: all 16 rows are inside [d0, d1) and the 16-byte X loads were not clamped
   // (every chunk but possibly the last): no row masks, no realignment of the X registers.
-  auto chunk = [&](int dch, auto full_tag) __attribute__((always_inline)) {
+  auto chunk = [&](int dch, const f32x4_t (&xcur)[4], auto full_tag) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_tag)::value;
-    const int rowP = FULL ? c16 : min(c16, d1 - 1 - dch);  // rows past d1: any valid row (their q is zeroed)
     float bP[KQ];
     {
-      const float *pr = stage + rowP * kp + KQ * g;
+      const float *pr = stage + (FULL ? pofs : min(c16, d1 - 1 - dch) * 17 + KQ * g);
 #pragma unroll
-      for (int sq = 0; sq < KQ; ++sq) bP[sq] = (KQ * g + sq < k) ? pr[sq] : 0.0f;
+      for (int sq = 0; sq < KQ; ++sq) bP[sq] = (FULLK || KQ * g + sq < k) ? pr[sq] : 0.0f;
     }
     float bN[4];
     bool rv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int dl = 4 * g + r;
-      rv[r] = FULL || (dch + dl < d1);
-      bN[r] = (rv[r] && c16 < k) ? stage[dl * kp + c16] : 0.0f;
+      rv[r] = FULL || (dch + 4 * g + r < d1);
+      bN[r] = (rv[r] && (FULLK || c16 < k)) ? stage[nofs + 17 * r] : 0.0f;
     }
     f32x4_t p[4];
 #pragma unroll
@@ -599,11 +599,7 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-#if NMFK_MFMA_EXP == 2  // timing experiment: no reciprocal
-        for (int r = 0; r < 4; ++r) q[t][r] = xcur[t][r] * p[t][r];
-#else
         for (int r = 0; r < 4; ++r) q[t][r] = div_t(xcur[t][r], p[t][r]);
-#endif
     } else {
       // the 16-byte X load started at min(dch + 4g, D - 4): shift the registers when it was clamped
       const int shift = (dch + 4 * g) - min(dch + 4 * g, D - 4);
@@ -621,23 +617,29 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bN[r], q[t][r], acc[t], 0, 0, 0);
   };
-  for (int ci = 0; ci < nch; ++ci) {
+  // stage the chunk held in (xc, bc), start the loads of the next one into (xn, bn), compute
+  auto step = [&](int ci, const f32x4_t (&xc)[4], const f32x4_t &bc, f32x4_t (&xn)[4], f32x4_t &bn)
+                  __attribute__((always_inline)) {
     const int dch = d0 + 16 * ci;
-    // stage this chunk of the loop factor, then start the next chunk's loads
-    if (lane < nload) *(f32x4_t *)(stage + 4 * lane) = bcur;
-    if (ci + 1 < nch) {
-      load_x(dch + 16, xnxt);
-      bnxt = load_b(dch + 16);
+    if (lane < nload) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) stage[wofs[e]] = bc[e];
     }
+    if (ci + 1 < nch) load(dch + 16, xn, bn);
     __builtin_amdgcn_wave_barrier();
     if (dch + 16 <= d1 && dch + 16 <= D)
-      chunk(dch, std::true_type());
+      chunk(dch, xc, std::true_type());
     else
-      chunk(dch, std::false_type());
+      chunk(dch, xc, std::false_type());
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) xcur[t] = xnxt[t];
-    bcur = bnxt;
+  };
+  {
+    f32x4_t x0[4], x1[4], b0, b1;
+    if (nch > 0) load(d0, x0, b0);
+    for (int ci = 0; ci < nch; ci += 2) {
+      step(ci, x0, b0, x1, b1);
+      if (ci + 1 < nch) step(ci + 1, x1, b1, x0, b0);
+    }
   }
   // acc[t][r] = numerator of signal c = 4g + r at lane element l0 + 16t + c16
 
@@ -1036,11 +1038,15 @@ void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs,
   const int lpw = a.wsplit == 4 ? 64 : NMFK_TILE;
   const int ntile = (a.L + lpw - 1) / lpw;
   const dim3 grid(ntile * a.S, cnt), blk(NMFK_TILE);
+  // kp == k for k <= 16
+#define NMFK_MFMA_LAUNCH(KQ, FK) \
+  hipLaunchKernelGGL((mfma_step_kernel<KQ, FK>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0)
+  const bool fullk = (kp % 4) == 0;
   switch ((kp + 3) / 4) {
-    case 1: hipLaunchKernelGGL((mfma_step_kernel<1>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0); break;
-    case 2: hipLaunchKernelGGL((mfma_step_kernel<2>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0); break;
-    case 3: hipLaunchKernelGGL((mfma_step_kernel<3>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0); break;
-    case 4: hipLaunchKernelGGL((mfma_step_kernel<4>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0); break;
+    case 1: if (fullk) NMFK_MFMA_LAUNCH(1, true); else NMFK_MFMA_LAUNCH(1, false); break;
+    case 2: if (fullk) NMFK_MFMA_LAUNCH(2, true); else NMFK_MFMA_LAUNCH(2, false); break;
+    case 3: if (fullk) NMFK_MFMA_LAUNCH(3, true); else NMFK_MFMA_LAUNCH(3, false); break;
+    case 4: if (fullk) NMFK_MFMA_LAUNCH(4, true); else NMFK_MFMA_LAUNCH(4, false); break;
     default: break;
   }
 }

@@ -86,6 +86,14 @@ int nmfk_mu_default_params(nmfk_mu_params *p);
 int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, int64_t ldx, double lambda, int64_t *nan_count,
                int64_t *zero_count);
 
+/* Sparse X in CSC form (BASELINE configs[3], "zeros stay zeros").  The reference turns every zero into
+ * lambda = 1e-32 (Mult:17-18), so only the stored non-zeros contribute to the update ratios; the gather kernels
+ * selected by this call are that arithmetic to < 1e-30 and stream 8 B + 4k B per non-zero instead of the dense
+ * n x m passes.  colptr: m+1 offsets, rowidx/vals: nnz entries (entries <= 0 are dropped, negative => error,
+ * NaN (missing data) needs the dense path).  *kept (optional) receives the number of stored non-zeros. */
+int nmfk_set_X_csc(nmfk_ctx *ctx, int64_t n, int64_t m, int64_t nnz, const int64_t *colptr, const int32_t *rowidx,
+                   const float *vals, int64_t *kept);
+
 /* Array-valued `weight` of the monitored objective sum((((X - W*H) .* weight)[.!inan]).^2) (Mult:74,125; the
  * assertion on its shape is Exec:484).  weight: n x m column-major (the host layer broadcasts vector forms), or NULL
  * to clear.  It multiplies the scalar nmfk_mu_params.weight.  Cleared by nmfk_set_X. */

@@ -76,6 +76,7 @@ def lib():
     L.nmfk_mu_batch.argtypes = [vp, C.c_int, C.c_int, fp, fp, C.POINTER(C.c_uint64), C.POINTER(MuParams), fp, fp, fp,
                                 dp, ip, ip]
     L.nmfk_cluster_silhouette.argtypes = [vp, C.c_int, C.c_int, C.c_int64, fp, ip, fp, fp, fp]
+    L.nmfk_set_X_csc.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, fp, i64p]
     L.nmfk_silhouette.argtypes = [vp, C.c_int, C.c_int, C.c_int64, fp, ip, fp, fp]
     L.nmfk_set_weight.argtypes = [vp, fp, C.c_int64, C.c_int64]
     L.nmfk_cluster_stats.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int64, fp, fp, ip, fp, fp, fp, fp]
@@ -155,6 +156,22 @@ class Context:
         _check(lib().nmfk_set_X(self._h, Xf.ctypes.data, n, m, max(n, 1), float(lambda_), C.byref(nan), C.byref(zero)))
         self.n, self.m = n, m
         self.nan_count, self.zero_count = nan.value, zero.value
+        return self
+
+    def set_X_sparse(self, X):
+        """nmfk_set_X_csc: X is a scipy.sparse matrix (any format); zeros stay zeros (gather kernels)."""
+        Xc = X.tocsc()
+        Xc.sum_duplicates()
+        n, m = Xc.shape
+        colptr = np.ascontiguousarray(Xc.indptr, dtype=np.int64)
+        rowidx = np.ascontiguousarray(Xc.indices, dtype=np.int32)
+        vals = np.ascontiguousarray(Xc.data, dtype=np.float32)
+        kept = C.c_int64()
+        _check(lib().nmfk_set_X_csc(self._h, n, m, len(vals), colptr.ctypes.data, rowidx.ctypes.data, vals.ctypes.data,
+                                    C.byref(kept)))
+        self.n, self.m = n, m
+        self.nan_count, self.zero_count = 0, n * m - kept.value
+        self.nnz = kept.value
         return self
 
     def fill_uniform(self, seed, offset, count):

@@ -76,6 +76,11 @@ struct nmfk_ctx {
   int64_t n = 0, m = 0;
   float *Xc = nullptr, *Xr = nullptr;
   float *Wgt = nullptr;  // optional n x m weight array of the monitored objective
+  // sparse X (nmfk_set_X_csc): CSC for the H half-step, CSR for the W half-step and the objective
+  bool sparse = false;
+  int64_t nnz = 0;
+  int32_t *colptr = nullptr, *rowidx = nullptr, *rowptr = nullptr, *colidx = nullptr;
+  float *vcsc = nullptr, *vcsr = nullptr;
   int64_t nan_count = 0, zero_count = 0;
   double lambda = 1e-32;
   // workspaces
@@ -94,6 +99,16 @@ struct nmfk_ctx {
 };
 
 namespace {
+
+void free_sparse(nmfk_ctx *ctx) {
+  void *ps[] = {ctx->colptr, ctx->rowidx, ctx->rowptr, ctx->colidx, ctx->vcsc, ctx->vcsr};
+  for (void *q : ps)
+    if (q) (void)hipFree(q);
+  ctx->colptr = ctx->rowidx = ctx->rowptr = ctx->colidx = nullptr;
+  ctx->vcsc = ctx->vcsr = nullptr;
+  ctx->sparse = false;
+  ctx->nnz = 0;
+}
 
 struct Bump {
   size_t off = 0;
@@ -219,6 +234,7 @@ NMFK_EXPORT int nmfk_destroy(nmfk_ctx *ctx) {
   if (ctx->Xc) (void)hipFree(ctx->Xc);
   if (ctx->Xr) (void)hipFree(ctx->Xr);
   if (ctx->Wgt) (void)hipFree(ctx->Wgt);
+  free_sparse(ctx);
   ctx->arena.release();
   ctx->scratch.release();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -249,6 +265,7 @@ NMFK_EXPORT int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, 
   ctx->n = ctx->m = 0;
   if (ctx->Wgt) (void)hipFree(ctx->Wgt);
   ctx->Wgt = nullptr;
+  free_sparse(ctx);
   HIPCHECK(hipMalloc((void **)&ctx->Xc, bytes));
   HIPCHECK(hipMalloc((void **)&ctx->Xr, bytes));
   const size_t inbytes = (size_t)ldx * (size_t)m * sizeof(float);
@@ -279,13 +296,85 @@ NMFK_EXPORT int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, 
   return NMFK_OK;
 }
 
+NMFK_EXPORT int nmfk_set_X_csc(nmfk_ctx *ctx, int64_t n, int64_t m, int64_t nnz, const int64_t *colptr,
+                               const int32_t *rowidx, const float *vals, int64_t *kept) {
+  if (!ctx || !colptr || (nnz > 0 && (!rowidx || !vals))) return fail(NMFK_ERR_BAD_ARG, "null argument");
+  if (n <= 0 || m <= 0) return fail(NMFK_ERR_BAD_ARG, "Input array has a zero dimension!");
+  if (n > 0x7fffff00 || m > 0x7fffff00 || nnz > 0x7fffff00) return fail(NMFK_ERR_UNSUPPORTED, "size exceeds int32 range");
+  if (colptr[0] != 0 || colptr[m] != nnz) return fail(NMFK_ERR_BAD_ARG, "bad colptr");
+  HIPCHECK(hipSetDevice(ctx->device));
+  // host-side: validate, drop entries <= 0 (they are zeros: Mult:17-18 turns them into lambda), build CSR
+  std::vector<int32_t> cp(m + 1, 0), ri, rp(n + 1, 0), ci;
+  std::vector<float> vc, vr;
+  ri.reserve(nnz);
+  vc.reserve(nnz);
+  for (int64_t j = 0; j < m; ++j) {
+    if (colptr[j + 1] < colptr[j]) return fail(NMFK_ERR_BAD_ARG, "colptr is not monotone");
+    for (int64_t p = colptr[j]; p < colptr[j + 1]; ++p) {
+      const float v = vals[p];
+      const int32_t i = rowidx[p];
+      if (i < 0 || i >= n) return fail(NMFK_ERR_BAD_ARG, "row index out of range");
+      if (v < 0) return fail(NMFK_ERR_NEGATIVE, "All matrix entries must be nonnegative!");
+      if (v != v) return fail(NMFK_ERR_UNSUPPORTED, "NaN (missing) entries need the dense path (nmfk_set_X)");
+      if (v > 0) {
+        ri.push_back(i);
+        vc.push_back(v);
+        rp[i + 1]++;
+      }
+    }
+    cp[j + 1] = (int32_t)ri.size();
+  }
+  const int64_t nz = (int64_t)ri.size();
+  for (int64_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
+  ci.resize(nz);
+  vr.resize(nz);
+  {
+    std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
+    for (int64_t j = 0; j < m; ++j)
+      for (int32_t p = cp[j]; p < cp[j + 1]; ++p) {
+        const int32_t q = fill[ri[p]]++;
+        ci[q] = (int32_t)j;
+        vr[q] = vc[p];
+      }
+  }
+  if (ctx->Xc) (void)hipFree(ctx->Xc);
+  if (ctx->Xr) (void)hipFree(ctx->Xr);
+  ctx->Xc = ctx->Xr = nullptr;
+  if (ctx->Wgt) (void)hipFree(ctx->Wgt);
+  ctx->Wgt = nullptr;
+  free_sparse(ctx);
+  const size_t nzs = (size_t)std::max<int64_t>(nz, 1);
+  HIPCHECK(hipMalloc((void **)&ctx->colptr, sizeof(int32_t) * (m + 1)));
+  HIPCHECK(hipMalloc((void **)&ctx->rowptr, sizeof(int32_t) * (n + 1)));
+  HIPCHECK(hipMalloc((void **)&ctx->rowidx, sizeof(int32_t) * nzs));
+  HIPCHECK(hipMalloc((void **)&ctx->colidx, sizeof(int32_t) * nzs));
+  HIPCHECK(hipMalloc((void **)&ctx->vcsc, sizeof(float) * nzs));
+  HIPCHECK(hipMalloc((void **)&ctx->vcsr, sizeof(float) * nzs));
+  HIPCHECK(hipMemcpy(ctx->colptr, cp.data(), sizeof(int32_t) * (m + 1), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(ctx->rowptr, rp.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
+  if (nz > 0) {
+    HIPCHECK(hipMemcpy(ctx->rowidx, ri.data(), sizeof(int32_t) * nz, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->colidx, ci.data(), sizeof(int32_t) * nz, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->vcsc, vc.data(), sizeof(float) * nz, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->vcsr, vr.data(), sizeof(float) * nz, hipMemcpyHostToDevice));
+  }
+  ctx->sparse = true;
+  ctx->nnz = nz;
+  ctx->n = n;
+  ctx->m = m;
+  ctx->nan_count = 0;
+  ctx->zero_count = n * m - nz;
+  if (kept) *kept = nz;
+  return NMFK_OK;
+}
+
 NMFK_EXPORT int nmfk_set_weight(nmfk_ctx *ctx, const float *weight, int64_t n, int64_t m) {
   if (!ctx) return fail(NMFK_ERR_BAD_ARG, "ctx is null");
-  if (!ctx->Xc) return fail(NMFK_ERR_NO_X, "nmfk_set_X has not been called");
   HIPCHECK(hipSetDevice(ctx->device));
   if (ctx->Wgt) (void)hipFree(ctx->Wgt);
   ctx->Wgt = nullptr;
   if (!weight) return NMFK_OK;
+  if (!ctx->Xc) return fail(NMFK_ERR_NO_X, "nmfk_set_X has not been called (array weights need the dense path)");
   if (n != ctx->n || m != ctx->m) return fail(NMFK_ERR_BAD_ARG, "weight must have the size of X");
   HIPCHECK(hipMalloc((void **)&ctx->Wgt, sizeof(float) * (size_t)n * (size_t)m));
   HIPCHECK(hipMemcpyAsync(ctx->Wgt, weight, sizeof(float) * (size_t)n * (size_t)m, hipMemcpyDefault, ctx->stream));
@@ -336,7 +425,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
                               float *const *W_out, float *const *H_out, float *const *frob_out,
                               double *const *sse_out, int32_t *const *iters_out, int32_t *const *reason_out) {
   if (!ctx || !ks || !params || !W_out || !H_out || !frob_out) return fail(NMFK_ERR_BAD_ARG, "null argument");
-  if (!ctx->Xc) return fail(NMFK_ERR_NO_X, "nmfk_set_X has not been called");
+  if (!ctx->Xc && !ctx->sparse) return fail(NMFK_ERR_NO_X, "nmfk_set_X has not been called");
   if (nk <= 0 || nruns <= 0) return fail(NMFK_ERR_BAD_ARG, "nk and nruns must be positive");
   const nmfk_mu_params P = *params;
   if (P.compute != NMFK_COMPUTE_F32 && P.compute != NMFK_COMPUTE_F64) return fail(NMFK_ERR_BAD_ARG, "bad compute mode");
@@ -381,7 +470,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     g.slots = tiles(g.wsplit, 1);  // units with kp > 16 use one lane element per thread => the most tiles
     return g;
   };
-  const Geo gh = geometry(m, n), gw = geometry(n, m);
+  Geo gh = geometry(m, n), gw = geometry(n, m);
+  if (ctx->sparse) {  // gather kernels: one lane element per thread, always finished in-kernel
+    gh = Geo{1, 1, n, 1, (m + NMFK_TILE - 1) / NMFK_TILE};
+    gw = Geo{1, 1, m, 1, (n + NMFK_TILE - 1) / NMFK_TILE};
+  }
   const int Sh = gh.S, Sw = gw.S;
   const int PH = gh.slots, PW = gw.slots;  // slots of the sum tables: rowsum(H) is produced by the H half-step
   const int tiles_n = (n + NMFK_TILE - 1) / NMFK_TILE;  // objective kernel tiles
@@ -418,7 +511,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         rd.opart = (int64_t)B.take(std::max(tsz * pe, sizeof(int32_t) * (size_t)m));
         rd.osumW = (int64_t)B.take(sizeof(double) * (size_t)PW * kp);
         rd.osumH = (int64_t)B.take(sizeof(double) * (size_t)PH * kp);
-        rd.ossepart = (int64_t)B.take(sizeof(double) * tiles_n);
+        rd.ossepart = (int64_t)B.take(sizeof(double) * (tiles_n + 1));  // sparse objective: slot 0 = <W'W, HH'>
         rd.ocanon = (int64_t)B.take(sizeof(int32_t) * (size_t)m);
         rd.seed = seeds ? seeds[(size_t)q * nruns + r] : 0;
       }
@@ -551,7 +644,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ca.n = n;
   ca.m = m;
   ca.it = 0;
-  ca.ntile_n = tiles_n;
+  ca.ntile_n = ctx->sparse ? tiles_n + 1 : tiles_n;
   ca.PW = PW;
   ca.PH = PH;
   ca.tol = P.tol;
@@ -564,6 +657,27 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ca.state = d_state;
   ca.nunits = nunits;
 
+  NmfkSparseArgs sph, spw;  // CSC view (H half-step), CSR view (W half-step, objective)
+  sph.arena = A;
+  sph.ptr = ctx->colptr;
+  sph.idx = ctx->rowidx;
+  sph.val = ctx->vcsc;
+  sph.runs = d_runs;
+  sph.state = d_state;
+  sph.L = m;
+  sph.which = 0;
+  sph.it = 0;
+  sph.PW = PW;
+  sph.PH = PH;
+  sph.force = 0;
+  spw = sph;
+  spw.ptr = ctx->rowptr;
+  spw.idx = ctx->colidx;
+  spw.val = ctx->vcsr;
+  spw.L = n;
+  spw.which = 1;
+  const bool sparse = ctx->sparse;
+
   // Rank groups run concurrently: group j owns stream j mod NS.  Inside a group the order H half-step ->
   // W half-step -> (every 10th iteration) objective + check block is the stream order; different ranks never
   // exchange data before the clustering step, so no cross-stream synchronisation is needed inside the loop.
@@ -572,7 +686,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // matrix pipe busy while the packed-VALU kernels of the smaller ranks run on the vector pipe of the same CUs
   int mfma_mink = 0;  // experimental, off by default: enable with NMFK_MFMA_MINK=<k>
   if (const char *e = getenv("NMFK_MFMA_MINK")) mfma_mink = atoi(e);
-  auto use_mfma = [&](const Group &G) { return !f64 && ctx->nan_count == 0 && n >= 16 && m >= 16 && G.k <= 16 && mfma_mink > 0 && G.k >= mfma_mink; };
+  auto use_mfma = [&](const Group &G) { return !f64 && !ctx->sparse && ctx->nan_count == 0 && n >= 16 && m >= 16 && G.k <= 16 && mfma_mink > 0 && G.k >= mfma_mink; };
   int max_streams = 8;
   if (const char *e = getenv("NMFK_STREAMS")) max_streams = std::max(1, std::min(64, atoi(e)));
   const int NS = std::min(ngroups, max_streams);
@@ -616,7 +730,12 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       hipStream_t gs = ctx->gstreams[j % NS];
       if (!P.Hfixed) {  // Mult:66-68
         const size_t e0 = timed ? prof.begin(gs) : 0;
-        if (f64)
+        sph.it = it;
+        if (sparse && f64)
+          nmfk_launch_sp_step_f64(&sph, G.kp, G.begin, G.count, gs);
+        else if (sparse)
+          nmfk_launch_sp_step_f32(&sph, G.kp, G.begin, G.count, gs);
+        else if (f64)
           nmfk_launch_step_f64(hs, d_hs, G.kp, G.begin, G.count, gs);
         else if (use_mfma(G))
           nmfk_launch_step_mfma_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
@@ -632,7 +751,12 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       }
       if (!P.Wfixed) {  // Mult:69-71
         const size_t e0 = timed ? prof.begin(gs) : 0;
-        if (f64)
+        spw.it = it;
+        if (sparse && f64)
+          nmfk_launch_sp_step_f64(&spw, G.kp, G.begin, G.count, gs);
+        else if (sparse)
+          nmfk_launch_sp_step_f32(&spw, G.kp, G.begin, G.count, gs);
+        else if (f64)
           nmfk_launch_step_f64(ws, d_ws, G.kp, G.begin, G.count, gs);
         else if (use_mfma(G))
           nmfk_launch_step_mfma_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
@@ -647,13 +771,21 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         }
       }
       if (check) {
-        if (f64) {
+        if (sparse) {
+          spw.it = it;
+          if (f64)
+            nmfk_launch_sp_obj_f64(&spw, n, m, (it + 1) & 1, 0, P.weight, G.begin, G.count, gs);
+          else
+            nmfk_launch_sp_obj_f32(&spw, n, m, (it + 1) & 1, 0, P.weight, G.begin, G.count, gs);
+        } else if (f64) {
           nmfk_launch_sse_f64(sa, G.begin, G.count, gs);
-          nmfk_launch_check_f64(ca, G.begin, G.count, gs);
         } else {
           nmfk_launch_sse_f32(sa, G.begin, G.count, gs);
-          nmfk_launch_check_f32(ca, G.begin, G.count, gs);
         }
+        if (f64)
+          nmfk_launch_check_f64(ca, G.begin, G.count, gs);
+        else
+          nmfk_launch_check_f32(ca, G.begin, G.count, gs);
       }
     }
     total_iters = it + 1;
@@ -688,17 +820,24 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   sa.force = 1;
   sa.total_iters = total_iters;
   // Mult:125: sum(((X - W*H) .* weight)[.!inan].^2) on the final factors (only needed when a weight is in play)
+  const int fa_ntile = ctx->sparse ? tiles_n + 1 : tiles_n;
   const size_t o_sse = 0;
   const bool weighted = ctx->Wgt != nullptr || P.weight != 1.0;
+  spw.force = 1;
   if (weighted && sse_out) {
     if (ctx->scratch.ensure(sizeof(double) * (size_t)nunits)) return fail(NMFK_ERR_HIP, "out of device memory");
-    if (f64) {
+    if (sparse && f64)
+      nmfk_launch_sp_obj_f64(&spw, n, m, -1, total_iters, P.weight, 0, nunits, st);
+    else if (sparse)
+      nmfk_launch_sp_obj_f32(&spw, n, m, -1, total_iters, P.weight, 0, nunits, st);
+    else if (f64)
       nmfk_launch_sse_f64(sa, 0, nunits, st);
-      nmfk_launch_sum_parts_f64(A, d_runs, nunits, tiles_n, (double *)(ctx->scratch.p + o_sse), st);
-    } else {
+    else
       nmfk_launch_sse_f32(sa, 0, nunits, st);
-      nmfk_launch_sum_parts_f32(A, d_runs, nunits, tiles_n, (double *)(ctx->scratch.p + o_sse), st);
-    }
+    if (f64)
+      nmfk_launch_sum_parts_f64(A, d_runs, nunits, fa_ntile, (double *)(ctx->scratch.p + o_sse), st);
+    else
+      nmfk_launch_sum_parts_f32(A, d_runs, nunits, fa_ntile, (double *)(ctx->scratch.p + o_sse), st);
   }
   sa.weight = 1.0;
   sa.Wgt = nullptr;
@@ -706,7 +845,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   fa.arena = A;
   fa.n = n;
   fa.m = m;
-  fa.ntile_n = tiles_n;
+  fa.ntile_n = ctx->sparse ? tiles_n + 1 : tiles_n;
   fa.total_iters = total_iters;
   fa.normalize = P.normalize;
   fa.runs = d_runs;
@@ -717,13 +856,18 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   fa.frob = (float *const *)(d_ptrs + 4 * nk);
   fa.iters = (int32_t *const *)(d_ptrs + 5 * nk);
   fa.reason = (int32_t *const *)(d_ptrs + 6 * nk);
-  if (f64) {
+  if (sparse && f64)
+    nmfk_launch_sp_obj_f64(&spw, n, m, -1, total_iters, 1.0, 0, nunits, st);
+  else if (sparse)
+    nmfk_launch_sp_obj_f32(&spw, n, m, -1, total_iters, 1.0, 0, nunits, st);
+  else if (f64)
     nmfk_launch_sse_f64(sa, 0, nunits, st);
-    nmfk_launch_finish_f64(fa, st);
-  } else {
+  else
     nmfk_launch_sse_f32(sa, 0, nunits, st);
+  if (f64)
+    nmfk_launch_finish_f64(fa, st);
+  else
     nmfk_launch_finish_f32(fa, st);
-  }
   HIPCHECK(hipGetLastError());
 
   std::vector<std::vector<float>> h_frob(nk);
@@ -907,17 +1051,77 @@ NMFK_EXPORT int nmfk_cluster_stats(nmfk_ctx *ctx, int k, int nsol, int64_t n64, 
 
 NMFK_EXPORT int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float *H, double *out) {
   if (!ctx || !W || !H || !out) return fail(NMFK_ERR_BAD_ARG, "null argument");
-  if (!ctx->Xc) return fail(NMFK_ERR_NO_X, "nmfk_set_X has not been called");
+  if (!ctx->Xc && !ctx->sparse) return fail(NMFK_ERR_NO_X, "nmfk_set_X has not been called");
   if (k < 1) return fail(NMFK_ERR_BAD_ARG, "k must be >= 1");
   HIPCHECK(hipSetDevice(ctx->device));
   const int n = (int)ctx->n, m = (int)ctx->m;
   const int tiles = (n + 255) / 256;
+  hipStream_t st = ctx->stream;
+  if (ctx->sparse) {
+    // one-unit arena: the init kernel turns (W, H) into the signal-major layout, then the sparse objective
+    if (k > NMFK_MAX_K) return fail(NMFK_ERR_UNSUPPORTED, "k exceeds NMFK_MAX_K (64)");
+    const int kp = nmfk_padded_k(k);
+    Bump B;
+    const size_t oRun = B.take(sizeof(NmfkRun)), oSt = B.take(sizeof(NmfkState)), oPtr = B.take(2 * sizeof(void *));
+    const size_t oFlag = B.take(64), oOut = B.take(sizeof(double));
+    const size_t oWi = B.take(sizeof(float) * (size_t)n * k), oHi = B.take(sizeof(float) * (size_t)m * k);
+    NmfkRun rd;
+    memset(&rd, 0, sizeof(rd));
+    rd.k = k;
+    rd.kp = kp;
+    rd.oWt = (int64_t)B.take(sizeof(float) * (size_t)n * kp);
+    rd.oH0 = rd.oH1 = (int64_t)B.take(sizeof(float) * (size_t)m * kp);
+    rd.osumW = (int64_t)B.take(sizeof(double) * kp);
+    rd.osumH = (int64_t)B.take(sizeof(double) * kp);
+    rd.ossepart = (int64_t)B.take(sizeof(double) * (tiles + 1));
+    if (ctx->scratch.ensure(B.off)) return fail(NMFK_ERR_HIP, "out of device memory");
+    char *S = ctx->scratch.p;
+    void *ptrs[2] = {S + oWi, S + oHi};
+    HIPCHECK(hipMemcpyAsync(S + oRun, &rd, sizeof(rd), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S + oPtr, ptrs, sizeof(ptrs), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S + oWi, W, sizeof(float) * (size_t)n * k, hipMemcpyDefault, st));
+    HIPCHECK(hipMemcpyAsync(S + oHi, H, sizeof(float) * (size_t)m * k, hipMemcpyDefault, st));
+    HIPCHECK(hipMemsetAsync(S + oFlag, 0, 64, st));
+    HIPCHECK(hipStreamSynchronize(st));  // rd / ptrs are stack objects
+    NmfkInitArgs ia;
+    ia.arena = S;
+    ia.n = n;
+    ia.m = m;
+    ia.runs = (const NmfkRun *)(S + oRun);
+    ia.state = (NmfkState *)(S + oSt);
+    ia.nunits = 1;
+    ia.Winit = (const float *const *)(S + oPtr);
+    ia.Hinit = (const float *const *)(S + oPtr) + 1;
+    ia.PW = 1;
+    ia.PH = 1;
+    ia.nan_flag = (int32_t *)(S + oFlag);
+    nmfk_launch_init_f32(ia, st);
+    NmfkSparseArgs sp;
+    sp.arena = S;
+    sp.ptr = ctx->rowptr;
+    sp.idx = ctx->colidx;
+    sp.val = ctx->vcsr;
+    sp.runs = ia.runs;
+    sp.state = ia.state;
+    sp.L = n;
+    sp.which = 1;
+    sp.it = 0;
+    sp.PW = sp.PH = 1;
+    sp.force = 1;
+    nmfk_launch_sp_obj_f32(&sp, n, m, 0, 0, 1.0, 0, 1, st);
+    nmfk_launch_sum_parts_f32(S, ia.runs, 1, tiles + 1, (double *)(S + oOut), st);
+    HIPCHECK(hipGetLastError());
+    double v = 0;
+    HIPCHECK(hipMemcpyAsync(&v, S + oOut, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    *out = sqrt(v > 0 ? v : 0.0);
+    return NMFK_OK;
+  }
   Bump B;
   const size_t oW = B.take(sizeof(float) * (size_t)n * k), oH = B.take(sizeof(float) * (size_t)m * k);
   const size_t oP = B.take(sizeof(double) * tiles);
   if (ctx->scratch.ensure(B.off)) return fail(NMFK_ERR_HIP, "out of device memory");
   char *S = ctx->scratch.p;
-  hipStream_t st = ctx->stream;
   HIPCHECK(hipMemcpyAsync(S + oW, W, sizeof(float) * (size_t)n * k, hipMemcpyDefault, st));
   HIPCHECK(hipMemcpyAsync(S + oH, H, sizeof(float) * (size_t)m * k, hipMemcpyDefault, st));
   nmfk_launch_frob(ctx->Xc, n, m, k, (const float *)(S + oW), (const float *)(S + oH), (double *)(S + oP), st);

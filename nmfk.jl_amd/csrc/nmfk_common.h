@@ -77,6 +77,17 @@ struct NmfkSseArgs {
   int32_t total_iters;  // iterations the host loop executed (selects the final H buffer of still-active units)
 };
 
+// half-step / objective on sparse X: CSC view for the H half-step (L = m), CSR view otherwise (L = n)
+struct NmfkSparseArgs {
+  char *arena;
+  const int32_t *ptr;   // CSC colptr (H half-step) or CSR rowptr (W half-step), length L + 1
+  const int32_t *idx;   // row indices / column indices
+  const float *val;
+  const NmfkRun *runs;
+  const NmfkState *state;
+  int32_t L, which, it, PW, PH, force;
+};
+
 struct NmfkCheckArgs {
   char *arena;
   int32_t n, m;
@@ -172,6 +183,9 @@ static inline int nmfk_padded_k(int k) {
   void nmfk_launch_check_##SUF(const NmfkCheckArgs &a, int u0, int cnt, hipStream_t s);                           \
   void nmfk_launch_sum_parts_##SUF(char *arena, const NmfkRun *runs, int nunits, int ntile, double *out,           \
                                    hipStream_t s);                                                                \
+  void nmfk_launch_sp_step_##SUF(const void *sparse_args, int kp, int u0, int cnt, hipStream_t s);                \
+  void nmfk_launch_sp_obj_##SUF(const void *sparse_args, int n, int m, int hsel, int total_iters, double weight,   \
+                                int u0, int cnt, hipStream_t s);                                                  \
   void nmfk_launch_finish_##SUF(const NmfkFinishArgs &a, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f32)
 void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s);

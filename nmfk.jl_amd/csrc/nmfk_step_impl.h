@@ -728,6 +728,171 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
 #endif
 
 // ------------------------------------------------------------------------------------------------------
+// Sparse X (BASELINE configs[3]: zeros stay zeros).  In the reference a zero becomes lambda = 1e-32 (Mult:17-18), so
+// its ratio X/(W*H) is ~1e-32 and only the stored non-zeros contribute to the numerators: the gather form below is
+// the reference arithmetic to < 1e-30.  One thread per output element (a column of H via CSC, a row of W via CSR)
+// walks its non-zeros and gathers the other factor's k-vector (contiguous in the signal-major layout):
+//     p = <a, b_d>;  q = x / p;  acc += q * b_d ;   A_new = A .* acc ./ sumB   (fused finish, always S == 1)
+// HBM/L2-gather bound: 8 B (index + value) + 4k B of gathered factor per non-zero.
+// ------------------------------------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(NMFK_TILE) void sp_step_kernel(NmfkSparseArgs g, int u0) {
+  __shared__ double lds[5 * NMFK_MAX_K];
+  const int u = u0 + blockIdx.y;
+  if (!g.force && !g.state[u].active) return;
+  const NmfkRun rd = g.runs[u];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x;
+  const int l = tile * NMFK_TILE + tid;
+  const bool valid = l < g.L;
+  const int lc = valid ? l : 0;
+  const T *__restrict__ Hcur = NMFK_PTR(const T, g, NMFK_HOFF(rd, g.it));
+  const T *__restrict__ Hnew = NMFK_PTR(const T, g, NMFK_HOFF(rd, g.it + 1));
+  const T *__restrict__ Wt = NMFK_PTR(const T, g, rd.oWt);
+  const T *__restrict__ A = g.which == 0 ? Hcur : Wt;
+  const T *__restrict__ B = g.which == 0 ? Wt : Hnew;
+  T a[KP], acc[KP];
+#pragma unroll
+  for (int c = 0; c < KP; ++c) {
+    a[c] = A[c + (int64_t)lc * KP];
+    acc[c] = (T)0;
+  }
+  const int p0 = valid ? g.ptr[lc] : 0, p1 = valid ? g.ptr[lc + 1] : 0;
+  for (int pp = p0; pp < p1; ++pp) {
+    const int d = g.idx[pp];
+    const T x = (T)g.val[pp];
+    const T *__restrict__ b = B + (int64_t)d * KP;
+    T bv[KP];
+#pragma unroll
+    for (int c = 0; c < KP; ++c) bv[c] = b[c];
+    T pr = (T)0;
+#pragma unroll
+    for (int c = 0; c < KP; ++c) pr = fma_t(a[c], bv[c], pr);
+    const T q = div_t(x, pr);
+#pragma unroll
+    for (int c = 0; c < KP; ++c) acc[c] = fma_t(bv[c], q, acc[c]);
+  }
+  // fused finish (same as the dense kernel's): denominators from the other factor's sum table
+  const double *sumB = NMFK_PTR(const double, g, g.which == 0 ? rd.osumW : rd.osumH);
+  const int PB = g.which == 0 ? g.PW : g.PH;
+  double *den = lds;
+  if (tid < KP) {
+    double sd = 0;
+    for (int q = 0; q < PB; ++q) sd += sumB[q * KP + tid];
+    den[tid] = sd;
+  }
+  __syncthreads();
+  T *__restrict__ Anew = g.which == 0 ? NMFK_PTR(T, g, NMFK_HOFF(rd, g.it + 1)) : NMFK_PTR(T, g, rd.oWt);
+  double *sumA = NMFK_PTR(double, g, g.which == 0 ? rd.osumH : rd.osumW) + (int64_t)tile * KP;
+  double *red = den + NMFK_MAX_K;
+  const int k = rd.k;
+#pragma unroll
+  for (int c = 0; c < KP; ++c) {
+    T v = a[c] * acc[c] / (T)den[c];
+    if (c >= k || !valid) v = (T)0;
+    if (valid) Anew[c + (int64_t)lc * KP] = v;
+    const double sv = wave_sum((double)v);
+    if (lane == 0) red[wave * KP + c] = sv;
+  }
+  __syncthreads();
+  if (tid < KP) sumA[tid] = (red[tid] + red[KP + tid]) + (red[2 * KP + tid] + red[3 * KP + tid]);
+}
+
+// objective on sparse X:  sum_all (x - p)^2 = sum_nz [(x - p)^2 - p^2] + sum_all p^2,  sum_all p^2 = <W'W, HH'>.
+// part 1: non-zero terms, one thread per row (CSR), fp64 accumulation, one partial per workgroup
+template <int KP>
+__device__ __forceinline__ void sp_obj_body(const NmfkSparseArgs &g, const NmfkRun &rd, const T *__restrict__ H, double weight,
+                                            double *sh) {
+  const int i = blockIdx.x * NMFK_TILE + threadIdx.x;
+  const bool valid = i < g.L;
+  const int ic = valid ? i : 0;
+  const T *__restrict__ Wt = NMFK_PTR(const T, g, rd.oWt);
+  T a[KP];
+#pragma unroll
+  for (int c = 0; c < KP; ++c) a[c] = Wt[c + (int64_t)ic * KP];
+  const int p0 = valid ? g.ptr[ic] : 0, p1 = valid ? g.ptr[ic + 1] : 0;
+  double s = 0;
+  for (int pp = p0; pp < p1; ++pp) {
+    const T *__restrict__ b = H + (int64_t)g.idx[pp] * KP;
+    T pr = (T)0;
+#pragma unroll
+    for (int c = 0; c < KP; ++c) pr = fma_t(a[c], b[c], pr);
+    const double x = (double)g.val[pp], p = (double)pr;
+    s += (x - p) * (x - p) - p * p;
+  }
+  s = block_sum(s * weight * weight, sh);
+  if (threadIdx.x == 0) NMFK_PTR(double, g, rd.ossepart)[1 + blockIdx.x] = s;
+}
+#define NMFK_SPOBJ_CASE(KP) sp_obj_body<KP>(g, rd, H, weight, sh)
+__global__ __launch_bounds__(NMFK_TILE) void sp_obj_kernel(NmfkSparseArgs g, int hsel, int total_iters, double weight, int u0) {
+  __shared__ double sh[8];
+  const int u = u0 + blockIdx.y;
+  const NmfkState st = g.state[u];
+  if (!g.force && !st.active) return;
+  const NmfkRun rd = g.runs[u];
+  const int sel = hsel >= 0 ? hsel : ((st.active ? total_iters : st.iters) & 1);
+  const T *H = NMFK_PTR(const T, g, NMFK_HOFF(rd, sel));
+  NMFK_DISPATCH_KP(rd.kp, NMFK_SPOBJ_CASE)
+}
+
+// part 2: <W'W, HH'> -> ssepart[0].  One workgroup per unit; Gram matrices accumulated in fp64, pairs (a, b) over
+// threads, factor rows staged through LDS in chunks of 64.
+__global__ __launch_bounds__(NMFK_TILE) void sp_gram_kernel(NmfkSparseArgs g, int n, int m, int hsel, int total_iters,
+                                                           double weight, int u0) {
+  __shared__ T chunk[64 * NMFK_MAX_K];
+  __shared__ double gw[NMFK_MAX_K * NMFK_MAX_K];
+  __shared__ double sh[8];
+  const int u = u0 + blockIdx.x;
+  const NmfkState st = g.state[u];
+  if (!g.force && !st.active) return;
+  const NmfkRun rd = g.runs[u];
+  const int sel = hsel >= 0 ? hsel : ((st.active ? total_iters : st.iters) & 1);
+  const T *Wt = NMFK_PTR(const T, g, rd.oWt);
+  const T *H = NMFK_PTR(const T, g, NMFK_HOFF(rd, sel));
+  const int kp = rd.kp, npair = kp * kp, tid = threadIdx.x;
+  double total = 0;
+  for (int pass = 0; pass < 2; ++pass) {  // pass 0: G = W'W kept in LDS; pass 1: <G, HH'>
+    const T *F = pass == 0 ? Wt : H;
+    const int len = pass == 0 ? n : m;
+    double accp[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) accp[q] = 0;
+    for (int r0 = 0; r0 < len; r0 += 64) {
+      const int rows = min(64, len - r0);
+      __syncthreads();
+      for (int e = tid; e < rows * kp; e += NMFK_TILE) chunk[e] = F[(int64_t)r0 * kp + e];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int pr = tid + q * NMFK_TILE;
+        if (pr < npair) {
+          const int a = pr % kp, b = pr / kp;
+          double sacc = 0;
+          for (int r = 0; r < rows; ++r) sacc += (double)chunk[r * kp + a] * (double)chunk[r * kp + b];
+          accp[q] += sacc;
+        }
+      }
+    }
+    if (pass == 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int pr = tid + q * NMFK_TILE;
+        if (pr < npair) gw[pr] = accp[q];
+      }
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int pr = tid + q * NMFK_TILE;
+        if (pr < npair) total += accp[q] * gw[pr];
+      }
+    }
+  }
+  total = block_sum(total * weight * weight, sh);
+  if (tid == 0) NMFK_PTR(double, g, rd.ossepart)[0] = total;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // half-step finish: A_new = A .* (sum of partial numerators) ./ sumB ;  sumA_new   (one workgroup per unit)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NMFK_TILE) void reduce_kernel(NmfkStepArgs g, int u0) {
@@ -995,7 +1160,7 @@ __global__ __launch_bounds__(NMFK_TILE) void finish_kernel(NmfkFinishArgs g) {
   if (tid == 0) {
     double obj = 0;
     for (int t = 0; t < g.ntile_n; ++t) obj += NMFK_PTR(const double, g, rd.ossepart)[t];
-    g.frob[rd.kidx][rd.ridx] = (float)sqrt(obj);
+    g.frob[rd.kidx][rd.ridx] = (float)sqrt(obj > 0 ? obj : 0.0);  // (the sparse form can round to a tiny negative)
     g.iters[rd.kidx][rd.ridx] = iters;
     g.reason[rd.kidx][rd.ridx] = reason;
     st->iters = iters;
@@ -1051,6 +1216,22 @@ void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs,
   }
 }
 #endif
+
+void NMFK_NAME(nmfk_launch_sp_step)(const void *argsv, int kp, int u0, int cnt, hipStream_t s) {
+  const NmfkSparseArgs &a = *(const NmfkSparseArgs *)argsv;
+  const dim3 grid((a.L + NMFK_TILE - 1) / NMFK_TILE, cnt), blk(NMFK_TILE);
+#define NMFK_SP_CASE(KP) hipLaunchKernelGGL((sp_step_kernel<KP>), grid, blk, 0, s, a, u0)
+  NMFK_DISPATCH_KP(kp, NMFK_SP_CASE)
+}
+
+// objective of units [u0, u0 + cnt): ssepart[0] = <W'W, HH'>, ssepart[1 + tile] = non-zero terms
+void NMFK_NAME(nmfk_launch_sp_obj)(const void *argsv, int n, int m, int hsel, int total_iters, double weight, int u0,
+                                   int cnt, hipStream_t s) {
+  const NmfkSparseArgs &a = *(const NmfkSparseArgs *)argsv;  // CSR view: L = n
+  hipLaunchKernelGGL(sp_obj_kernel, dim3((a.L + NMFK_TILE - 1) / NMFK_TILE, cnt), dim3(NMFK_TILE), 0, s, a, hsel,
+                     total_iters, weight, u0);
+  hipLaunchKernelGGL(sp_gram_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, n, m, hsel, total_iters, weight, u0);
+}
 
 void NMFK_NAME(nmfk_launch_reduce)(const NmfkStepArgs &a, int u0, int cnt, hipStream_t s) {
   hipLaunchKernelGGL(reduce_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, u0);

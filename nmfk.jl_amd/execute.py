@@ -37,6 +37,19 @@ def _context(device=None):
     return ctx
 
 
+def _is_sparse(X):
+    return hasattr(X, "tocsc") and hasattr(X, "nnz")
+
+
+def _upload(ctx, X, lambda_=1e-32):
+    """Dense arrays go through NMFpreprocessing! (zeros -> lambda); scipy.sparse matrices select the gather kernels
+    (zeros stay zeros, the same arithmetic to < 1e-30; BASELINE configs[3])."""
+    if _is_sparse(X):
+        ctx.set_X_sparse(X)
+    else:
+        ctx.set_X(X, lambda_)
+
+
 def run_seed(seed, nk, run):
     """Seed of restart `run` (0-based) of rank nk.  The reference gives restart i the seed kwseed+i (Exec:536)
     and draws W = rand(n,k) then H = rand(k,m) from Julia's RNG (Mult:38,48); Julia's stream cannot be
@@ -78,11 +91,11 @@ def input_checks(X, load, save, casefilename, mixture, method, algorithm, cluste
         casefilename = "nmfk"
     if mixture not in ("null", None):
         raise NotImplementedError("mixture != :null (MixMatch, Ipopt) is outside the :simple hot path")
-    if np.ndim(X) > 2:
+    if getattr(X, "ndim", np.ndim(X)) > 2:
         raise ValueError("NMFk analysis can be executed for matrices!")  # ArgumentError, Exec:110-112
     method = str(method).lstrip(":")
     if method in _METHOD_ALIASES or method in ("nmf", "sparsity", "ipopt", "nlopt"):
-        if np.isnan(np.asarray(X, dtype=np.float32)).any() and method not in ("ipopt", "nlopt"):
+        if not _is_sparse(X) and np.isnan(np.asarray(X, dtype=np.float32)).any() and method not in ("ipopt", "nlopt"):
             warnings.warn(f"Analyzed matrix has NaN's! NMF method {method} cannot be used! "
                           "Simple multiplicative NMF will be performed!")  # Exec:128-130
             method = "simple"
@@ -90,7 +103,6 @@ def input_checks(X, load, save, casefilename, mixture, method, algorithm, cluste
             raise NotImplementedError(f"method=:{method} is a different solver; libnmfk_hip implements method=:simple")
     if method != "simple":
         raise ValueError(f"Unknown method: {method}")  # Exec:777
-    X = np.asarray(X)
     if X.ndim == 2 and X.shape[0] < X.shape[1] and not quiet:
         warnings.warn(f"Processed matrix size has more columns than rows (matrix size={X.shape})!")
     return load, save, casefilename, "null", method, algorithm, clusterWmatrix
@@ -158,6 +170,10 @@ def _sweep(ctx, X, ks, nNMF, kw):
             hi = {k: np.broadcast_to(Hinit, (nNMF, k, m))}
     params = _lib.default_params(**mu)
     seeds = np.array([[run_seed(seed, k, r) for r in range(nNMF)] for k in ks], dtype=np.uint64)
+    if normalizevector is not None and _is_sparse(X):
+        raise NotImplementedError("normalizevector with a sparse X: scale the rows of X yourself")
+    if weight_array is not None and _is_sparse(X):
+        raise NotImplementedError("array-valued weight needs the dense path")
     if normalizevector is not None:  # Mult:27-31: X ./= normalizevector (rows) for the duration of the loop
         v = np.asarray(normalizevector, dtype=np.float32)
         if v.shape != (n,):
@@ -244,7 +260,7 @@ def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1
         Wa, Ha = Wbest, Hbest  # Exec:655-658
     phi_final = ctx.frobenius(Wa, Ha)  # Exec:664-667 (E[isnan] = 0 then norm == normnan)
     phi_final = float(np.float32(phi_final))
-    numobservations = int(X.size - ctx.nan_count)  # Exec:697
+    numobservations = int(X.shape[0] * X.shape[1] - ctx.nan_count)  # Exec:697
     numparameters = Wa.size + Ha.size
     aic = 2 * numparameters + numobservations * math.log(phi_final / numobservations) if phi_final > 0 else -math.inf
     extra.update(Wbest=Wbest, Hbest=Hbest)
@@ -253,11 +269,12 @@ def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1
 
 def execute_run(X, nk, nNMF, device=None, return_details=False, **kw):
     """execute_run(X, nk, nNMF; ...) (Exec:483-711) -> (Wa, Ha, phi_final, minsilhouette, aic)."""
-    X = np.asarray(X)
-    if X.size == 0:
+    if not _is_sparse(X):
+        X = np.asarray(X)
+    if X.shape[0] * X.shape[1] == 0:
         raise ValueError(f"Input array has a zero dimension! Array size={X.shape}")
     ctx = _context(device)
-    ctx.set_X(X, kw.get("lambda_", 1e-32))
+    _upload(ctx, X, kw.get("lambda_", 1e-32))
     post = {k: kw.pop(k) for k in ("clusterWmatrix", "acceptratio", "acceptfactor", "best", "nanaction") if k in kw}
     for k in ("mixture", "resultdir", "casefilename", "loadall", "saveall", "method", "algorithm"):
         kw.pop(k, None)
@@ -279,10 +296,11 @@ def execute(X, nkrange, nNMF=10, *, cutoff=0.5, clusterWmatrix=False, mixture="n
     nkrange: an int (-> 5-tuple W, H, fit, robustness, aic) or a range/list (-> 6-tuple with kopt).
     ctx: an nmfk Context on which set_X(X) has ALREADY been called (X resident in HBM, e.g. for repeated sweeps);
     by default the per-device context is used and X is uploaded here."""
-    X = np.asarray(X)
+    if not _is_sparse(X):
+        X = np.asarray(X)
     if X.ndim > 2:
         raise ValueError("NMFk analysis can be executed for matrices!")
-    if X.size == 0:
+    if X.shape[0] * X.shape[1] == 0:
         raise ValueError(f"Input array has a zero dimension! Array size={X.shape}")  # Exec:242-244
     single = isinstance(nkrange, (int, np.integer))
     ks = [int(nkrange)] if single else [int(k) for k in nkrange]
@@ -320,7 +338,7 @@ def execute(X, nkrange, nNMF=10, *, cutoff=0.5, clusterWmatrix=False, mixture="n
 
     if ctx is None and (todo or not all(np.isinf(fitquality[[k - 1 for k in ks]]))):
         ctx = _context(device)
-        ctx.set_X(X, kw.get("lambda_", 1e-32))  # raises "All matrix entries must be nonnegative!" (Mult:4-7)
+        _upload(ctx, X, kw.get("lambda_", 1e-32))  # raises "All matrix entries must be nonnegative!" (Mult:4-7)
     if todo:
         res, _ = _sweep(ctx, X, todo, int(nNMF), kw)
         for nk in todo:

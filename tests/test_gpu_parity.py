@@ -473,3 +473,60 @@ def test_array_weight_and_normalizevector(NMFk, ctx, oracle):
     assert abs(fit - ref["phi"]) <= 1e-5 * ref["phi"]
     so = oracle.signalorder(ref["Wa"], ref["Ha"])
     np.testing.assert_allclose(W, ref["Wa"][:, so], rtol=1e-4, atol=1e-6)
+
+
+def _sparse_case(oracle, n, m, fill, seed):
+    import scipy.sparse as sp
+
+    pos = oracle.uniform_fill(seed, 0, n * m).reshape(n, m) < fill
+    X = np.where(pos, 1 + 4 * oracle.uniform_fill(seed + 1, 0, n * m).reshape(n, m), 0.0).astype(np.float32)
+    X[np.arange(n), np.arange(n) % m] = np.maximum(X[np.arange(n), np.arange(n) % m], 0.5)  # no empty row
+    X[np.arange(m) % n, np.arange(m)] = np.maximum(X[np.arange(m) % n, np.arange(m)], 0.5)  # no empty column
+    return X, sp.csc_matrix(X)
+
+
+@pytest.mark.parametrize("compute,tol", [("f64", 1e-6), ("f32", 1e-4)])
+@pytest.mark.parametrize("k", [1, 4, 7, 16, 20])
+def test_sparse_gather_path_matches_dense_oracle(NMFk, ctx, oracle, compute, tol, k):
+    """BASELINE configs[3] semantics: the CSC/CSR gather kernels against the DENSE Float64 oracle (zeros -> lambda)."""
+    n, m = 300, 96
+    X, Xs = _sparse_case(oracle, n, m, 0.04, 91)
+    ctx.set_X_sparse(Xs)
+    assert ctx.nnz == int((X > 0).sum()) and ctx.zero_count == int((X == 0).sum())
+    seeds = _seeds(NMFk, 8, [k], 2)
+    res = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=30, compute=NMFk.COMPUTE_F64 if compute == "f64" else 0, **NOSTOP)[k]
+    for r in range(2):
+        W0, H0 = oracle.init_factors(int(seeds[0, r]), n, m, k)
+        ref = oracle.singlerun(X, k, W0, H0, maxiter=30, **NOSTOP)
+        assert res["iters"][r] == 30
+        assert _rel(res["W"][r] @ res["H"][r], ref["W"] @ ref["H"], X) <= tol
+        assert abs(res["objvalue"][r] - ref["objvalue"]) <= max(tol, 1e-6) * ref["objvalue"]
+        assert abs(ctx.frobenius(res["W"][r], res["H"][r]) - res["objvalue"][r]) <= 1e-4 * res["objvalue"][r]
+
+
+def test_sparse_execute_equals_dense_execute(NMFk, oracle):
+    """Whole execute() on a scipy.sparse X: same stop decisions, fit, robustness and kopt as the dense path."""
+    n, m = 120, 40
+    X, Xs = _sparse_case(oracle, n, m, 0.15, 95)
+    kw = dict(load=False, save=False, quiet=True, seed=12, compute="f64", maxiter=300, return_details=True)
+    Wd, Hd, fd, rd, ad, kd, dd = NMFk.execute(X, range(2, 5), 4, **kw)
+    Ws, Hs, fs, rs, as_, ks, ds = NMFk.execute(Xs, range(2, 5), 4, **kw)
+    assert kd == ks
+    for k in range(2, 5):
+        assert list(dd[k]["iters"]) == list(ds[k]["iters"])
+        assert abs(fd[k - 1] - fs[k - 1]) <= 1e-5 * fd[k - 1]
+        assert abs(rd[k - 1] - rs[k - 1]) <= 1e-3
+        np.testing.assert_allclose(Ws[k - 1] @ Hs[k - 1], Wd[k - 1] @ Hd[k - 1], rtol=1e-3, atol=1e-4)
+
+
+def test_sparse_rejects_what_it_cannot_do(NMFk, ctx):
+    import scipy.sparse as sp
+
+    X = sp.csc_matrix(np.array([[1.0, 0.0], [0.0, -2.0]], dtype=np.float32))
+    with pytest.raises(NMFk.NMFkError, match="nonnegative") as e:
+        ctx.set_X_sparse(X)
+    assert e.value.code == 2
+    X = sp.csc_matrix(np.array([[1.0, 0.0], [0.0, np.nan]], dtype=np.float32))
+    with pytest.raises(NMFk.NMFkError, match="dense path") as e:
+        ctx.set_X_sparse(X)
+    assert e.value.code == 6

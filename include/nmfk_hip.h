@@ -162,7 +162,7 @@ int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float *H, double 
  * After a sweep with profiling enabled: names[i] / total_ms[i] / launches[i] / flops[i] for i < *count:
  *   "mu_loop"                     GPU wall time of the whole MU loop (all rank groups run concurrently) and the
  *                                 algorithmic flops of every half-step in it (4*n*m*k per ACTIVE restart)
- *   "h_step<kp>" / "w_step<kp>"   sampled launches (every 8th iteration) of the half-step kernel of one rank,
+ *   "h_step<kp>" / "w_step<kp>"   sampled launches (every 50th iteration) of the half-step kernel of one rank,
  *                                 each timed on its own stream, with the flops of the restarts active in them */
 int nmfk_set_profiling(nmfk_ctx *ctx, int enabled);
 int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *total_ms, int64_t *launches,

@@ -151,7 +151,7 @@ struct Sampler {
     }
     return used++;
   }
-  bool want(int it) const { return on && (it % 8) == 0; }
+  bool want(int it) const { return on && (it % 50) == 0; }  // sparse sampling: the events cost host time too
   size_t begin(hipStream_t s) {
     const size_t e = event();
     if (on) (void)hipEventRecord(ctx->events[e], s);
@@ -909,7 +909,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // Profile (nmfk_get_profile):
   //  "mu_loop"            wall time of the whole MU loop on the GPU (all rank groups, concurrent streams) and the
   //                        algorithmic flops of every half-step executed in it: 4*n*m*k per active unit per half-step
-  //  "h_step<kp>" / "w_step<kp>"  sampled launches (every 8th iteration) of one rank group, timed on their own
+  //  "h_step<kp>" / "w_step<kp>"  sampled launches (every 50th iteration) of one rank group, timed on their own
   //                        stream while the other groups keep running; flops of exactly the units still active
   if (ctx->profiling) {
     float loop_ms = 0.f;

@@ -127,7 +127,7 @@ def _mu_params(kw):
     return args
 
 
-def _sweep(ctx, X, ks, nNMF, kw):
+def _sweep(ctx, X, ks, nNMF, kw, need_all_W=True):
     """All restarts of all ranks in `ks`: dict k -> dict(W (R,n,k), H (R,k,m), objvalue, iters, reason)."""
     from . import parallel
 
@@ -180,7 +180,8 @@ def _sweep(ctx, X, ks, nNMF, kw):
             raise ValueError(f"Length of normalizing vector does not match: {v.size} vs {n}")
         ctx.set_X((np.asarray(X, dtype=np.float32) / v[:, None]).astype(np.float32), mu.get("lambda_", 1e-32))
     ctx.set_weight(weight_array)
-    res = parallel.sharded_sweep(ctx.mu_sweep, ks, nNMF, seeds, wi, hi, params, n, m)
+    res = parallel.sharded_sweep(ctx.mu_sweep, ks, nNMF, seeds, wi, hi, params, n, m,
+                                 need_all_W=need_all_W or normalizevector is not None)
     if normalizevector is not None:  # Mult:119-122: X .*= normalizevector; W .*= normalizevector, then Exec:791-792
         ctx.set_X(X, mu.get("lambda_", 1e-32))
         for k in ks:
@@ -194,7 +195,8 @@ def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1
                       nanaction="zeroed", quiet=True):
     """Everything of execute_run after the restart loop (Exec:545-710)."""
     n, m = X.shape
-    WBig = [np.array(res["W"][i], dtype=np.float32) for i in range(nNMF)]  # Matrix{T} (Exec:529-531)
+    # Matrix{T} (Exec:529-531).  Multi-GPU with best=true: only this rank's restarts and the best one carry a W
+    WBig = [None if res["W"][i] is None else np.array(res["W"][i], dtype=np.float32) for i in range(nNMF)]
     HBig = [np.array(res["H"][i], dtype=np.float32) for i in range(nNMF)]
     objvalue = np.asarray(res["objvalue"], dtype=np.float32)
     idxsort = np.argsort(objvalue, kind="stable")  # Exec:545
@@ -214,15 +216,18 @@ def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1
     if nanaction == "zeroed":  # Exec:567-580
         zerod = 0
         for i in idxsort:
-            isnw, isnh = np.isnan(WBig[i]), np.isnan(HBig[i])
-            WBig[i][isnw] = 0
+            isnh = np.isnan(HBig[i])
             HBig[i][isnh] = 0
+            isnw = np.zeros(1, dtype=bool)
+            if WBig[i] is not None:
+                isnw = np.isnan(WBig[i])
+                WBig[i][isnw] = 0
             zerod += bool(isnw.any() or isnh.any())
         if zerod:
             warnings.warn(f"NMF solutions contain NaN's: {zerod} out of {nNMF} solutions! NaN's have been converted to zeros!")
     elif nanaction == "removed":  # Exec:581-595
         for i in idxsort:
-            if np.isnan(WBig[i]).any() or np.isnan(HBig[i]).any():
+            if (WBig[i] is not None and np.isnan(WBig[i]).any()) or np.isnan(HBig[i]).any():
                 idxnan[i] = False
     idxsol = idxrat & idxcut & idxnan  # Exec:596
     sel = idxsort[idxsol]  # WBig[idxsort][idxsol]
@@ -278,7 +283,8 @@ def execute_run(X, nk, nNMF, device=None, return_details=False, **kw):
     post = {k: kw.pop(k) for k in ("clusterWmatrix", "acceptratio", "acceptfactor", "best", "nanaction") if k in kw}
     for k in ("mixture", "resultdir", "casefilename", "loadall", "saveall", "method", "algorithm"):
         kw.pop(k, None)
-    res, _ = _sweep(ctx, X, [int(nk)], int(nNMF), kw)
+    need_all_W = bool(post.get("clusterWmatrix")) or not post.get("best", True)
+    res, _ = _sweep(ctx, X, [int(nk)], int(nNMF), kw, need_all_W=need_all_W)
     out = _execute_run_post(ctx, X, int(nk), int(nNMF), res[int(nk)], **post)
     return out if return_details else out[:5]
 
@@ -340,7 +346,7 @@ def execute(X, nkrange, nNMF=10, *, cutoff=0.5, clusterWmatrix=False, mixture="n
         ctx = _context(device)
         _upload(ctx, X, kw.get("lambda_", 1e-32))  # raises "All matrix entries must be nonnegative!" (Mult:4-7)
     if todo:
-        res, _ = _sweep(ctx, X, todo, int(nNMF), kw)
+        res, _ = _sweep(ctx, X, todo, int(nNMF), kw, need_all_W=bool(clusterWmatrix) or not post.get("best", True))
         for nk in todo:
             Wa, Ha, phi, sil, a, extra = _execute_run_post(ctx, X, nk, int(nNMF), res[nk], clusterWmatrix, quiet=quiet,
                                                            **post)

@@ -64,28 +64,46 @@ def _all_gather_np(d, a):
     return [o.cpu().numpy() for o in outs]
 
 
-def sharded_sweep(sweep_fn, ks, nruns, seeds, Winit, Hinit, params, n, m):
+def sharded_sweep(sweep_fn, ks, nruns, seeds, Winit, Hinit, params, n, m, need_all_W=True):
     """Runs `sweep_fn` (Context.mu_sweep) on this rank's restarts and returns the results of ALL restarts.
 
-    seeds: (len(ks), nruns).  Result: dict k -> dict(W (nruns,n,k), H (nruns,k,m), objvalue, sse, iters, reason)."""
+    seeds: (len(ks), nruns).  Result: dict k -> dict(W (nruns,n,k), H (nruns,k,m), objvalue, sse, iters, reason).
+    need_all_W=False (the default `best=true`, clusterWmatrix=false path of execute_run, Exec:655-658): only the W of
+    the restart with the lowest objective is exchanged (one broadcast of n x k per rank k from its owner); W of the
+    other restarts is then only present for this rank's own restarts, None elsewhere ("W" becomes a list)."""
     d = _dist()
     if d is None:
         return sweep_fn(ks, nruns, seeds=seeds, Winit=Winit, Hinit=Hinit, params=params)
+    import torch
+
     rank, N = d.get_rank(), d.get_world_size()
     mine = list(range(rank, nruns, N))
     per = (nruns + N - 1) // N  # every rank runs `per` restarts so that all gathers have equal shapes;
     pad = mine + [mine[-1] if mine else 0] * (per - len(mine))  # padding restarts repeat one and are dropped
     sub = lambda dct: None if dct is None else {k: np.asarray(v)[pad] for k, v in dct.items()}
     local = sweep_fn(ks, per, seeds=np.asarray(seeds)[:, pad], Winit=sub(Winit), Hinit=sub(Hinit), params=params)
+    dev = _device(d)
     out = {}
     for k in ks:
         o = {}
-        for key in ("W", "H", "objvalue", "sse", "iters", "reason"):
+        keys = ("W", "H", "objvalue", "sse", "iters", "reason") if need_all_W else ("H", "objvalue", "sse", "iters", "reason")
+        for key in keys:
             parts = _all_gather_np(d, np.ascontiguousarray(local[k][key]))
             full = np.empty((nruns,) + parts[0].shape[1:], dtype=parts[0].dtype)
             for g in range(N):
                 idx = list(range(g, nruns, N))
                 full[idx] = parts[g][:len(idx)]
             o[key] = full
+        if not need_all_W:
+            best = int(np.argsort(o["objvalue"], kind="stable")[0])  # Exec:545-546 (NaN sorts last)
+            owner = best % N
+            wb = np.ascontiguousarray(local[k]["W"][best // N]) if rank == owner else np.empty((n, k), np.float32)
+            t = torch.from_numpy(wb).to(dev)
+            d.broadcast(t, owner)
+            W = [None] * nruns
+            for j, r in enumerate(mine):
+                W[r] = local[k]["W"][j]
+            W[best] = t.cpu().numpy()
+            o["W"] = W
         out[k] = o
     return out

@@ -59,6 +59,16 @@ def _worker(rank, world, port, nruns, q):
         seeds = np.array([[NMFk.run_seed(5, k, r) for r in range(nruns)] for k in ks], dtype=np.uint64)
         params = NMFk.default_params(maxiter=30, maxbaditers=10 ** 9)
         res = NMFk.parallel.sharded_sweep(_oracle_sweep(X), ks, nruns, seeds, None, None, params, n, m)
+        lean = NMFk.parallel.sharded_sweep(_oracle_sweep(X), ks, nruns, seeds, None, None, params, n, m, need_all_W=False)
+        for k in ks:  # best-only exchange: H/objective complete, W of the best restart present on every rank
+            best = int(np.argsort(res[k]["objvalue"], kind="stable")[0])
+            assert np.array_equal(lean[k]["H"], res[k]["H"]) and np.array_equal(lean[k]["objvalue"], res[k]["objvalue"])
+            assert np.array_equal(lean[k]["W"][best], res[k]["W"][best])
+            for r in range(nruns):
+                if r % world == rank:
+                    assert np.array_equal(lean[k]["W"][r], res[k]["W"][r])
+                elif r != best:
+                    assert lean[k]["W"][r] is None
         q.put((rank, X, {k: {kk: np.asarray(v) for kk, v in res[k].items()} for k in ks}))
     finally:
         dist.destroy_process_group()

@@ -578,14 +578,23 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
     {
       const float *pr = stage + (FULL ? pofs : min(c16, d1 - 1 - dch) * 17 + KQ * g);
 #pragma unroll
+#if NMFK_MFMA_EXP == 3
+      for (int sq = 0; sq < KQ; ++sq) bP[sq] = 0.25f + 0.01f * sq + 0.001f * (dch & 255);
+      (void)pr;
+#else
       for (int sq = 0; sq < KQ; ++sq) bP[sq] = (FULLK || KQ * g + sq < k) ? pr[sq] : 0.0f;
+#endif
     }
     float bN[4];
     bool rv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       rv[r] = FULL || (dch + 4 * g + r < d1);
+#if NMFK_MFMA_EXP == 3
+      bN[r] = 0.5f + 0.01f * r + 0.001f * (dch & 255);
+#else
       bN[r] = (rv[r] && (FULLK || c16 < k)) ? stage[nofs + 17 * r] : 0.0f;
+#endif
     }
     f32x4_t p[4];
 #pragma unroll
@@ -621,10 +630,12 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
   auto step = [&](int ci, const f32x4_t (&xc)[4], const f32x4_t &bc, f32x4_t (&xn)[4], f32x4_t &bn)
                   __attribute__((always_inline)) {
     const int dch = d0 + 16 * ci;
+#if NMFK_MFMA_EXP != 3
     if (lane < nload) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) stage[wofs[e]] = bc[e];
     }
+#endif
     if (ci + 1 < nch) load(dch + 16, xn, bn);
     __builtin_amdgcn_wave_barrier();
     if (dch + 16 <= d1 && dch + 16 <= D)

@@ -457,13 +457,17 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   struct Geo {
     int wsplit, S, dchunk, fused, slots;
   };
+  int max_ws = 8;  // the experimental MFMA variant is written for 4-wave workgroups
+  if (const char *e = getenv("NMFK_MFMA_MINK")) max_ws = atoi(e) > 0 ? 4 : 8;
+  if (const char *e = getenv("NMFK_MAX_WSPLIT")) max_ws = atoi(e) >= 8 ? 8 : 4;
   auto geometry = [&](int L, int D) {
     Geo g;
-    auto tiles = [&](int ws, int lb) { const int per = (ws == 4 ? 64 : NMFK_TILE) * lb; return (L + per - 1) / per; };
-    g.wsplit = ((int64_t)tiles(1, NMFK_LB) * nunits >= target) ? 1 : 4;
+    auto tiles = [&](int ws, int lb) { const int per = (ws > 1 ? 64 : NMFK_TILE) * lb; return (L + per - 1) / per; };
+    g.wsplit = 1;
+    if ((int64_t)tiles(1, NMFK_LB) * nunits < target) g.wsplit = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
     const int64_t have = (int64_t)tiles(g.wsplit, NMFK_LB) * nunits;
     int S = (int)((target + have - 1) / have);
-    const int maxS = std::max(1, D / (g.wsplit == 4 ? 256 : 64));
+    const int maxS = std::max(1, D / (64 * g.wsplit));
     g.S = std::max(1, std::min(S, maxS));
     g.dchunk = (D + g.S - 1) / g.S;
     g.fused = g.S == 1;

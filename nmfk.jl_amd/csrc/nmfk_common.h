@@ -49,7 +49,7 @@ struct NmfkStepArgs {
   int64_t ld;
   int32_t L, D;
   int32_t S;        // grid-level splits of the loop dimension (S > 1 => fused = 0, reduce kernel finishes)
-  int32_t wsplit;   // 1: each wave owns 64*LB lane elements; 4: the 4 waves share them and split the loop range
+  int32_t wsplit;   // 1: each wave owns 64*LB lane elements; 4 / 8: that many waves share them and split the loop range
   int32_t fused;    // the step kernel finishes the update itself
   int32_t PW, PH;   // slots of the sum tables of W and H
   int32_t dchunk;   // loop extent per split
@@ -160,6 +160,12 @@ static inline int nmfk_padded_k(int k) {
 #define NMFK_LB4_MAXK 0  // ranks up to this use 4 lane elements per thread
 #endif
 #define NMFK_LB_OF(KP) ((KP) <= NMFK_LB4_MAXK ? 4 : ((KP) <= 16 ? NMFK_LB : 1))
+#ifndef NMFK_LDSB
+#define NMFK_LDSB 0      // 1: loop-factor rows through LDS for kp >= NMFK_LDSB_MINK (no missing data)
+#endif
+#ifndef NMFK_LDSB_MINK
+#define NMFK_LDSB_MINK 9
+#endif
 #ifndef NMFK_MFMA_EXP
 #define NMFK_MFMA_EXP 0
 #endif

@@ -15,6 +15,7 @@
 #include "nmfk_common.h"
 #include "../../include/nmfk_hip.h"
 #include "nmfk_rng.h"
+#include <algorithm>
 #include <type_traits>
 
 #define NMFK_CAT2(a, b) a##b
@@ -195,11 +196,11 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   g.it = it;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ws = g.wsplit;
-  const int lpw = (ws == 4) ? 64 : NMFK_TILE;
+  const int lpw = (ws > 1) ? 64 : NMFK_TILE;
   const int tile = blockIdx.x / g.S;
   const int s = blockIdx.x - tile * g.S;
   if (tile * lpw * LB >= g.L) return;  // the grid is sized for the smallest LB of the launch
-  const int lbase = tile * lpw * LB + ((ws == 4) ? lane : tid);
+  const int lbase = tile * lpw * LB + ((ws > 1) ? lane : tid);
 
   const T *__restrict__ Hcur = NMFK_PTR(const T, g, NMFK_HOFF(*rdp, g.it));
   const T *__restrict__ Hnew = NMFK_PTR(const T, g, NMFK_HOFF(*rdp, g.it + 1));
@@ -238,8 +239,8 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   }
   int d0 = s * g.dchunk;
   int d1 = min(g.D, d0 + g.dchunk);
-  if (ws == 4) {  // quarter of the range per wave
-    const int q = (d1 - d0 + 3) >> 2;
+  if (ws > 1) {  // the ws waves of the workgroup share the lane elements and split the loop range
+    const int q = (d1 - d0 + ws - 1) / ws;
     d0 = min(d0 + wave * q, d1);
     d1 = min(d0 + q, d1);
   }
@@ -316,8 +317,70 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
     for (int uu = 0; uu < U; ++uu) row(d + uu, bufv[uu], bufx[uu]);
   };
 
-  const int nfull = (d1 - d0) / U;
   int d = d0;
+#if NMFK_LDSB
+  // Variant: loop-factor rows staged through LDS.  Scalar loads can only be waited for with lgkmcnt(0), which caps
+  // their run-ahead at one loop step; here a wave copies 16 rows at a time into its own LDS buffer one whole chunk
+  // (16 loop steps) ahead with ordinary vector loads, reads each row back as a broadcast, and keeps X loads three
+  // rows ahead (vmcnt is counted, in order).
+  if (!NANS && KP >= NMFK_LDSB_MINK) {
+    constexpr int CH = 16, CHF = CH * KP, NPL = (CHF + 63) / 64;
+    T *stg = (T *)(lds + 9 * NMFK_MAX_K) + wave * 2 * CHF;
+    const int64_t bend = (int64_t)g.D * KP - 1;
+    T sreg[NPL];
+    auto gload = [&](int dch) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) {
+        const int64_t o = (int64_t)dch * KP + lane + 64 * q;
+        sreg[q] = B[o < bend ? o : bend];
+      }
+    };
+    auto swrite = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+        if (lane + 64 * q < CHF) stg[buf * CHF + lane + 64 * q] = sreg[q];
+    };
+    float xq[4][LB];
+    auto xload = [&](int rr, float (&xs)[LB]) __attribute__((always_inline)) {
+      const float *__restrict__ xr = g.X + (int64_t)min(rr, d1 - 1) * ld;
+#pragma unroll
+      for (int e = 0; e < LB; ++e) xs[e] = xr[lofs[e]];
+    };
+    if (d1 > d0) {
+      gload(d0);
+      xload(d0, xq[0]);
+      xload(d0 + 1, xq[1]);
+      xload(d0 + 2, xq[2]);
+    }
+    int cur = 0;
+    for (int dch = d0; dch < d1; dch += CH) {
+      swrite(cur);
+      if (dch + CH < d1) gload(dch + CH);
+      __builtin_amdgcn_wave_barrier();
+      const T *cb = stg + cur * CHF;
+      const int rend = min(CH, d1 - dch);
+#pragma unroll 1
+      for (int r0 = 0; r0 < rend; r0 += 4) {
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) {
+          const int r = r0 + uu;
+          xload(dch + r + 3, xq[(uu + 3) & 3]);
+          if (r < rend) {
+            T bv[KP];
+#pragma unroll
+            for (int c = 0; c < KP; ++c) bv[c] = cb[r * KP + c];
+            row(dch + r, bv, xq[uu]);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      cur ^= 1;
+    }
+    d = d1;
+    if (ws > 1) __syncthreads();  // the cross-wave scratch below overlays the staging buffers
+  }
+#endif
+  const int nfull = (d1 - d) / U;
   if (nfull > 0) {
     T v0[U][KP], v1[U][KP];  // the two register buffers: loop-factor rows (SGPRs) ...
     float x0[U][LB], x1[U][LB];  // ... and X entries (VGPRs)
@@ -368,8 +431,8 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   }
 
   // wsplit = 4: numerators of waves 1..3 are added to wave 0's in wave order (deterministic)
-  T *ldsT = (T *)(lds + 5 * NMFK_MAX_K);  // cross-wave scratch behind den[64] and red[4*64]
-  if (ws == 4) {
+  T *ldsT = (T *)(lds + 9 * NMFK_MAX_K);  // cross-wave scratch behind den[64] and red[8*64]
+  if (ws > 1) {
     if (wave > 0) {
 #pragma unroll
       for (int e = 0; e < LB; ++e)
@@ -379,7 +442,7 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
     __syncthreads();
     if (wave == 0) {
 #pragma unroll 1
-      for (int w = 0; w < 3; ++w) {  // not unrolled: one wave's worth of temporaries at a time
+      for (int w = 0; w < ws - 1; ++w) {  // not unrolled: one wave's worth of temporaries at a time
 #pragma unroll
         for (int e = 0; e < LB; ++e)
 #pragma unroll
@@ -423,7 +486,7 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   const int k = rdp->k;
   // per-workgroup partial sums of A_new -> slot `tile` of the sum table of this factor
   double *sumA = NMFK_PTR(double, g, g.which == 0 ? rdp->osumH : rdp->osumW) + (int64_t)tile * KP;
-  double *red = den + NMFK_MAX_K;  // [4][KP]
+  double *red = den + NMFK_MAX_K;  // [8][KP]
 #pragma unroll
   for (int c = 0; c < KP; ++c) {
     T vs = (T)0;
@@ -441,7 +504,7 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   }
   __syncthreads();
   if (tid < KP) {
-    const double t = (ws == 4) ? red[tid] : ((red[tid] + red[KP + tid]) + (red[2 * KP + tid] + red[3 * KP + tid]));
+    const double t = (ws > 1) ? red[tid] : ((red[tid] + red[KP + tid]) + (red[2 * KP + tid] + red[3 * KP + tid]));
     sumA[tid] = t;
   }
 }
@@ -449,18 +512,19 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
 // One kernel per rank width KP: the register allocation (hence occupancy) of a kernel is the maximum over
 // everything it can dispatch to, and a switch over ranks inside one kernel inflates it well beyond the widest
 // case.  Units of equal rank are contiguous (sorted by k), so a launch covers the unit range [u0, u0 + gridDim.y).
-// LDS: den[64], red[4*64], then the cross-wave scratch of 3*LB*KP*64 elements of T.
+// LDS (dynamic, sized by the launcher): den[64], red[8*64], then the cross-wave scratch of (ws-1)*LB*KP*64 elements
+// of T (wsplit > 1 only).
 // min waves per SIMD requested from the register allocator (2nd __launch_bounds__ argument = waves per EU)
 #ifndef NMFK_MINWAVES
 #define NMFK_MINWAVES(KP) ((KP) <= 16 ? 4 : 1)
 #endif
 template <bool NANS, int KP>
-__global__ __launch_bounds__(NMFK_TILE, NMFK_MINWAVES(KP)) void step_kernel(char *arena, const float *__restrict__ X,
+__global__ __launch_bounds__(2 * NMFK_TILE, NMFK_MINWAVES(KP)) void step_kernel(char *arena, const float *__restrict__ X,
                                                          const NmfkRun *__restrict__ runs,
                                                          const NmfkState *__restrict__ state,
                                                          const NmfkStepArgs *__restrict__ gp, int it, int u0) {
   constexpr int LB = NMFK_LB_OF(KP);
-  __shared__ double lds[5 * NMFK_MAX_K + 3 * KP * LB * (sizeof(T) == 8 ? 64 : 32)];
+  extern __shared__ double lds[];
   const int u = u0 + blockIdx.y;
   if (!gp->force && !state[u].active) return;
   step_body<KP, LB, NANS>(arena, X, gp, runs + u, it, lds);
@@ -1194,13 +1258,19 @@ void NMFK_NAME(nmfk_launch_init)(const NmfkInitArgs &a, hipStream_t s) {
 template <int KP>
 static void launch_step_kp(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int u0, int cnt, hipStream_t s) {
   constexpr int LB = NMFK_LB_OF(KP);
-  const int lpw = a.wsplit == 4 ? 64 : NMFK_TILE;
+  const int ws = a.wsplit;
+  const int lpw = ws > 1 ? 64 : NMFK_TILE;
   const int ntile = (a.L + lpw * LB - 1) / (lpw * LB);
-  const dim3 grid(ntile * a.S, cnt), blk(NMFK_TILE);
+  const dim3 grid(ntile * a.S, cnt), blk(ws > 1 ? 64 * ws : NMFK_TILE);
+  size_t scratch = ws > 1 ? (size_t)(ws - 1) * LB * KP * 64 * sizeof(T) : 0;
+#if NMFK_LDSB
+  scratch = std::max(scratch, (size_t)(ws > 1 ? ws : 4) * 2 * 16 * KP * sizeof(T));
+#endif
+  const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + scratch;
   if (a.has_nan)
-    hipLaunchKernelGGL((step_kernel<true, KP>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
+    hipLaunchKernelGGL((step_kernel<true, KP>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
   else
-    hipLaunchKernelGGL((step_kernel<false, KP>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
+    hipLaunchKernelGGL((step_kernel<false, KP>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
 }
 
 #define NMFK_LAUNCH_CASE(KP) launch_step_kp<KP>(a, dargs, u0, cnt, s)

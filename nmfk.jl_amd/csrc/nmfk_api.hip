@@ -457,21 +457,46 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   struct Geo {
     int wsplit, S, dchunk, fused, slots;
   };
+  // ranks above 16 use the all-MFMA half-step (fp32 compute, no missing data, dense X); NMFK_MFMA_WIDE=0 disables
+  int wide_on = 1;
+  if (const char *e = getenv("NMFK_MFMA_WIDE")) wide_on = atoi(e);
+  const bool wide_ok_nowide = !f64 && !ctx->sparse && ctx->nan_count == 0 && n >= 16 && m >= 16;
+  const bool wide_ok = wide_on && wide_ok_nowide;
+  bool any_wide = false;
+  for (int q = 0; q < nk; ++q) any_wide = any_wide || (wide_ok && ks[q] > 16);
+  // ranks in [mfma_mink, 16] can use an MFMA variant of the half-step too: experimental, off by default (see
+  // no gain over the packed-VALU kernel at k <= 16); enable with NMFK_MFMA_MINK=<k>
+  int mfma_mink = 0;
+  if (const char *e = getenv("NMFK_MFMA_MINK")) mfma_mink = atoi(e);
+  auto use_wide_k = [&](int k) { return wide_ok && k > 16; };
+  auto use_mfma_k = [&](int k) { return wide_ok_nowide && k <= 16 && mfma_mink > 0 && k >= mfma_mink; };
+  // lane elements per workgroup (= per sum-table slot) of the half-step kernel a rank runs
+  auto lane_tile = [&](int k, int ws) {
+    if (ctx->sparse) return NMFK_TILE;
+    if (use_wide_k(k)) return nmfk_mfma_wide_lane_tile(ws);
+    if (use_mfma_k(k)) return ws == 4 ? 64 : NMFK_TILE;
+    return (ws > 1 ? 64 : NMFK_TILE) * NMFK_LB_OF(nmfk_padded_k(k));
+  };
   int max_ws = 8;  // the experimental MFMA variant is written for 4-wave workgroups
   if (const char *e = getenv("NMFK_MFMA_MINK")) max_ws = atoi(e) > 0 ? 4 : 8;
   if (const char *e = getenv("NMFK_MAX_WSPLIT")) max_ws = atoi(e) >= 8 ? 8 : 4;
   auto geometry = [&](int L, int D) {
     Geo g;
-    auto tiles = [&](int ws, int lb) { const int per = (ws > 1 ? 64 : NMFK_TILE) * lb; return (L + per - 1) / per; };
+    auto wgs = [&](int ws) {  // workgroups of one half-step over all units
+      int64_t t = 0;
+      for (int q = 0; q < nk; ++q) t += (int64_t)((L + lane_tile(ks[q], ws) - 1) / lane_tile(ks[q], ws)) * nruns;
+      return t;
+    };
     g.wsplit = 1;
-    if ((int64_t)tiles(1, NMFK_LB) * nunits < target) g.wsplit = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
-    const int64_t have = (int64_t)tiles(g.wsplit, NMFK_LB) * nunits;
+    if (wgs(1) < target) g.wsplit = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
+    const int64_t have = wgs(g.wsplit);
     int S = (int)((target + have - 1) / have);
     const int maxS = std::max(1, D / (64 * g.wsplit));
     g.S = std::max(1, std::min(S, maxS));
     g.dchunk = (D + g.S - 1) / g.S;
     g.fused = g.S == 1;
-    g.slots = tiles(g.wsplit, 1);  // units with kp > 16 use one lane element per thread => the most tiles
+    g.slots = 1;  // slots of the sum tables = the most lane tiles any rank's kernel uses
+    for (int q = 0; q < nk; ++q) g.slots = std::max(g.slots, (L + lane_tile(ks[q], g.wsplit) - 1) / lane_tile(ks[q], g.wsplit));
     return g;
   };
   Geo gh = geometry(m, n), gw = geometry(n, m);
@@ -518,6 +543,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         rd.ossepart = (int64_t)B.take(sizeof(double) * (tiles_n + 1));  // sparse objective: slot 0 = <W'W, HH'>
         rd.ocanon = (int64_t)B.take(sizeof(int32_t) * (size_t)m);
         rd.seed = seeds ? seeds[(size_t)q * nruns + r] : 0;
+        // slots the unit's kernels write: the fused half-step one per lane tile, the grid-parallel helpers any count
+        rd.nsH = gh.fused ? (m + lane_tile(k, gh.wsplit) - 1) / lane_tile(k, gh.wsplit) : PH;
+        rd.nsW = gw.fused ? (n + lane_tile(k, gw.wsplit) - 1) / lane_tile(k, gw.wsplit) : PW;
       }
     }
   }
@@ -686,11 +714,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // W half-step -> (every 10th iteration) objective + check block is the stream order; different ranks never
   // exchange data before the clustering step, so no cross-stream synchronisation is needed inside the loop.
   const int ngroups = (int)groups.size();
-  // ranks in [mfma_mink, 16] use the MFMA variant of the half-step (fp32 compute, no missing data): it keeps the
-  // matrix pipe busy while the packed-VALU kernels of the smaller ranks run on the vector pipe of the same CUs
-  int mfma_mink = 0;  // experimental, off by default: enable with NMFK_MFMA_MINK=<k>
-  if (const char *e = getenv("NMFK_MFMA_MINK")) mfma_mink = atoi(e);
-  auto use_mfma = [&](const Group &G) { return !f64 && !ctx->sparse && ctx->nan_count == 0 && n >= 16 && m >= 16 && G.k <= 16 && mfma_mink > 0 && G.k >= mfma_mink; };
+  auto use_wide = [&](const Group &G) { return use_wide_k(G.k); };
+  auto use_mfma = [&](const Group &G) { return use_mfma_k(G.k); };
   int max_streams = 8;
   if (const char *e = getenv("NMFK_STREAMS")) max_streams = std::max(1, std::min(64, atoi(e)));
   const int NS = std::min(ngroups, max_streams);
@@ -741,6 +766,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_sp_step_f32(&sph, G.kp, G.begin, G.count, gs);
         else if (f64)
           nmfk_launch_step_f64(hs, d_hs, G.kp, G.begin, G.count, gs);
+        else if (use_wide(G))
+          nmfk_launch_step_mfma_wide_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         else if (use_mfma(G))
           nmfk_launch_step_mfma_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         else
@@ -762,6 +789,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_sp_step_f32(&spw, G.kp, G.begin, G.count, gs);
         else if (f64)
           nmfk_launch_step_f64(ws, d_ws, G.kp, G.begin, G.count, gs);
+        else if (use_wide(G))
+          nmfk_launch_step_mfma_wide_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         else if (use_mfma(G))
           nmfk_launch_step_mfma_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         else
@@ -1073,6 +1102,7 @@ NMFK_EXPORT int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float
     memset(&rd, 0, sizeof(rd));
     rd.k = k;
     rd.kp = kp;
+    rd.nsW = rd.nsH = 1;
     rd.oWt = (int64_t)B.take(sizeof(float) * (size_t)n * kp);
     rd.oH0 = rd.oH1 = (int64_t)B.take(sizeof(float) * (size_t)m * kp);
     rd.osumW = (int64_t)B.take(sizeof(double) * kp);

@@ -23,6 +23,7 @@ struct NmfkRun {
   int64_t ossepart;  // double[ntile_n] per-workgroup partial objective
   int64_t ocanon;    // int32[m] canonical co-clustering partition of the previous check (Mult:101-116)
   uint64_t seed;
+  int32_t nsW, nsH;  // slots of the sum tables this unit's kernels write (<= PW, PH); the others stay zero
 };
 
 // Stop-rule state machine of NMFmultiplicative (Mult:57-63), one per unit, device resident.
@@ -160,6 +161,9 @@ static inline int nmfk_padded_k(int k) {
 #define NMFK_LB4_MAXK 0  // ranks up to this use 4 lane elements per thread
 #endif
 #define NMFK_LB_OF(KP) ((KP) <= NMFK_LB4_MAXK ? 4 : ((KP) <= 16 ? NMFK_LB : 1))
+#ifndef NMFK_WIDE_NT
+#define NMFK_WIDE_NT 2   // 16-wide lane tiles per wave of the all-MFMA kernel for k > 16
+#endif
 #ifndef NMFK_LDSB
 #define NMFK_LDSB 0      // 1: loop-factor rows through LDS for kp >= NMFK_LDSB_MINK (no missing data)
 #endif
@@ -194,6 +198,9 @@ static inline int nmfk_padded_k(int k) {
                                 int u0, int cnt, hipStream_t s);                                                  \
   void nmfk_launch_finish_##SUF(const NmfkFinishArgs &a, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f32)
+void nmfk_launch_step_mfma_wide_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt,
+                                    hipStream_t s);
+int nmfk_mfma_wide_lane_tile(int wsplit);
 void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f64)
 

@@ -49,26 +49,47 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
   return sh[4];
 }
 
-// sum table of a factor: P slots of kp doubles; consumers add the slots in order.  This writes the complete
-// sums  out[c] = sum_l F[c + l*kp]  (colsum(W) / rowsum(H) in the signal-major layout) to slot 0 and zeroes
-// the other slots.
-__device__ __forceinline__ void block_signal_sums(const T *F, int kp, int k, int len, double *out, int P, double *sh) {
-  for (int c = 0; c < k; ++c) {
-    double s = 0;
-    for (int l = threadIdx.x; l < len; l += NMFK_TILE) s += (double)F[c + (int64_t)l * kp];
-    s = block_sum(s, sh);
-    if (threadIdx.x == 0) out[c] = s;
+// sum table of a factor: P slots of kp doubles; consumers add the slots in order.  The half-step kernels write one
+// slot per lane tile; the grid-parallel helper kernels (init, clamp, reduce) split the lane range into P equal
+// chunks, workgroup b owning chunk b and slot b.  Any partition works as long as every slot is written or zero:
+// a unit uses the first NmfkRun::nsW / nsH slots (what its fused half-step kernel writes), the rest stay zero.
+__device__ __forceinline__ void slot_range(int len, int P, int b, int &l0, int &l1) {
+  const int ch = (len + P - 1) / P;
+  l0 = min(len, b * ch);
+  l1 = min(len, l0 + ch);
+}
+
+__device__ __forceinline__ void zero_slot(double *slot, int kp) {
+  if ((int)threadIdx.x < kp) slot[threadIdx.x] = 0.0;
+}
+
+// out[c] = sum_{l in [l0,l1)} F[c + l*kp]  (c < k; zero for the padding signals), fixed order.  Thread (c, r) adds
+// the elements l = l0 + r, l0 + r + rows, ... so that consecutive threads read consecutive addresses.
+// sh: NMFK_TILE doubles.  out may be LDS or global memory.
+__device__ __forceinline__ void range_signal_sums(const T *F, int kp, int k, int l0, int l1, double *out, double *sh) {
+  const int rows = NMFK_TILE / kp;
+  const int tid = threadIdx.x, c = tid % kp, r = tid / kp;
+  double s = 0;
+  if (r < rows)
+    for (int l = l0 + r; l < l1; l += rows) s += (double)F[c + (int64_t)l * kp];
+  __syncthreads();
+  if (r < rows) sh[tid] = s;
+  __syncthreads();
+  if (tid < kp) {
+    double t = 0;
+    for (int q = 0; q < rows; ++q) t += sh[q * kp + tid];
+    out[tid] = tid < k ? t : 0.0;
   }
-  for (int c = k + threadIdx.x; c < P * kp; c += NMFK_TILE) out[c] = 0.0;
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------------
 // init: W = rand(n,k) then H = rand(k,m) (Mult:38,48) or the caller's Winit/Hinit (Mult:40-41,50-51);
 // state of Mult:57-63; colsum(W), rowsum(H).
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NMFK_TILE) void init_kernel(NmfkInitArgs g) {
-  __shared__ double sh[8];
-  const int u = blockIdx.x;
+__global__ __launch_bounds__(NMFK_TILE) void init_kernel(NmfkInitArgs g) {  // grid (max(PW, PH), units)
+  __shared__ double sh[NMFK_TILE];
+  const int u = blockIdx.y, b = blockIdx.x;
   const NmfkRun rd = g.runs[u];
   const int k = rd.k, kp = rd.kp, n = g.n, m = g.m;
   T *Wt = NMFK_PTR(T, g, rd.oWt);
@@ -77,28 +98,39 @@ __global__ __launch_bounds__(NMFK_TILE) void init_kernel(NmfkInitArgs g) {
   const float *Hi = g.Hinit ? g.Hinit[rd.kidx] : nullptr;
   const uint64_t key = nmfk_splitmix64(rd.seed);
   int bad = 0;
-  for (int64_t e = threadIdx.x; e < (int64_t)n * kp; e += NMFK_TILE) {
-    const int c = (int)(e % kp);
-    const int64_t i = e / kp;
-    float v = 0.f;
-    if (c < k) v = Wi ? Wi[(int64_t)rd.ridx * n * k + i + (int64_t)c * n] : nmfk_uniform_keyed(key, (uint64_t)(i + (int64_t)c * n));
-    bad |= (v != v);
-    Wt[e] = (T)v;
+  if (b >= rd.nsW && b < g.PW) zero_slot(NMFK_PTR(double, g, rd.osumW) + (int64_t)b * kp, kp);
+  if (b >= rd.nsH && b < g.PH) zero_slot(NMFK_PTR(double, g, rd.osumH) + (int64_t)b * kp, kp);
+  if (b < rd.nsW) {
+    int l0, l1;
+    slot_range(n, rd.nsW, b, l0, l1);
+    for (int64_t e = (int64_t)l0 * kp + threadIdx.x; e < (int64_t)l1 * kp; e += NMFK_TILE) {
+      const int c = (int)(e % kp);
+      const int64_t i = e / kp;
+      float v = 0.f;
+      if (c < k) v = Wi ? Wi[(int64_t)rd.ridx * n * k + i + (int64_t)c * n] : nmfk_uniform_keyed(key, (uint64_t)(i + (int64_t)c * n));
+      bad |= (v != v);
+      Wt[e] = (T)v;
+    }
+    __syncthreads();
+    range_signal_sums(Wt, kp, k, l0, l1, NMFK_PTR(double, g, rd.osumW) + (int64_t)b * kp, sh);
   }
-  for (int64_t e = threadIdx.x; e < (int64_t)m * kp; e += NMFK_TILE) {
-    const int c = (int)(e % kp);
-    const int64_t j = e / kp;
-    float v = 0.f;
-    if (c < k)
-      v = Hi ? Hi[(int64_t)rd.ridx * m * k + c + j * k] : nmfk_uniform_keyed(key, (uint64_t)((int64_t)n * k + c + j * k));
-    bad |= (v != v);
-    H[e] = (T)v;
+  if (b < rd.nsH) {
+    int l0, l1;
+    slot_range(m, rd.nsH, b, l0, l1);
+    for (int64_t e = (int64_t)l0 * kp + threadIdx.x; e < (int64_t)l1 * kp; e += NMFK_TILE) {
+      const int c = (int)(e % kp);
+      const int64_t j = e / kp;
+      float v = 0.f;
+      if (c < k)
+        v = Hi ? Hi[(int64_t)rd.ridx * m * k + c + j * k] : nmfk_uniform_keyed(key, (uint64_t)((int64_t)n * k + c + j * k));
+      bad |= (v != v);
+      H[e] = (T)v;
+    }
+    __syncthreads();
+    range_signal_sums(H, kp, k, l0, l1, NMFK_PTR(double, g, rd.osumH) + (int64_t)b * kp, sh);
   }
   if (bad) atomicOr(g.nan_flag, 1);
-  __syncthreads();
-  block_signal_sums(Wt, kp, k, n, NMFK_PTR(double, g, rd.osumW), g.PW, sh);
-  block_signal_sums(H, kp, k, m, NMFK_PTR(double, g, rd.osumH), g.PH, sh);
-  if (threadIdx.x == 0) {
+  if (b == 0 && threadIdx.x == 0) {
     NmfkState s;
     s.best = __builtin_inf();
     s.last_obj = __builtin_nan("");
@@ -802,6 +834,250 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const
 
 #endif
 
+#ifdef NMFK_IS_F32
+// ------------------------------------------------------------------------------------------------------
+// All-MFMA half-step for wide ranks (16 < k <= 64; kp is a multiple of 4, padding rows of the factors are zero).
+// The VALU kernel needs 4k VGPRs per thread for a and acc, which leaves 1-3 waves/SIMD at k >= 32; here the
+// numerators live in MFMA accumulator tiles: a wave owns NT tiles of 16 lane elements and NB = ceil(kp/16) blocks
+// of 16 signals, i.e. NT*NB accumulators of 4 VGPRs.  Per 16 loop steps and tile: KQ = kp/4 MFMAs for
+// P = B'A (16 x 16), 16 reciprocals on the VALU, 4*NB MFMAs for N += B Q.
+// ------------------------------------------------------------------------------------------------------
+template <int KQ, int NB, int NT>
+__global__ __launch_bounds__(2 * NMFK_TILE) void mfma_wide_kernel(char *arena, const float *__restrict__ X,
+                                                                 const NmfkRun *__restrict__ runs,
+                                                                 const NmfkState *__restrict__ state,
+                                                                 const NmfkStepArgs *__restrict__ gp, int it, int u0) {
+  extern __shared__ double lds[];  // den[64], red[8*64], then max(staging, cross-wave scratch)
+  constexpr int KP = 4 * KQ, RS = KP + 4;  // staged row stride (floats): 16-byte aligned, off the 32-bank period
+  const int u = u0 + blockIdx.y;
+  if (!gp->force && !state[u].active) return;
+  const NmfkRun *__restrict__ rdp = runs + u;
+  const int k = rdp->k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int which = gp->which, ws = gp->wsplit, S = gp->S, L = gp->L, D = gp->D;
+  const int nwaves = blockDim.x >> 6;
+  const int lpw = 16 * NT * (ws > 1 ? 1 : nwaves);
+  const int tile = blockIdx.x / S, s = blockIdx.x - tile * S;
+  const int l0 = tile * lpw + (ws > 1 ? 0 : wave * 16 * NT);
+
+  const float *__restrict__ Hcur = (const float *)(arena + NMFK_HOFF(*rdp, it));
+  const float *__restrict__ Hnew = (const float *)(arena + NMFK_HOFF(*rdp, it + 1));
+  const float *__restrict__ Wt = (const float *)(arena + rdp->oWt);
+  const float *__restrict__ A = which == 0 ? Hcur : Wt;  // lane factor
+  const float *__restrict__ B = which == 0 ? Wt : Hnew;  // loop factor
+
+  int d0 = s * gp->dchunk;
+  int d1 = min(D, d0 + gp->dchunk);
+  if (ws > 1) {
+    const int q = (((d1 - d0 + ws - 1) / ws) + 15) & ~15;  // equal shares of the range per wave, in whole chunks
+    d0 = min(d0 + wave * q, d1);
+    d1 = min(d0 + q, d1);
+  }
+  d0 = __builtin_amdgcn_readfirstlane(d0);
+  d1 = __builtin_amdgcn_readfirstlane(d1);
+
+  // first product: contraction index (MFMA step sq, k-lane g) <-> signal c = KQ*g + sq
+  float afrag[NT][KQ];
+  int lt[NT];
+  bool lv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int l = l0 + 16 * t + c16;
+    lv[t] = l < L;
+    lt[t] = lv[t] ? l : 0;
+#pragma unroll
+    for (int sq = 0; sq < KQ; ++sq) afrag[t][sq] = lv[t] ? A[KQ * g + sq + (int64_t)lt[t] * KP] : 0.0f;
+  }
+  f32x4_t acc[NT][NB];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[t][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const float *__restrict__ Xa = gp->Xalt;  // element (l, d) at d + l*D
+  float *scratch = (float *)(lds + 9 * NMFK_MAX_K);
+  float *stage = scratch + wave * (16 * RS);
+  const int nch = (d1 - d0 + 15) >> 4;
+  const float *xbase[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) xbase[t] = Xa + (int64_t)lt[t] * D + 4 * g;
+  // this lane's pieces (16 bytes each) of a 16 x KP chunk: piece pi = lane + 64q, row (4 pi)/KP, column (4 pi)%KP
+  int wofs[NB];
+  bool wv[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int pi = lane + 64 * q;
+    wv[q] = pi < 4 * KP;
+    wofs[q] = ((4 * pi) / KP) * RS + (4 * pi) % KP;
+  }
+  const int pofs = c16 * RS + KQ * g;
+  const int nofs = 4 * g * RS + c16;
+
+  auto load = [&](int dch, f32x4_t (&xv)[NT], f32x4_t (&bv)[NB]) __attribute__((always_inline)) {
+    const int dx = (dch + 16 <= D) ? dch : (min(dch + 4 * g, D - 4) - 4 * g);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xv[t] = *(const f32x4_u *)(xbase[t] + dx);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      bv[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (wv[q]) bv[q] = *(const f32x4_u *)(B + (int64_t)dch * KP + 4 * (lane + 64 * q));
+    }
+  };
+  auto chunk = [&](int dch, const f32x4_t (&xcur)[NT], auto full_tag) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    float bP[KQ];
+    {
+      const float *pr = stage + (FULL ? pofs : min(c16, d1 - 1 - dch) * RS + KQ * g);
+#pragma unroll
+      for (int sq = 0; sq < KQ; ++sq) bP[sq] = pr[sq];
+    }
+    bool rv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rv[r] = FULL || (dch + 4 * g + r < d1);
+    f32x4_t p[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sq = 0; sq < KQ; ++sq)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bP[sq], afrag[t][sq], p[t], 0, 0, 0);
+    f32x4_t q[NT];
+    if (FULL) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[t][r] = div_t(xcur[t][r], p[t][r]);
+    } else {
+      const int shift = (dch + 4 * g) - min(dch + 4 * g, D - 4);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = r + shift;
+          const float xx = rr <= 0 ? xcur[t][0] : rr == 1 ? xcur[t][1] : rr == 2 ? xcur[t][2] : xcur[t][3];
+          q[t][r] = rv[r] ? div_t(xx, p[t][r]) : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float bN = (rv[r] && 16 * nb + c16 < KP) ? stage[nofs + RS * r + 16 * nb] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bN, q[t][r], acc[t][nb], 0, 0, 0);
+      }
+  };
+  auto step = [&](int ci, const f32x4_t (&xc)[NT], const f32x4_t (&bc)[NB], f32x4_t (&xn)[NT], f32x4_t (&bn)[NB])
+                  __attribute__((always_inline)) {
+    const int dch = d0 + 16 * ci;
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      if (wv[q]) *(f32x4_t *)(stage + wofs[q]) = bc[q];
+    if (ci + 1 < nch) load(dch + 16, xn, bn);
+    __builtin_amdgcn_wave_barrier();
+    if (dch + 16 <= d1 && dch + 16 <= D)
+      chunk(dch, xc, std::true_type());
+    else
+      chunk(dch, xc, std::false_type());
+    __builtin_amdgcn_wave_barrier();
+  };
+  {
+    f32x4_t x0[NT], x1[NT], b0[NB], b1[NB];
+    if (nch > 0) load(d0, x0, b0);
+    for (int ci = 0; ci < nch; ci += 2) {
+      step(ci, x0, b0, x1, b1);
+      if (ci + 1 < nch) step(ci + 1, x1, b1, x0, b0);
+    }
+  }
+  // acc[t][nb][r] = numerator of signal c = 16nb + 4g + r at lane element l0 + 16t + c16
+
+  if (ws > 1) {  // add the waves' numerators in wave order (the scratch overlays the staging buffers)
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) scratch[((((wave - 1) * NT + t) * NB + nb) * 4 + r) * 64 + lane] = acc[t][nb][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll 1
+      for (int w = 0; w < ws - 1; ++w)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][nb][r] += scratch[(((w * NT + t) * NB + nb) * 4 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  const bool owner = (ws == 1) || (wave == 0);
+
+  if (!gp->fused) {
+    if (owner) {
+      float *__restrict__ part = (float *)(arena + rdp->opart);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (lv[t]) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int c = 16 * nb + 4 * g + r;
+              if (c < KP) part[((int64_t)s * L + lt[t]) * KP + c] = acc[t][nb][r];
+            }
+        }
+    }
+    return;
+  }
+
+  const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
+  const int PB = which == 0 ? gp->PW : gp->PH;
+  double *den = lds;
+  if (tid < KP) {
+    double sd = 0;
+    for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * KP + tid];
+    den[tid] = sd;
+  }
+  __syncthreads();
+  float *__restrict__ Anew = which == 0 ? (float *)(arena + NMFK_HOFF(*rdp, it + 1)) : (float *)(arena + rdp->oWt);
+  double *sumA = (double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)) + (int64_t)tile * KP;
+  double *red = den + NMFK_MAX_K;  // [8][KP]
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * nb + 4 * g + r;
+      float vs = 0.f;
+      if (owner && c < KP) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (lv[t]) {
+            float v = 0.f;
+            if (c < k) v = A[c + (int64_t)lt[t] * KP] * acc[t][nb][r] / (float)den[c];  // Mult:67 / Mult:70 order
+            Anew[c + (int64_t)lt[t] * KP] = v;
+            vs += v;
+          }
+      }
+      double v = (double)vs;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (c16 == 0 && c < KP) red[wave * KP + c] = v;
+    }
+  __syncthreads();
+  if (tid < KP) {
+    double t = red[tid];
+    if (ws == 1)
+      for (int w = 1; w < nwaves; ++w) t += red[w * KP + tid];
+    sumA[tid] = (tid < k) ? t : 0.0;
+  }
+}
+
+#endif
+
 // ------------------------------------------------------------------------------------------------------
 // Sparse X (BASELINE configs[3]: zeros stay zeros).  In the reference a zero becomes lambda = 1e-32 (Mult:17-18), so
 // its ratio X/(W*H) is ~1e-32 and only the stored non-zeros contribute to the numerators: the gather form below is
@@ -968,12 +1244,12 @@ __global__ __launch_bounds__(NMFK_TILE) void sp_gram_kernel(NmfkSparseArgs g, in
 }
 
 // ------------------------------------------------------------------------------------------------------
-// half-step finish: A_new = A .* (sum of partial numerators) ./ sumB ;  sumA_new   (one workgroup per unit)
+// half-step finish: A_new = A .* (sum of partial numerators) ./ sumB ;  sumA_new.  Grid (slots of A's table, units).
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NMFK_TILE) void reduce_kernel(NmfkStepArgs g, int u0) {
-  __shared__ double sh[8];
+  __shared__ double sh[NMFK_TILE];
   __shared__ double den[NMFK_MAX_K];
-  const int u = u0 + blockIdx.x;
+  const int u = u0 + blockIdx.y, b = blockIdx.x;
   if (!g.force && !g.state[u].active) return;
   const NmfkRun rd = g.runs[u];
   const T *Aold;
@@ -987,25 +1263,31 @@ __global__ __launch_bounds__(NMFK_TILE) void reduce_kernel(NmfkStepArgs g, int u
     sumB = NMFK_PTR(const double, g, rd.osumW);
     sumA = NMFK_PTR(double, g, rd.osumH);
     PB = g.PW;
-    PA = g.PH;
+    PA = rd.nsH;
   } else {
     Aold = NMFK_PTR(const T, g, rd.oWt);
     Anew = NMFK_PTR(T, g, rd.oWt);
     sumB = NMFK_PTR(const double, g, rd.osumH);
     sumA = NMFK_PTR(double, g, rd.osumW);
     PB = g.PH;
-    PA = g.PW;
+    PA = rd.nsW;
   }
   const int k = rd.k, kp = rd.kp;
+  if (b >= PA) {
+    zero_slot(sumA + (int64_t)b * kp, kp);
+    return;
+  }
   if (threadIdx.x < kp) {
     double sd = 0;
     for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * kp + threadIdx.x];
     den[threadIdx.x] = sd;
   }
   __syncthreads();
+  int l0, l1;
+  slot_range(g.L, PA, b, l0, l1);
   const T *part = NMFK_PTR(const T, g, rd.opart);
   const int64_t LK = (int64_t)g.L * kp;
-  for (int64_t e = threadIdx.x; e < LK; e += NMFK_TILE) {
+  for (int64_t e = (int64_t)l0 * kp + threadIdx.x; e < (int64_t)l1 * kp; e += NMFK_TILE) {
     const int c = (int)(e % kp);
     T num = (T)0;
     for (int s = 0; s < g.S; ++s) num += part[(int64_t)s * LK + e];
@@ -1014,7 +1296,7 @@ __global__ __launch_bounds__(NMFK_TILE) void reduce_kernel(NmfkStepArgs g, int u
     Anew[e] = v;
   }
   __syncthreads();
-  block_signal_sums(Anew, kp, k, g.L, sumA, PA, sh);
+  range_signal_sums(Anew, kp, k, l0, l1, sumA + (int64_t)b * kp, sh);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1074,70 +1356,86 @@ __global__ void sum_parts_kernel(char *arena, const NmfkRun *runs, int nunits, i
 }
 
 // ------------------------------------------------------------------------------------------------------
-// check block, every 10th iteration (Mult:73-117): objective -> tol test -> bad-iteration bookkeeping ->
-// clamp at eps(Float64) -> co-clustering consistency -> loop guard (Mult:64).  One workgroup per unit.
+// check block, every 10th iteration (Mult:73-117), three launches in stream order:
+//   check_a  objective -> tol test -> bad-iteration bookkeeping           (one thread per unit)
+//   clamp    H = max.(H, eps()), W = max.(W, eps()) and the sum tables    (grid (slots, units))
+//   check_b  co-clustering consistency -> loop guard (Mult:64)            (one workgroup per unit)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NMFK_TILE) void check_kernel(NmfkCheckArgs g, int u0) {
-  __shared__ double sh[8];
-  __shared__ int sh_action, sh_diff;
+__global__ void check_a_kernel(NmfkCheckArgs g, int u0, int cnt) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= cnt) return;
+  const int u = u0 + q;
+  NmfkState *st = g.state + u;
+  if (!st->active) return;
+  const NmfkRun rd = g.runs[u];
+  double obj = 0;
+  for (int t = 0; t < g.ntile_n; ++t) obj += NMFK_PTR(const double, g, rd.ossepart)[t];
+  st->last_obj = obj;
+  if (obj < g.tol) {  // Mult:75-78: leaves the loop before the clamp
+    st->active = 0;
+    st->reason = NMFK_STOP_TOL;
+    st->iters = g.it + 1;
+  } else {  // Mult:79-98
+    double best = st->best;
+    int bad = st->baditers, re = st->reattempts;
+    if (obj < best) {
+      if ((best - obj) < g.tolOF)
+        bad += 1;
+      else
+        bad = 0;
+      best = obj;
+    } else {
+      bad += 1;
+    }
+    if (bad >= g.maxbaditers) {
+      re += 1;
+      bad = 0;
+    }
+    st->best = best;
+    st->baditers = bad;
+    st->reattempts = re;
+  }
+}
+
+// Mult:99-100; eps() is Float64 eps whatever T is; NaN stays NaN
+__global__ __launch_bounds__(NMFK_TILE) void clamp_kernel(NmfkCheckArgs g, int u0) {
+  __shared__ double sh[NMFK_TILE];
+  const int u = u0 + blockIdx.y, b = blockIdx.x;
+  if (!g.state[u].active) return;
+  const NmfkRun rd = g.runs[u];
+  const int tid = threadIdx.x, k = rd.k, kp = rd.kp;
+  const T eps = (T)2.220446049250313e-16;
+  for (int f = 0; f < 2; ++f) {
+    const int P = f == 0 ? rd.nsW : rd.nsH, PT = f == 0 ? g.PW : g.PH, len = f == 0 ? g.n : g.m;
+    T *F = f == 0 ? NMFK_PTR(T, g, rd.oWt) : NMFK_PTR(T, g, NMFK_HOFF(rd, g.it + 1));
+    double *tab = NMFK_PTR(double, g, f == 0 ? rd.osumW : rd.osumH);
+    if (b >= P) {
+      if (b < PT) zero_slot(tab + (int64_t)b * kp, kp);
+      continue;
+    }
+    int l0, l1;
+    slot_range(len, P, b, l0, l1);
+    for (int64_t e = (int64_t)l0 * kp + tid; e < (int64_t)l1 * kp; e += NMFK_TILE) {
+      const T v = F[e];
+      if ((int)(e % kp) < k && v < eps) F[e] = eps;
+    }
+    __syncthreads();
+    range_signal_sums(F, kp, k, l0, l1, tab + (int64_t)b * kp, sh);
+  }
+}
+
+__global__ __launch_bounds__(NMFK_TILE) void check_b_kernel(NmfkCheckArgs g, int u0) {
+  __shared__ int sh_diff;
   __shared__ int sh_first[NMFK_MAX_K];
   const int u = u0 + blockIdx.x;
   NmfkState *st = g.state + u;
   if (!st->active) return;
   const NmfkRun rd = g.runs[u];
-  const int tid = threadIdx.x, k = rd.k, kp = rd.kp, n = g.n, m = g.m;
-  if (tid == 0) {
-    double obj = 0;
-    for (int t = 0; t < g.ntile_n; ++t) obj += NMFK_PTR(const double, g, rd.ossepart)[t];
-    st->last_obj = obj;
-    int action = 1;
-    if (obj < g.tol) {  // Mult:75-78
-      st->active = 0;
-      st->reason = NMFK_STOP_TOL;
-      st->iters = g.it + 1;
-      action = 0;
-    } else {  // Mult:79-98
-      double best = st->best;
-      int bad = st->baditers, re = st->reattempts;
-      if (obj < best) {
-        if ((best - obj) < g.tolOF)
-          bad += 1;
-        else
-          bad = 0;
-        best = obj;
-      } else {
-        bad += 1;
-      }
-      if (bad >= g.maxbaditers) {
-        re += 1;
-        bad = 0;
-      }
-      st->best = best;
-      st->baditers = bad;
-      st->reattempts = re;
-    }
-    sh_action = action;
-    sh_diff = 0;
-  }
+  const int tid = threadIdx.x, k = rd.k, kp = rd.kp, m = g.m;
+  if (tid == 0) sh_diff = 0;
   if (tid < NMFK_MAX_K) sh_first[tid] = 0x7fffffff;
   __syncthreads();
-  if (!sh_action) return;
-
-  // H = max.(H, eps()); W = max.(W, eps())  (Mult:99-100; eps() is Float64 eps whatever T is; NaN stays NaN)
-  T *Wt = NMFK_PTR(T, g, rd.oWt);
-  T *H = NMFK_PTR(T, g, NMFK_HOFF(rd, g.it + 1));
-  const T eps = (T)2.220446049250313e-16;
-  for (int64_t e = tid; e < (int64_t)n * kp; e += NMFK_TILE) {
-    const T v = Wt[e];
-    if ((int)(e % kp) < k && v < eps) Wt[e] = eps;
-  }
-  for (int64_t e = tid; e < (int64_t)m * kp; e += NMFK_TILE) {
-    const T v = H[e];
-    if ((int)(e % kp) < k && v < eps) H[e] = eps;
-  }
-  __syncthreads();
-  block_signal_sums(Wt, kp, k, n, NMFK_PTR(double, g, rd.osumW), g.PW, sh);
-  block_signal_sums(H, kp, k, m, NMFK_PTR(double, g, rd.osumH), g.PH, sh);
+  const T *H = NMFK_PTR(const T, g, NMFK_HOFF(rd, g.it + 1));
 
   // index[q] = argmin(H[:,q]) (first minimum; a NaN wins, as in Julia); cons[i,j] = index[i]==index[j];
   // consdiff == 0  <=>  the partition of the columns is unchanged.  Canonical form of a partition: every
@@ -1192,12 +1490,12 @@ __global__ __launch_bounds__(NMFK_TILE) void check_kernel(NmfkCheckArgs g, int u
 
 // ------------------------------------------------------------------------------------------------------
 // finish (Exec:790-805): objvalue = normnan(X - W*H); total = sum(H;dims=2); W .*= total'; H ./= total;
-// results stored as T = Float32 (Exec:529-531).  One workgroup per unit.
+// results stored as T = Float32 (Exec:529-531).  Grid (slices of the rows of W / columns of H, units).
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NMFK_TILE) void finish_kernel(NmfkFinishArgs g) {
-  __shared__ double sh[8];
+  __shared__ double sh[NMFK_TILE];
   __shared__ double rs[NMFK_MAX_K];
-  const int u = blockIdx.x;
+  const int u = blockIdx.y, b = blockIdx.x, NB = gridDim.x;
   NmfkState *st = g.state + u;
   const NmfkRun rd = g.runs[u];
   const int tid = threadIdx.x, k = rd.k, kp = rd.kp, n = g.n, m = g.m;
@@ -1206,40 +1504,46 @@ __global__ __launch_bounds__(NMFK_TILE) void finish_kernel(NmfkFinishArgs g) {
     iters = g.total_iters;
     reason = NMFK_STOP_MAXITER;
   }
-  __syncthreads();
   const T *Wt = NMFK_PTR(const T, g, rd.oWt);
   const T *H = NMFK_PTR(const T, g, NMFK_HOFF(rd, iters));
-  for (int c = 0; c < k; ++c) {
-    double s = 0;
-    for (int j = tid; j < m; j += NMFK_TILE) s += (double)H[c + (int64_t)j * kp];
-    s = block_sum(s, sh);
-    if (tid == 0) rs[c] = s;
-  }
-  __syncthreads();
+  range_signal_sums(H, kp, k, 0, m, rs, sh);
   float *Wo = g.Wout[rd.kidx] + (int64_t)rd.ridx * n * k;
   float *Ho = g.Hout[rd.kidx] + (int64_t)rd.ridx * m * k;
-  for (int64_t e = tid; e < (int64_t)n * k; e += NMFK_TILE) {
-    const int c = (int)(e / n);
-    const int64_t i = e - (int64_t)c * n;
+  int i0, i1, j0, j1;
+  slot_range(n, NB, b, i0, i1);
+  slot_range(m, NB, b, j0, j1);
+  const int ni = i1 - i0;
+  for (int64_t e = tid; e < (int64_t)ni * k; e += NMFK_TILE) {
+    const int c = (int)(e / ni);
+    const int64_t i = i0 + (e - (int64_t)c * ni);
     T v = Wt[c + i * kp];
     if (g.normalize) v = v * (T)rs[c];
-    Wo[e] = (float)v;
+    Wo[i + (int64_t)c * n] = (float)v;
   }
-  for (int64_t e = tid; e < (int64_t)m * k; e += NMFK_TILE) {
+  for (int64_t e = (int64_t)j0 * k + tid; e < (int64_t)j1 * k; e += NMFK_TILE) {
     const int c = (int)(e % k);
     const int64_t j = e / k;
     T v = H[c + j * kp];
     if (g.normalize) v = v / (T)rs[c];
     Ho[e] = (float)v;
   }
-  if (tid == 0) {
+  if (b == 0 && tid == 0) {
     double obj = 0;
     for (int t = 0; t < g.ntile_n; ++t) obj += NMFK_PTR(const double, g, rd.ossepart)[t];
     g.frob[rd.kidx][rd.ridx] = (float)sqrt(obj > 0 ? obj : 0.0);  // (the sparse form can round to a tiny negative)
     g.iters[rd.kidx][rd.ridx] = iters;
     g.reason[rd.kidx][rd.ridx] = reason;
-    st->iters = iters;
-    st->reason = reason;
+  }
+}
+
+// after finish: the units' final state (separate launch: finish workgroups of one unit read it concurrently)
+__global__ void finish_state_kernel(NmfkFinishArgs g) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= g.nunits) return;
+  NmfkState *st = g.state + u;
+  if (st->active) {
+    st->iters = g.total_iters;
+    st->reason = NMFK_STOP_MAXITER;
     st->active = 0;
   }
 }
@@ -1250,7 +1554,7 @@ __global__ __launch_bounds__(NMFK_TILE) void finish_kernel(NmfkFinishArgs g) {
 // launchers
 // ------------------------------------------------------------------------------------------------------
 void NMFK_NAME(nmfk_launch_init)(const NmfkInitArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(init_kernel, dim3(a.nunits), dim3(NMFK_TILE), 0, s, a);
+  hipLaunchKernelGGL(init_kernel, dim3(std::max(a.PW, a.PH), a.nunits), dim3(NMFK_TILE), 0, s, a);
 }
 
 // `dargs`: device copy of `a` (constant over the sweep except `it`, which is passed by value).
@@ -1298,6 +1602,38 @@ void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs,
 }
 #endif
 
+#ifdef NMFK_IS_F32
+// all-MFMA half-step for 16 < kp <= 64 (fp32, no missing data, D >= 16)
+template <int KQ, int NB, int NT>
+static void launch_mfma_wide(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int u0, int cnt, hipStream_t s) {
+  const int ws = a.wsplit, nwaves = ws > 1 ? ws : 4;
+  const int lpw = 16 * NT * (ws > 1 ? 1 : nwaves);
+  const int ntile = (a.L + lpw - 1) / lpw;
+  const dim3 grid(ntile * a.S, cnt), blk(64 * nwaves);
+  const size_t stage = (size_t)nwaves * 16 * (4 * KQ + 4) * sizeof(float);
+  const size_t cross = ws > 1 ? (size_t)(ws - 1) * NT * NB * 4 * 64 * sizeof(float) : 0;
+  const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + std::max(stage, cross);
+  hipLaunchKernelGGL((mfma_wide_kernel<KQ, NB, NT>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
+}
+
+int nmfk_mfma_wide_lane_tile(int wsplit) { return 16 * NMFK_WIDE_NT * (wsplit > 1 ? 1 : 4); }
+
+void nmfk_launch_step_mfma_wide_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt,
+                                    hipStream_t s) {
+  switch (kp) {
+    case 20: launch_mfma_wide<5, 2, NMFK_WIDE_NT>(a, dargs, u0, cnt, s); break;
+    case 24: launch_mfma_wide<6, 2, NMFK_WIDE_NT>(a, dargs, u0, cnt, s); break;
+    case 28: launch_mfma_wide<7, 2, NMFK_WIDE_NT>(a, dargs, u0, cnt, s); break;
+    case 32: launch_mfma_wide<8, 2, NMFK_WIDE_NT>(a, dargs, u0, cnt, s); break;
+    case 40: launch_mfma_wide<10, 3, NMFK_WIDE_NT>(a, dargs, u0, cnt, s); break;
+    case 48: launch_mfma_wide<12, 3, NMFK_WIDE_NT>(a, dargs, u0, cnt, s); break;
+    case 56: launch_mfma_wide<14, 4, NMFK_WIDE_NT>(a, dargs, u0, cnt, s); break;
+    case 64: launch_mfma_wide<16, 4, NMFK_WIDE_NT>(a, dargs, u0, cnt, s); break;
+    default: break;
+  }
+}
+#endif
+
 void NMFK_NAME(nmfk_launch_sp_step)(const void *argsv, int kp, int u0, int cnt, hipStream_t s) {
   const NmfkSparseArgs &a = *(const NmfkSparseArgs *)argsv;
   const dim3 grid((a.L + NMFK_TILE - 1) / NMFK_TILE, cnt), blk(NMFK_TILE);
@@ -1315,7 +1651,7 @@ void NMFK_NAME(nmfk_launch_sp_obj)(const void *argsv, int n, int m, int hsel, in
 }
 
 void NMFK_NAME(nmfk_launch_reduce)(const NmfkStepArgs &a, int u0, int cnt, hipStream_t s) {
-  hipLaunchKernelGGL(reduce_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, u0);
+  hipLaunchKernelGGL(reduce_kernel, dim3(a.which == 0 ? a.PH : a.PW, cnt), dim3(NMFK_TILE), 0, s, a, u0);
 }
 
 void NMFK_NAME(nmfk_launch_sse)(const NmfkSseArgs &a, int u0, int cnt, hipStream_t s) {
@@ -1328,9 +1664,14 @@ void NMFK_NAME(nmfk_launch_sum_parts)(char *arena, const NmfkRun *runs, int nuni
 }
 
 void NMFK_NAME(nmfk_launch_check)(const NmfkCheckArgs &a, int u0, int cnt, hipStream_t s) {
-  hipLaunchKernelGGL(check_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, u0);
+  hipLaunchKernelGGL(check_a_kernel, dim3((cnt + 63) / 64), dim3(64), 0, s, a, u0, cnt);
+  hipLaunchKernelGGL(clamp_kernel, dim3(std::max(a.PW, a.PH), cnt), dim3(NMFK_TILE), 0, s, a, u0);
+  hipLaunchKernelGGL(check_b_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, u0);
 }
 
 void NMFK_NAME(nmfk_launch_finish)(const NmfkFinishArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(finish_kernel, dim3(a.nunits), dim3(NMFK_TILE), 0, s, a);
+  const int64_t work = (int64_t)std::max(a.n, a.m) * 16;
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, work / 65536));
+  hipLaunchKernelGGL(finish_kernel, dim3(nb, a.nunits), dim3(NMFK_TILE), 0, s, a);
+  hipLaunchKernelGGL(finish_state_kernel, dim3((a.nunits + 63) / 64), dim3(64), 0, s, a);
 }

@@ -88,6 +88,42 @@ def test_padded_ranks(NMFk, ctx, oracle, k):
         assert _rel(res["W"][r] @ res["H"][r], ref["W"] @ ref["H"], X) <= 3e-7
 
 
+@pytest.mark.parametrize("k", [17, 20, 24, 28, 33, 40, 48, 56, 64])
+@pytest.mark.parametrize("shape", [(130, 70), (96, 2100)])
+def test_wide_ranks_fp32_mfma_path(NMFk, ctx, oracle, k, shape):
+    """fp32 compute at k > 16 runs the all-MFMA half-step (mfma_wide_kernel): fixed budget against the oracle, ragged
+    sizes (loop ranges that are not multiples of 16, lane tiles that are not full)."""
+    n, m = shape
+    X = (0.05 + oracle.uniform_fill(12, 0, n * m)).reshape(n, m).astype(np.float32)
+    ctx.set_X(X)
+    seeds = _seeds(NMFk, 6, [k], 2)
+    res = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=20, **NOSTOP)[k]
+    for r in range(2):
+        W0, H0 = oracle.init_factors(int(seeds[0, r]), n, m, k)
+        ref = oracle.singlerun(X, k, W0, H0, maxiter=20, **NOSTOP)
+        assert _rel(res["W"][r] @ res["H"][r], ref["W"] @ ref["H"], X) <= 1e-4
+        assert abs(res["objvalue"][r] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
+        np.testing.assert_allclose(res["H"][r].sum(axis=1), 1.0, atol=1e-4)
+
+
+def test_wide_rank_mfma_matches_valu_kernel_large(NMFk, ctx):
+    """The two fp32 half-step kernels for k > 16 (MFMA, default; VALU with NMFK_MFMA_WIDE=0) agree at a size where
+    the lane dimension alone fills the chip (no wave split) and with a grid-level split (few lane tiles)."""
+    for (n, m, k, R) in [(16384, 1024, 24, 4), (16384, 1024, 64, 2), (1000, 4096, 40, 1)]:
+        X = (0.05 + ctx.fill_uniform(7, 0, n * m)).reshape(m, n).T.astype(np.float32)
+        ctx.set_X(X)
+        seeds = _seeds(NMFk, 8, [k], R)
+        a = ctx.mu_sweep([k], R, seeds=seeds, maxiter=10, **NOSTOP)[k]
+        os.environ["NMFK_MFMA_WIDE"] = "0"
+        try:
+            b = ctx.mu_sweep([k], R, seeds=seeds, maxiter=10, **NOSTOP)[k]
+        finally:
+            del os.environ["NMFK_MFMA_WIDE"]
+        for r in range(R):
+            assert _rel(a["W"][r] @ a["H"][r], b["W"][r] @ b["H"][r], X) <= 2e-5
+        np.testing.assert_allclose(a["objvalue"], b["objvalue"], rtol=1e-4)
+
+
 def test_stop_rule_fp64_identical_iterations(NMFk, ctx, oracle, bss_X):
     """Default stop rule (Mult:64-98) in fp64 compute mode: same iteration counts and stop reasons as the oracle."""
     X = bss_X.astype(np.float32)

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/nmfk_hip.h"
@@ -453,7 +454,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // chip, else the four waves of a workgroup share 64*LB lane elements and split the loop range; grid-level
   // splits S > 1 (finished by the reduce kernel) only when there are too few units to fill the chip otherwise.
   const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-  const int target = 2 * cus;
+  int target = 2 * cus;
+  if (const char *e = getenv("NMFK_TARGET_WGS")) target = std::max(1, atoi(e));
   struct Geo {
     int wsplit, S, dchunk, fused, slots;
   };
@@ -520,14 +522,37 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   struct Group {
     int k, kp, begin, count;
   };
-  std::vector<Group> groups;  // contiguous unit range per rank (units are sorted by k descending)
-  {
-    int u = 0;
+  // Launch groups = contiguous unit ranges.  Default: one group per rank (units sorted by k descending), each with its
+  // own kernel instantiation and stream.  With few restarts per rank the per-rank launches are tiny and the loop is
+  // launch-bound: then the ranks <= 16 are merged into `merge` super-groups (restart r of every rank goes to
+  // super-group r mod merge; kp = 0 marks a mixed-rank group, served by step_kernel_multi).
+  int merge = -1;
+  if (const char *e = getenv("NMFK_MERGE")) merge = atoi(e);
+  if (merge < 0) merge = nruns <= NMFK_MERGE_MAX_RUNS ? std::min(nruns, NMFK_MERGE_GROUPS) : 0;
+  if (ctx->sparse || mfma_mink > 0) merge = 0;
+  merge = std::min(merge, nruns);
+  std::vector<Group> groups;
+  std::vector<std::pair<int, int>> ulist;  // (index into ks, restart) in unit order
+  ulist.reserve(nunits);
+  for (int oi = 0; oi < nk; ++oi) {
+    const int q = order[oi], k = ks[q];
+    if (merge > 0 && k <= 16) continue;
+    groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns});
+    for (int r = 0; r < nruns; ++r) ulist.push_back({q, r});
+  }
+  for (int g = 0; g < merge; ++g) {
+    Group G{0, 0, (int)ulist.size(), 0};
     for (int oi = 0; oi < nk; ++oi) {
-      const int q = order[oi], k = ks[q], kp = nmfk_padded_k(k);
-      if (groups.empty() || groups.back().k != k) groups.push_back({k, kp, u, 0});
-      groups.back().count += nruns;
-      for (int r = 0; r < nruns; ++r, ++u) {
+      const int q = order[oi];
+      if (ks[q] > 16) continue;
+      for (int r = g; r < nruns; r += merge, ++G.count) ulist.push_back({q, r});
+    }
+    if (G.count > 0) groups.push_back(G);
+  }
+  {
+    for (int u = 0; u < nunits; ++u) {
+      const int q = ulist[u].first, r = ulist[u].second, k = ks[q], kp = nmfk_padded_k(k);
+      {
         NmfkRun &rd = runs[u];
         rd.k = k;
         rd.kp = kp;
@@ -748,6 +773,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   int nchecks = 0;
   bool all_done = !guard0;
   const int maxiter = guard0 ? (int)P.maxiter : 0;
+  double host_wait_s = 0;  // time the host spent waiting for the GPU inside the loop (NMFK_HOST_TIMING=1 prints it)
+  const auto loop_w0 = std::chrono::steady_clock::now();
   for (int it = 0; it < maxiter && !all_done; ++it) {
     const bool check = (it + 1) % 10 == 0;  // Mult:73
     const bool timed = prof.want(it);
@@ -764,6 +791,10 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_sp_step_f64(&sph, G.kp, G.begin, G.count, gs);
         else if (sparse)
           nmfk_launch_sp_step_f32(&sph, G.kp, G.begin, G.count, gs);
+        else if (G.kp == 0 && f64)
+          nmfk_launch_step_multi_f64(hs, d_hs, G.begin, G.count, gs);
+        else if (G.kp == 0)
+          nmfk_launch_step_multi_f32(hs, d_hs, G.begin, G.count, gs);
         else if (f64)
           nmfk_launch_step_f64(hs, d_hs, G.kp, G.begin, G.count, gs);
         else if (use_wide(G))
@@ -787,6 +818,10 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_sp_step_f64(&spw, G.kp, G.begin, G.count, gs);
         else if (sparse)
           nmfk_launch_sp_step_f32(&spw, G.kp, G.begin, G.count, gs);
+        else if (G.kp == 0 && f64)
+          nmfk_launch_step_multi_f64(ws, d_ws, G.begin, G.count, gs);
+        else if (G.kp == 0)
+          nmfk_launch_step_multi_f32(ws, d_ws, G.begin, G.count, gs);
         else if (f64)
           nmfk_launch_step_f64(ws, d_ws, G.kp, G.begin, G.count, gs);
         else if (use_wide(G))
@@ -825,7 +860,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if (check) {
       const int slot = nchecks & 1;
       if (nchecks > 0) {  // inspect the PREVIOUS check while this one is still queued
+        const auto w0 = std::chrono::steady_clock::now();
         HIPCHECK(hipEventSynchronize(snap_ev[slot ^ 1]));
+        host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
         bool any = false;
         for (int u = 0; u < nunits; ++u) any = any || snap[slot ^ 1][u].active;
         if (!any) all_done = true;
@@ -839,6 +876,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       nchecks++;
     }
   }
+  if (getenv("NMFK_HOST_TIMING"))
+    fprintf(stderr, "[nmfk] loop: %d iterations, %d groups, host %.3f s of which waiting for the GPU %.3f s\n", total_iters,
+            ngroups, std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_w0).count(), host_wait_s);
   HIPCHECK(hipGetLastError());
   // join: the main stream continues after every group stream (and the poll stream) has drained
   for (int j = 0; j < NS; ++j) {
@@ -960,15 +1000,15 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, ctx->events[sm.e0], ctx->events[sm.e1]) != hipSuccess) continue;
       const Group &G = groups[sm.group];
-      int active = 0;
+      double active_k = 0;  // sum of the ranks of the units still iterating
       for (int u = G.begin; u < G.begin + G.count; ++u)
-        active += sm.it < h_iters[runs[u].kidx][runs[u].ridx] ? 1 : 0;
+        active_k += sm.it < h_iters[runs[u].kidx][runs[u].ridx] ? runs[u].k : 0;
       char name[64];
       snprintf(name, sizeof(name), "%s<%d>", sm.kind == PK_HSTEP ? "h_step" : "w_step", G.kp);
       auto &E = ctx->prof[name];
       E.ms += ms;
       E.launches += 1;
-      E.flops += 4.0 * n * (double)m * G.k * active;  // W*H + the product with the ratio
+      E.flops += 4.0 * n * (double)m * active_k;  // W*H + the product with the ratio
     }
   }
   return NMFK_OK;

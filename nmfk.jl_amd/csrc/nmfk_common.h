@@ -161,6 +161,12 @@ static inline int nmfk_padded_k(int k) {
 #define NMFK_LB4_MAXK 0  // ranks up to this use 4 lane elements per thread
 #endif
 #define NMFK_LB_OF(KP) ((KP) <= NMFK_LB4_MAXK ? 4 : ((KP) <= 16 ? NMFK_LB : 1))
+#ifndef NMFK_MERGE_MAX_RUNS
+#define NMFK_MERGE_MAX_RUNS 4  // restarts per rank at or below which the ranks <= 16 share launches (see nmfk_mu_sweep)
+#endif
+#ifndef NMFK_MERGE_GROUPS
+#define NMFK_MERGE_GROUPS 2    // number of mixed-rank launch groups then
+#endif
 #ifndef NMFK_WIDE_NT
 #define NMFK_WIDE_NT 2   // 16-wide lane tiles per wave of the all-MFMA kernel for k > 16
 #endif
@@ -188,6 +194,7 @@ static inline int nmfk_padded_k(int k) {
   void nmfk_launch_init_##SUF(const NmfkInitArgs &a, hipStream_t s);                                              \
   void nmfk_launch_step_##SUF(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt,          \
                               hipStream_t s);                                                                     \
+  void nmfk_launch_step_multi_##SUF(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int u0, int cnt, hipStream_t s); \
   void nmfk_launch_reduce_##SUF(const NmfkStepArgs &a, int u0, int cnt, hipStream_t s);                           \
   void nmfk_launch_sse_##SUF(const NmfkSseArgs &a, int u0, int cnt, hipStream_t s);                               \
   void nmfk_launch_check_##SUF(const NmfkCheckArgs &a, int u0, int cnt, hipStream_t s);                           \

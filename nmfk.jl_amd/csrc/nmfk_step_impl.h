@@ -562,6 +562,30 @@ __global__ __launch_bounds__(2 * NMFK_TILE, NMFK_MINWAVES(KP)) void step_kernel(
   step_body<KP, LB, NANS>(arena, X, gp, runs + u, it, lds);
 }
 
+// One launch for units of DIFFERENT ranks (all <= 16, so that they share the lane tile 64/256 * NMFK_LB): used when a
+// sweep has so few restarts per rank that per-rank launches leave the loop launch-bound (strong scaling over many
+// GPUs).  The register allocation is that of the widest case, which is irrelevant when the chip is not full anyway.
+#define NMFK_MULTI_CASE(KP) step_body<KP, NMFK_LB_OF(16), NANS>(arena, X, gp, runs + u, it, lds)
+template <bool NANS>
+__global__ __launch_bounds__(2 * NMFK_TILE, 2) void step_kernel_multi(char *arena, const float *__restrict__ X,
+                                                                      const NmfkRun *__restrict__ runs,
+                                                                      const NmfkState *__restrict__ state,
+                                                                      const NmfkStepArgs *__restrict__ gp, int it, int u0) {
+  static_assert(NMFK_LB_OF(1) == NMFK_LB_OF(16), "mixed-rank launches need one lane tile for all ranks <= 16");
+  extern __shared__ double lds[];
+  const int u = u0 + blockIdx.y;
+  if (!gp->force && !state[u].active) return;
+  switch (runs[u].kp) {
+    case 1: NMFK_MULTI_CASE(1); break;   case 2: NMFK_MULTI_CASE(2); break;   case 3: NMFK_MULTI_CASE(3); break;
+    case 4: NMFK_MULTI_CASE(4); break;   case 5: NMFK_MULTI_CASE(5); break;   case 6: NMFK_MULTI_CASE(6); break;
+    case 7: NMFK_MULTI_CASE(7); break;   case 8: NMFK_MULTI_CASE(8); break;   case 9: NMFK_MULTI_CASE(9); break;
+    case 10: NMFK_MULTI_CASE(10); break; case 11: NMFK_MULTI_CASE(11); break; case 12: NMFK_MULTI_CASE(12); break;
+    case 13: NMFK_MULTI_CASE(13); break; case 14: NMFK_MULTI_CASE(14); break; case 15: NMFK_MULTI_CASE(15); break;
+    case 16: NMFK_MULTI_CASE(16); break;
+    default: break;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // MFMA variant of the half-step (fp32, no missing data, k <= 16), v_mfma_f32_16x16x4_f32.
 //
@@ -1581,6 +1605,23 @@ static void launch_step_kp(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int
 void NMFK_NAME(nmfk_launch_step)(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt,
                                  hipStream_t s) {
   NMFK_DISPATCH_KP(kp, NMFK_LAUNCH_CASE)
+}
+
+void NMFK_NAME(nmfk_launch_step_multi)(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int u0, int cnt, hipStream_t s) {
+  constexpr int LB = NMFK_LB_OF(16);
+  const int ws = a.wsplit;
+  const int lpw = ws > 1 ? 64 : NMFK_TILE;
+  const int ntile = (a.L + lpw * LB - 1) / (lpw * LB);
+  const dim3 grid(ntile * a.S, cnt), blk(ws > 1 ? 64 * ws : NMFK_TILE);
+  size_t scratch = ws > 1 ? (size_t)(ws - 1) * LB * 16 * 64 * sizeof(T) : 0;
+#if NMFK_LDSB
+  scratch = std::max(scratch, (size_t)(ws > 1 ? ws : 4) * 2 * 16 * 16 * sizeof(T));
+#endif
+  const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + scratch;
+  if (a.has_nan)
+    hipLaunchKernelGGL((step_kernel_multi<true>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
+  else
+    hipLaunchKernelGGL((step_kernel_multi<false>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
 }
 
 #ifdef NMFK_IS_F32

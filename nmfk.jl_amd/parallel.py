@@ -2,10 +2,10 @@
 torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
 The reference's only parallelism is `Distributed.pmap` over the restarts of ONE k (src/NMFkExecute.jl:511-526),
-shipping X to a worker with every task.  Here rank g owns restarts {g, g+N, ...} of EVERY k (cost per unit is
-proportional to k x iterations, so sharding by restart balances the ranks where sharding by k would not), X is
-broadcast once, nothing is exchanged inside the MU loop, and the per-k results (H stack, objective, and W) are
-all-gathered once at the end so that every rank can run the clustering step."""
+shipping X to a worker with every task.  Here the (k, restart) units of the WHOLE sweep are sharded (`plan_shards`: rank g owns restarts {g, g+N, ...} of
+every k), X is broadcast once, nothing is exchanged inside the MU loop, and the results (H stack, objective,
+iterations, and W or only the best W per k) are exchanged in ONE padded all-gather each at the end, so that every
+rank can run the clustering step."""
 import numpy as np
 
 
@@ -64,46 +64,107 @@ def _all_gather_np(d, a):
     return [o.cpu().numpy() for o in outs]
 
 
+def plan_shards(ks, nruns, world):
+    """Deterministic assignment of the (k, restart) units to ranks (identical on every rank): rank g owns the restarts
+    {g, g + world, ...} of EVERY k.  The cost of a unit grows with k and with its iteration count, which is only
+    known afterwards, so giving every rank the same mix of ranks balances the load where dealing out whole ranks
+    does not (measured on MI355X at 8 ranks: cost-balanced blocks of 16 restarts of ~4 ranks per GPU and 4 restarts
+    of all 15 ranks per GPU take the same time, see scripts/rank_sim.py).
+    Returns (c, chunks): every rank runs c = ceil(nruns / world) restarts of every k (short lists are padded by
+    repeating the last restart; the padding runs are dropped); chunks = [(kidx, restarts, owner)]."""
+    c = -(-nruns // world)
+    chunks = []
+    for q in range(len(ks)):
+        for g in range(world):
+            rs = list(range(g, nruns, world))
+            if rs:
+                chunks.append((q, rs, g))
+    return c, chunks
+
+
+def _exchange(d, payload, sizes):
+    """All-gather of one byte string per rank (lengths `sizes`, known everywhere) -> list of uint8 arrays."""
+    import torch
+
+    dev = _device(d)
+    cap = max(max(sizes), 1)
+    buf = np.zeros(cap, dtype=np.uint8)
+    buf[:payload.size] = payload
+    t = torch.from_numpy(buf).to(dev)
+    outs = [torch.empty_like(t) for _ in range(d.get_world_size())]
+    d.all_gather(outs, t)
+    return [o.cpu().numpy()[:sizes[g]] for g, o in enumerate(outs)]
+
+
+_FIELDS = (("H", np.float32), ("objvalue", np.float32), ("sse", np.float64), ("iters", np.int32), ("reason", np.int32))
+
+
 def sharded_sweep(sweep_fn, ks, nruns, seeds, Winit, Hinit, params, n, m, need_all_W=True):
-    """Runs `sweep_fn` (Context.mu_sweep) on this rank's restarts and returns the results of ALL restarts.
+    """Runs `sweep_fn` (Context.mu_sweep) on this rank's chunks and returns the results of ALL restarts.
 
     seeds: (len(ks), nruns).  Result: dict k -> dict(W (nruns,n,k), H (nruns,k,m), objvalue, sse, iters, reason).
     need_all_W=False (the default `best=true`, clusterWmatrix=false path of execute_run, Exec:655-658): only the W of
-    the restart with the lowest objective is exchanged (one broadcast of n x k per rank k from its owner); W of the
-    other restarts is then only present for this rank's own restarts, None elsewhere ("W" becomes a list)."""
+    the restart with the lowest objective is exchanged; W of the other restarts is then only present for this rank's
+    own restarts, None elsewhere ("W" becomes a list)."""
     d = _dist()
     if d is None:
         return sweep_fn(ks, nruns, seeds=seeds, Winit=Winit, Hinit=Hinit, params=params)
-    import torch
-
     rank, N = d.get_rank(), d.get_world_size()
-    mine = list(range(rank, nruns, N))
-    per = (nruns + N - 1) // N  # every rank runs `per` restarts so that all gathers have equal shapes;
-    pad = mine + [mine[-1] if mine else 0] * (per - len(mine))  # padding restarts repeat one and are dropped
-    sub = lambda dct: None if dct is None else {k: np.asarray(v)[pad] for k, v in dct.items()}
-    local = sweep_fn(ks, per, seeds=np.asarray(seeds)[:, pad], Winit=sub(Winit), Hinit=sub(Hinit), params=params)
-    dev = _device(d)
-    out = {}
-    for k in ks:
-        o = {}
-        keys = ("W", "H", "objvalue", "sse", "iters", "reason") if need_all_W else ("H", "objvalue", "sse", "iters", "reason")
-        for key in keys:
-            parts = _all_gather_np(d, np.ascontiguousarray(local[k][key]))
-            full = np.empty((nruns,) + parts[0].shape[1:], dtype=parts[0].dtype)
-            for g in range(N):
-                idx = list(range(g, nruns, N))
-                full[idx] = parts[g][:len(idx)]
-            o[key] = full
-        if not need_all_W:
-            best = int(np.argsort(o["objvalue"], kind="stable")[0])  # Exec:545-546 (NaN sorts last)
-            owner = best % N
-            wb = np.ascontiguousarray(local[k]["W"][best // N]) if rank == owner else np.empty((n, k), np.float32)
-            t = torch.from_numpy(wb).to(dev)
-            d.broadcast(t, owner)
+    ks = [int(k) for k in ks]
+    c, chunks = plan_shards(ks, nruns, N)
+    seeds = np.asarray(seeds)
+    mine = [ch for ch in chunks if ch[2] == rank]
+    local = {}
+    if mine:
+        pad = {q: rs + [rs[-1]] * (c - len(rs)) for q, rs, _ in mine}
+        lks = [ks[q] for q, *_ in mine]
+        sub = lambda dct: None if dct is None else {ks[q]: np.asarray(dct[ks[q]])[pad[q]] for q in pad if dct.get(ks[q]) is not None}
+        local = sweep_fn(lks, c, seeds=np.stack([seeds[q, pad[q]] for q, *_ in mine]), Winit=sub(Winit), Hinit=sub(Hinit),
+                         params=params)
+    fields = _FIELDS + ((("W", np.float32),) if need_all_W else ())
+
+    def nbytes(ch):
+        k, cnt = ks[ch[0]], len(ch[1])
+        return cnt * ((k * m) * 4 + 4 + 8 + 4 + 4 + ((n * k) * 4 if need_all_W else 0))
+
+    parts = []
+    for q, rs, _ in mine:
+        for key, dt in fields:
+            parts.append(np.ascontiguousarray(np.asarray(local[ks[q]][key])[:len(rs)], dtype=dt).reshape(-1).view(np.uint8))
+    sizes = [sum(nbytes(ch) for ch in chunks if ch[2] == g) for g in range(N)]
+    got = _exchange(d, np.concatenate(parts) if parts else np.zeros(0, np.uint8), sizes)
+    out = {k: dict(H=np.empty((nruns, k, m), np.float32), objvalue=np.empty(nruns, np.float32), sse=np.empty(nruns, np.float64),
+                   iters=np.empty(nruns, np.int32), reason=np.empty(nruns, np.int32)) for k in ks}
+    if need_all_W:
+        for k in ks:
+            out[k]["W"] = np.empty((nruns, n, k), np.float32)
+    owner, slot = {}, {}
+    offs = [0] * N
+    for q, rs, g in chunks:  # same order as the packing loops of every rank
+        k, cnt = ks[q], len(rs)
+        for key, dt in fields:
+            shape = {"H": (cnt, k, m), "W": (cnt, n, k)}.get(key, (cnt,))
+            nb = int(np.prod(shape)) * np.dtype(dt).itemsize
+            out[k][key][rs] = got[g][offs[g]:offs[g] + nb].view(dt).reshape(shape)
+            offs[g] += nb
+        for j, r in enumerate(rs):
+            owner[(q, r)], slot[(q, r)] = g, j
+    if not need_all_W:
+        best = {q: int(np.argsort(out[ks[q]]["objvalue"], kind="stable")[0]) for q in range(len(ks))}  # Exec:545-546
+        wsz = [sum(n * ks[q] * 4 for q in best if owner[(q, best[q])] == g) for g in range(N)]
+        wb = [np.ascontiguousarray(local[ks[q]]["W"][slot[(q, best[q])]], dtype=np.float32).reshape(-1).view(np.uint8)
+              for q in sorted(best) if owner[(q, best[q])] == rank]
+        gotw = _exchange(d, np.concatenate(wb) if wb else np.zeros(0, np.uint8), wsz)
+        offs = [0] * N
+        for q in sorted(best):
+            k, g = ks[q], owner[(q, best[q])]
             W = [None] * nruns
-            for j, r in enumerate(mine):
-                W[r] = local[k]["W"][j]
-            W[best] = t.cpu().numpy()
-            o["W"] = W
-        out[k] = o
+            for qq, rs, _ in mine:
+                if qq == q:
+                    for j, r in enumerate(rs):
+                        W[r] = np.asarray(local[k]["W"][j])
+            nb = n * k * 4
+            W[best[q]] = gotw[g][offs[g]:offs[g] + nb].view(np.float32).reshape(n, k).copy()
+            offs[g] += nb
+            out[k]["W"] = W
     return out

@@ -124,6 +124,33 @@ def test_wide_rank_mfma_matches_valu_kernel_large(NMFk, ctx):
         np.testing.assert_allclose(a["objvalue"], b["objvalue"], rtol=1e-4)
 
 
+@pytest.mark.parametrize("compute", ["f32", "f64"])
+def test_merged_launch_groups_bitwise_equal(NMFk, ctx, oracle, compute):
+    """Few restarts per rank: ranks <= 16 share mixed-rank launches (step_kernel_multi, NMFK_MERGE).  Same arithmetic per
+    unit => results identical to per-rank launches bit for bit, for every grouping; missing data included."""
+    n, m = 700, 130
+    X = (0.05 + oracle.uniform_fill(33, 0, n * m)).reshape(n, m).astype(np.float32)
+    for nan in (False, True):
+        if nan:
+            X = X.copy()
+            X[::7, ::5] = np.nan
+        ctx.set_X(X)
+        ks, R = [2, 3, 5, 8, 13, 16, 20], 5
+        seeds = _seeds(NMFk, 11, ks, R)
+        cm = NMFk.COMPUTE_F64 if compute == "f64" else NMFk.COMPUTE_F32
+        out = {}
+        for mg in ("0", "1", "2", "5"):
+            os.environ["NMFK_MERGE"] = mg
+            try:
+                out[mg] = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=40, compute=cm)
+            finally:
+                del os.environ["NMFK_MERGE"]
+        for mg in ("1", "2", "5"):
+            for k in ks:
+                for key in ("W", "H", "objvalue", "iters", "reason"):
+                    assert np.array_equal(out[mg][k][key], out["0"][k][key], equal_nan=True), (mg, k, key)
+
+
 def test_stop_rule_fp64_identical_iterations(NMFk, ctx, oracle, bss_X):
     """Default stop rule (Mult:64-98) in fp64 compute mode: same iteration counts and stop reasons as the oracle."""
     X = bss_X.astype(np.float32)

@@ -1,5 +1,5 @@
-"""N > 1 path on CPU: two gloo ranks shard the restarts of every k (nmfk.jl_amd/parallel.py) and all-gather the
-results.  The compute function is injected (here: the CPU oracle, which only tests may use) so that the
+"""N > 1 path on CPU: two gloo ranks shard the restarts of every k (nmfk.jl_amd/parallel.py: plan_shards) and
+exchange the results in one padded all-gather.  The compute function is injected (here: the CPU oracle, which only tests may use) so that the
 partition / padding / gather logic is exercised without a GPU; on the GPU box the same code path runs with
 Context.mu_sweep and the nccl (RCCL) backend."""
 import os
@@ -64,8 +64,11 @@ def _worker(rank, world, port, nruns, q):
             best = int(np.argsort(res[k]["objvalue"], kind="stable")[0])
             assert np.array_equal(lean[k]["H"], res[k]["H"]) and np.array_equal(lean[k]["objvalue"], res[k]["objvalue"])
             assert np.array_equal(lean[k]["W"][best], res[k]["W"][best])
+            _, chunks = NMFk.parallel.plan_shards(ks, nruns, world)
+            own = {r for q, rs, g in chunks if g == rank and ks[q] == k for r in rs}
+            assert len(own) in (nruns // world, -(-nruns // world))
             for r in range(nruns):
-                if r % world == rank:
+                if r in own:
                     assert np.array_equal(lean[k]["W"][r], res[k]["W"][r])
                 elif r != best:
                     assert lean[k]["W"][r] is None
@@ -74,9 +77,24 @@ def _worker(rank, world, port, nruns, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nruns", [4, 5])  # 5: uneven shards (rank 0 gets 3 restarts, rank 1 gets 2 + one padding run)
-def test_sharded_sweep_two_ranks(oracle, nruns):
-    world, port = 2, _free_port()
+def test_plan_shards_covers_every_unit_once():
+    import nmfk_jl_amd as NMFk
+
+    for ks, nruns, world in [([2, 3, 4], 32, 8), ([5], 7, 4), ([2, 9], 2, 3), (list(range(2, 17)), 32, 1)]:
+        c, chunks = NMFk.parallel.plan_shards(ks, nruns, world)
+        assert c == -(-nruns // world)
+        seen = sorted((q, r) for q, rs, g in chunks for r in rs)
+        assert seen == [(q, r) for q in range(len(ks)) for r in range(nruns)]
+        for q, rs, g in chunks:
+            assert 0 <= g < world and 0 < len(rs) <= c
+        per_rank = [sum(len(rs) for q, rs, g in chunks if g == r) for r in range(world)]
+        assert max(per_rank) - min(per_rank) <= len(ks)
+
+
+# nruns 5: uneven shards (rank 0 gets 3 restarts, rank 1 gets 2 + one padding run); world 3 with 2 restarts: an idle rank
+@pytest.mark.parametrize("nruns,world", [(4, 2), (5, 2), (2, 3)])
+def test_sharded_sweep_two_ranks(oracle, nruns, world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, nruns, q)) for r in range(world)]
@@ -87,7 +105,7 @@ def test_sharded_sweep_two_ranks(oracle, nruns):
         p.join(timeout=60)
         assert p.exitcode == 0
     got.sort(key=lambda t: t[0])
-    (_, X0, r0), (_, X1, r1) = got
+    (_, X0, r0), (_, X1, r1) = got[0], got[-1]
     np.testing.assert_array_equal(X0, X1)
     # every rank holds the complete, identically ordered result ...
     for k in r0:

@@ -472,11 +472,17 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   if (const char *e = getenv("NMFK_MFMA_MINK")) mfma_mink = atoi(e);
   auto use_wide_k = [&](int k) { return wide_ok && k > 16; };
   auto use_mfma_k = [&](int k) { return wide_ok_nowide && k <= 16 && mfma_mink > 0 && k >= mfma_mink; };
+  int merge = -1;
+  if (const char *e = getenv("NMFK_MERGE")) merge = atoi(e);
+  if (merge < 0) merge = nruns <= NMFK_MERGE_MAX_RUNS ? std::min(nruns, NMFK_MERGE_GROUPS) : 0;
+  if (ctx->sparse || mfma_mink > 0) merge = 0;
+  merge = std::min(merge, nruns);
   // lane elements per workgroup (= per sum-table slot) of the half-step kernel a rank runs
   auto lane_tile = [&](int k, int ws) {
     if (ctx->sparse) return NMFK_TILE;
     if (use_wide_k(k)) return nmfk_mfma_wide_lane_tile(ws);
     if (use_mfma_k(k)) return ws == 4 ? 64 : NMFK_TILE;
+    if (merge > 0 && k <= 16) return (ws > 1 ? 64 : NMFK_TILE) * NMFK_MULTI_LB;
     return (ws > 1 ? 64 : NMFK_TILE) * NMFK_LB_OF(nmfk_padded_k(k));
   };
   int max_ws = 8;  // the experimental MFMA variant is written for 4-wave workgroups
@@ -526,11 +532,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // own kernel instantiation and stream.  With few restarts per rank the per-rank launches are tiny and the loop is
   // launch-bound: then the ranks <= 16 are merged into `merge` super-groups (restart r of every rank goes to
   // super-group r mod merge; kp = 0 marks a mixed-rank group, served by step_kernel_multi).
-  int merge = -1;
-  if (const char *e = getenv("NMFK_MERGE")) merge = atoi(e);
-  if (merge < 0) merge = nruns <= NMFK_MERGE_MAX_RUNS ? std::min(nruns, NMFK_MERGE_GROUPS) : 0;
-  if (ctx->sparse || mfma_mink > 0) merge = 0;
-  merge = std::min(merge, nruns);
   std::vector<Group> groups;
   std::vector<std::pair<int, int>> ulist;  // (index into ks, restart) in unit order
   ulist.reserve(nunits);

@@ -167,6 +167,9 @@ static inline int nmfk_padded_k(int k) {
 #ifndef NMFK_MERGE_GROUPS
 #define NMFK_MERGE_GROUPS 2    // number of mixed-rank launch groups then
 #endif
+#ifndef NMFK_MULTI_LB
+#define NMFK_MULTI_LB 2      // lane elements per thread of the mixed-rank kernel (1 measured 50 % slower: the wave-uniform rows are shared)
+#endif
 #ifndef NMFK_WIDE_NT
 #define NMFK_WIDE_NT 2   // 16-wide lane tiles per wave of the all-MFMA kernel for k > 16
 #endif

@@ -565,13 +565,12 @@ __global__ __launch_bounds__(2 * NMFK_TILE, NMFK_MINWAVES(KP)) void step_kernel(
 // One launch for units of DIFFERENT ranks (all <= 16, so that they share the lane tile 64/256 * NMFK_LB): used when a
 // sweep has so few restarts per rank that per-rank launches leave the loop launch-bound (strong scaling over many
 // GPUs).  The register allocation is that of the widest case, which is irrelevant when the chip is not full anyway.
-#define NMFK_MULTI_CASE(KP) step_body<KP, NMFK_LB_OF(16), NANS>(arena, X, gp, runs + u, it, lds)
+#define NMFK_MULTI_CASE(KP) step_body<KP, NMFK_MULTI_LB, NANS>(arena, X, gp, runs + u, it, lds)
 template <bool NANS>
 __global__ __launch_bounds__(2 * NMFK_TILE, 2) void step_kernel_multi(char *arena, const float *__restrict__ X,
                                                                       const NmfkRun *__restrict__ runs,
                                                                       const NmfkState *__restrict__ state,
                                                                       const NmfkStepArgs *__restrict__ gp, int it, int u0) {
-  static_assert(NMFK_LB_OF(1) == NMFK_LB_OF(16), "mixed-rank launches need one lane tile for all ranks <= 16");
   extern __shared__ double lds[];
   const int u = u0 + blockIdx.y;
   if (!gp->force && !state[u].active) return;
@@ -1608,7 +1607,7 @@ void NMFK_NAME(nmfk_launch_step)(const NmfkStepArgs &a, const NmfkStepArgs *darg
 }
 
 void NMFK_NAME(nmfk_launch_step_multi)(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int u0, int cnt, hipStream_t s) {
-  constexpr int LB = NMFK_LB_OF(16);
+  constexpr int LB = NMFK_MULTI_LB;
   const int ws = a.wsplit;
   const int lpw = ws > 1 ? 64 : NMFK_TILE;
   const int ntile = (a.L + lpw * LB - 1) / (lpw * LB);

@@ -15,6 +15,7 @@ clustering, silhouettes, fit re-checks); this file is orchestration only (sortin
 the acceptance filters, k selection).  The reference's serial loops over k and over restarts become one
 flat (k, restart) work list; with torch.distributed initialised the list is sharded by restart over the
 ranks (parallel.py)."""
+import hashlib
 import math
 import os
 import warnings
@@ -289,6 +290,44 @@ def execute_run(X, nk, nNMF, device=None, return_details=False, **kw):
     return out if return_details else out[:5]
 
 
+def hash_sha256_hex(X):
+    """Exec:62-66.  The reference hashes Julia's Serialization stream of X; that framing is Julia-internal, so the
+    digest here is over (dtype, shape, column-major little-endian bytes) -- the sidecar protocol is the same, the hex
+    strings of the two implementations are not interchangeable."""
+    h = hashlib.sha256()
+    if _is_sparse(X):
+        X = X.tocsc()
+        h.update(f"csc {X.dtype.str} {X.shape}".encode())
+        for a in (X.indptr, X.indices, X.data):
+            h.update(np.ascontiguousarray(a).tobytes())
+    else:
+        X = np.asarray(X)
+        h.update(f"{X.dtype.str} {X.shape}".encode())
+        h.update(np.asfortranarray(X).tobytes(order="F"))
+    return h.hexdigest()
+
+
+def check_x_hash(X, xfile, quiet=True):
+    """check_x_hash! (Exec:68-93): `<xfile>.sha256` sidecar; written when absent, compared (warning on mismatch)
+    when present.  Returns the digest."""
+    h = hash_sha256_hex(X)
+    hashfile = xfile + ".sha256"
+    if os.path.isfile(hashfile):
+        stored = open(hashfile).read().strip()
+        if stored and stored != h:
+            warnings.warn(f"Matrix hash mismatch in '{hashfile}': Cached results may not correspond to this matrix! "
+                          "Consider deleting the hash file and cached results to avoid confusion.")
+        elif not quiet:
+            print(f"Matrix hash DOES match the stored hash in '{hashfile}'.")
+    else:
+        os.makedirs(os.path.dirname(hashfile) or ".", exist_ok=True)
+        with open(hashfile, "w") as f:
+            f.write(h + "\n")
+        if not quiet:
+            print(f"Matrix hash saved in '{hashfile}'.")
+    return h
+
+
 def _result_filename(resultdir, casefilename, n, m, nk, nNMF):
     # Exec:265, 324: "<case>_<n>_<m>_<nk>_<nNMF>.jld"; the payload here is .npz with the same keys
     return os.path.join(resultdir, f"{casefilename}_{n}_{m}_{nk}_{nNMF}.npz")
@@ -326,16 +365,25 @@ def execute(X, nkrange, nNMF=10, *, cutoff=0.5, clusterWmatrix=False, mixture="n
     if "Wfixed" in kw or "Hfixed" in kw:  # Exec:305-307
         ordersignals = False
 
-    todo = []
+    if load or save:  # Exec:256-262 (the reference hashes X on every call, once per k; here only when the cache is in use)
+        xs = "_".join(str(v) for v in X.shape)
+        check_x_hash(X, os.path.join(resultdir, f"{casefilename or 'nmfk'}_x_matrix_{xs}.npz"), quiet=quiet)
+    todo, recheck = [], []
     for nk in ks:  # Exec:264-303: per-k result cache
         fn = _result_filename(resultdir, casefilename, n, m, nk, nNMF)
+        if load and not os.path.isfile(fn):  # Exec:266-269: old file-name convention
+            old = os.path.join(resultdir, f"{casefilename}-{nk}-{nNMF}.npz")
+            fn = old if os.path.isfile(old) else fn
         if load and os.path.isfile(fn):
             with np.load(fn) as z:
                 Wl, Hl = z["W"], z["H"]
                 if Wl.shape == (n, nk) and Hl.shape == (nk, m):
                     W[nk - 1], H[nk - 1] = Wl, Hl
                     fitquality[nk - 1], robustness[nk - 1], aic[nk - 1] = z["fit"], z["robustness"], z["aic"]
+                    recheck.append(nk)
                     continue
+            if not quiet:  # Exec:287-289
+                print(f"File {fn} contains inconsistent results; runs will be executed ...")
         if loadonly:  # Exec:291-298 sentinel
             W[nk - 1], H[nk - 1] = np.zeros((0, 0), np.float32), np.zeros((0, 0), np.float32)
             fitquality[nk - 1], robustness[nk - 1], aic[nk - 1] = np.inf, -1, -np.inf
@@ -345,6 +393,13 @@ def execute(X, nkrange, nNMF=10, *, cutoff=0.5, clusterWmatrix=False, mixture="n
     if ctx is None and (todo or not all(np.isinf(fitquality[[k - 1 for k in ks]]))):
         ctx = _context(device)
         _upload(ctx, X, kw.get("lambda_", 1e-32))  # raises "All matrix entries must be nonnegative!" (Mult:4-7)
+    for nk in recheck:  # Exec:274-283: a loaded result whose fit does not match X is re-saved with the new fit
+        fit = ctx.frobenius(W[nk - 1], H[nk - 1])
+        if abs(fit - fitquality[nk - 1]) > np.finfo(np.float16).eps:
+            warnings.warn(f"Fit quality is not consistent: {fit} != {fitquality[nk - 1]}")
+            fitquality[nk - 1] = fit
+            np.savez(_result_filename(resultdir, casefilename, n, m, nk, nNMF), W=W[nk - 1], H=H[nk - 1],
+                     fit=fitquality[nk - 1], robustness=robustness[nk - 1], aic=aic[nk - 1])
     if todo:
         res, _ = _sweep(ctx, X, todo, int(nNMF), kw, need_all_W=bool(clusterWmatrix) or not post.get("best", True))
         for nk in todo:

@@ -349,6 +349,19 @@ def test_execute_cache_roundtrip(NMFk, tmp_path):
     assert os.path.isfile(tmp_path / "case_8_6_2_3.npz")
     r2 = NMFk.execute(X, 2, 3, casefilename="case", resultdir=str(tmp_path), quiet=True, seed=999, maxiter=30)
     np.testing.assert_array_equal(r1[0], r2[0])  # second call is served from the cache
+    # X sidecar (check_x_hash!, Exec:68-93): written on the first call, a different X of the same shape warns
+    assert os.path.isfile(tmp_path / "case_x_matrix_8_6.npz.sha256")
+    with pytest.warns(UserWarning, match="hash mismatch"):
+        with pytest.warns(UserWarning, match="Fit quality is not consistent"):  # Exec:274-283: new fit, re-saved
+            r3 = NMFk.execute(X + 1, 2, 3, casefilename="case", resultdir=str(tmp_path), quiet=True, seed=1, maxiter=30)
+    assert r3[2] != r1[2]
+    with np.load(tmp_path / "case_8_6_2_3.npz") as z:
+        assert float(z["fit"]) == float(r3[2])
+    # old file-name convention (Exec:266-269)
+    os.replace(tmp_path / "case_8_6_2_3.npz", tmp_path / "case-2-3.npz")
+    with pytest.warns(UserWarning):
+        r4 = NMFk.execute(X + 1, 2, 3, casefilename="case", resultdir=str(tmp_path), quiet=True, seed=5, maxiter=30)
+    np.testing.assert_array_equal(r4[0], r3[0])
 
 
 def test_planted_rank_kopt_matches_oracle_fp32(NMFk, oracle):

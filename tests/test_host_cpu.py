@@ -101,3 +101,21 @@ def test_input_checks(NMFk):
 def test_run_seed_shared_with_oracle(NMFk, oracle):
     for args in [(0, 2, 0), (2021, 5, 9), (2 ** 40, 64, 31)]:
         assert NMFk.run_seed(*args) == oracle.run_seed(*args)
+
+
+def test_x_hash_sidecar(NMFk, tmp_path):
+    """check_x_hash! protocol (Exec:68-93): sidecar written once, mismatch warns, digest depends on values and shape."""
+    import warnings
+
+    from nmfk_jl_amd.execute import check_x_hash, hash_sha256_hex
+
+    X = np.arange(12, dtype=np.float32).reshape(3, 4)
+    xf = str(tmp_path / "c_x_matrix_3_4.npz")
+    h = check_x_hash(X, xf)
+    assert open(xf + ".sha256").read().strip() == h == hash_sha256_hex(np.asfortranarray(X))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert check_x_hash(X.copy(), xf) == h
+    with pytest.warns(UserWarning, match="hash mismatch"):
+        check_x_hash(X + 1, xf)
+    assert hash_sha256_hex(X.reshape(4, 3)) != h and hash_sha256_hex(X.astype(np.float64)) != h

@@ -267,8 +267,9 @@ NMFK_EXPORT int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, 
   if (ctx->Wgt) (void)hipFree(ctx->Wgt);
   ctx->Wgt = nullptr;
   free_sparse(ctx);
-  HIPCHECK(hipMalloc((void **)&ctx->Xc, bytes));
-  HIPCHECK(hipMalloc((void **)&ctx->Xr, bytes));
+  // + slack: the half-step kernels read pairs of adjacent entries; the pair of the last entry pokes 4 bytes past the end
+  HIPCHECK(hipMalloc((void **)&ctx->Xc, bytes + 64));
+  HIPCHECK(hipMalloc((void **)&ctx->Xr, bytes + 64));
   const size_t inbytes = (size_t)ldx * (size_t)m * sizeof(float);
   if (ctx->scratch.ensure(inbytes + 256)) return fail(NMFK_ERR_HIP, "out of device memory (X staging)");
   unsigned long long *counts = (unsigned long long *)ctx->scratch.p;

@@ -167,6 +167,18 @@ static inline int nmfk_padded_k(int k) {
 #ifndef NMFK_MERGE_GROUPS
 #define NMFK_MERGE_GROUPS 2    // number of mixed-rank launch groups then
 #endif
+#ifndef NMFK_UNIT_FAST
+#define NMFK_UNIT_FAST 1     // half-step grids: unit = fast dimension (XCD / L2 locality of X tiles and factors)
+#endif
+#ifndef NMFK_ADJ
+#define NMFK_ADJ 0           // 1: the two lane elements of a thread are adjacent, one 8-byte X load per step (measured 5-10 % slower)
+#endif
+#ifndef NMFK_EPACK
+#define NMFK_EPACK 1         // packed VALU lanes = the two lane elements of a thread (1) or adjacent signals (0)
+#endif
+#ifndef NMFK_XBUF
+#define NMFK_XBUF 1          // X entries through buffer loads (scalar address arithmetic); 0 = global loads
+#endif
 #ifndef NMFK_MULTI_LB
 #define NMFK_MULTI_LB 2      // lane elements per thread of the mixed-rank kernel (1 measured 50 % slower: the wave-uniform rows are shared)
 #endif

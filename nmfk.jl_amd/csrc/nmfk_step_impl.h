@@ -197,7 +197,7 @@ __device__ __forceinline__ f64x2 div2(f64x2 x, f64x2 p) { return x / p; }
 
 template <int KP, int LB, bool NANS>
 __device__ __forceinline__ void step_body(char *arena, const float *__restrict__ X, const NmfkStepArgs *__restrict__ gp,
-                                          const NmfkRun *__restrict__ rdp, const int it, double *lds) {
+                                          const NmfkRun *__restrict__ rdp, const int it, double *lds, const int bx) {
   // loop steps per group: the loop-factor rows of TWO groups live in SGPRs (about 100 available)
 #if NMFK_UPOL == 1
   constexpr int U = (KP <= 4) ? 4 : (KP <= 12) ? 2 : 1;
@@ -229,10 +229,12 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ws = g.wsplit;
   const int lpw = (ws > 1) ? 64 : NMFK_TILE;
-  const int tile = blockIdx.x / g.S;
-  const int s = blockIdx.x - tile * g.S;
+  const int tile = bx / g.S;  // bx: index of the (lane tile, loop split) pair, see NMFK_GRID
+  const int s = bx - tile * g.S;
   if (tile * lpw * LB >= g.L) return;  // the grid is sized for the smallest LB of the launch
-  const int lbase = tile * lpw * LB + ((ws > 1) ? lane : tid);
+  // lane elements of a thread: NMFK_ADJ: LB adjacent ones (one wide X load per loop step), else lpw apart
+  constexpr bool ADJ = (NMFK_ADJ != 0) && (NMFK_XBUF != 0) && LB == 2;
+  const int lbase = ADJ ? tile * lpw * LB + LB * ((ws > 1) ? lane : tid) : tile * lpw * LB + ((ws > 1) ? lane : tid);
 
   const T *__restrict__ Hcur = NMFK_PTR(const T, g, NMFK_HOFF(*rdp, g.it));
   const T *__restrict__ Hnew = NMFK_PTR(const T, g, NMFK_HOFF(*rdp, g.it + 1));
@@ -247,13 +249,18 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   constexpr bool TAIL = (KP & 1) != 0;
   bool valid[LB];
   int lc[LB];
+  // NMFK_EPACK: with two lane elements per thread the packed lanes are the two ELEMENTS instead (signal c of both
+  // elements in one register pair, the loop-factor entry b[c] broadcast to both halves): no horizontal add of the
+  // two halves of p, no odd-rank tail, and the ratio pair comes out packed.
+  constexpr bool EP = (NMFK_EPACK != 0) && LB == 2;
   T2 a2[LB][NPA], acc2[LB][NPA];
   T at[LB], acct[LB];
-#define A_(e, c) ((TAIL && (c) == KP - 1) ? at[(e)] : a2[(e)][(c) / 2][(c) & 1])
-#define ACC_(e, c) ((TAIL && (c) == KP - 1) ? acct[(e)] : acc2[(e)][(c) / 2][(c) & 1])
+  T2 ae[EP ? KP : 1], acce[EP ? KP : 1];
+#define A_(e, c) (EP ? ae[EP ? (c) : 0][(e)] : (TAIL && (c) == KP - 1) ? at[(e)] : a2[(e)][(c) / 2][(c) & 1])
+#define ACC_(e, c) (EP ? acce[EP ? (c) : 0][(e)] : (TAIL && (c) == KP - 1) ? acct[(e)] : acc2[(e)][(c) / 2][(c) & 1])
 #pragma unroll
   for (int e = 0; e < LB; ++e) {
-    const int l = lbase + e * lpw;
+    const int l = ADJ ? lbase + e : lbase + e * lpw;
     valid[e] = l < g.L;
     lc[e] = valid[e] ? l : 0;
     at[e] = (T)0;
@@ -261,7 +268,9 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
 #pragma unroll
     for (int c = 0; c < KP; ++c) {
       const T v = valid[e] ? A[c + (int64_t)lc[e] * KP] : (T)1;
-      if (TAIL && c == KP - 1)
+      if (EP)
+        ae[EP ? c : 0][e] = v;
+      else if (TAIL && c == KP - 1)
         at[e] = v;
       else
         a2[e][c / 2][c & 1] = v;
@@ -269,6 +278,8 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
 #pragma unroll
     for (int j = 0; j < NPA; ++j) acc2[e][j] = splat2((T)0);
   }
+#pragma unroll
+  for (int c = 0; c < (EP ? KP : 1); ++c) acce[c] = splat2((T)0);
   int d0 = s * g.dchunk;
   int d1 = min(g.D, d0 + g.dchunk);
   if (ws > 1) {  // the ws waves of the workgroup share the lane elements and split the loop range
@@ -287,7 +298,40 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   const T *__restrict__ bnext = B + (int64_t)d0 * KP;
   const int64_t ld = g.ld;
 
+#if NMFK_XBUF
+  // X entries come through BUFFER loads: address = resource base (the group's first row, wave-uniform, SGPRs) +
+  // soffset (row within the group, SGPR) + per-lane 32-bit byte offset (VGPR, loop invariant).  All address
+  // arithmetic is scalar; with global loads the compiler keeps one 64-bit VGPR base per (row, element) and adds the
+  // running offset with a VALU instruction per load (1 of every 5 VALU issue slots at k = 4).
+  unsigned lbyte[LB];
+#pragma unroll
+  for (int e = 0; e < LB; ++e) lbyte[e] = lofs[e] * 4u;
+  const int ldb = (int)(ld * 4);  // bytes per row (nmfk_set_X limits the dimensions to 2^27)
+#endif
   auto load = [&](T (&bufv)[U][KP], float (&bufx)[U][LB]) __attribute__((always_inline)) {
+#if NMFK_XBUF
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)xnext, 0, -1, 0x00020000);
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu) {
+#pragma unroll
+      for (int c = 0; c < KP; ++c) bufv[uu][c] = bnext[uu * KP + c];
+      if (ADJ) {  // the pair (l, l + 1) in one 8-byte load (dword alignment suffices); l + 1 may be a dummy
+        typedef float xpair_t __attribute__((ext_vector_type(2)));
+        const xpair_t xx = __builtin_bit_cast(xpair_t, __builtin_amdgcn_raw_buffer_load_b64(rs, lbyte[0], uu * ldb, 0));
+        bufx[uu][0] = xx.x;
+        bufx[uu][LB - 1] = xx.y;
+        continue;
+      }
+#pragma unroll
+      for (int e = 0; e < LB; ++e)
+#ifdef NMFK_DBG_NOLOAD
+        bufx[uu][e] = __builtin_bit_cast(float, lbyte[e] + uu);
+#else
+        bufx[uu][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lbyte[e], uu * ldb, 0));
+#endif
+    }
+    xnext += U * ld;
+#else
     const float *__restrict__ xr = xnext;
 #pragma unroll
     for (int uu = 0; uu < U; ++uu) {
@@ -298,6 +342,7 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
       xr += ld;
     }
     xnext = xr;
+#endif
     bnext += U * KP;
   };
   // imputed value of a missing entry (EM imputation, Mult:72): fl32(W*H) of the previous iteration's result,
@@ -312,6 +357,30 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
     return (T)(float)po;
   };
   auto row = [&](int d, const T *bv, const float *xf) __attribute__((always_inline)) {
+    if (EP) {
+      T2 p2 = splat2((T)0);
+#pragma unroll
+      for (int c = 0; c < KP; ++c) p2 = fma2(ae[EP ? c : 0], splat2(bv[c]), p2);
+      T2 x2 = {(T)xf[0], (T)xf[LB - 1]};
+      if (NANS) {
+#pragma unroll
+        for (int e = 0; e < LB; ++e) {
+          const bool isn = xf[e] != xf[e];
+          if (__any(isn)) {
+            const T xi = impute(d, e, p2[e]);
+            x2[e] = isn ? xi : x2[e];
+          }
+        }
+      }
+#ifdef NMFK_DBG_NORCP
+      const T2 q2 = x2 * p2;
+#else
+      const T2 q2 = div2(x2, p2);
+#endif
+#pragma unroll
+      for (int c = 0; c < KP; ++c) acce[EP ? c : 0] = fma2(splat2(bv[c]), q2, acce[EP ? c : 0]);
+      return;
+    }
     T p[LB], q[LB], x[LB];
 #pragma unroll
     for (int e = 0; e < LB; ++e) {
@@ -480,7 +549,9 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
 #pragma unroll
           for (int c = 0; c < KP; ++c) {
             const T v = ldsT[((w * LB + e) * KP + c) * 64 + lane];
-            if (TAIL && c == KP - 1)
+            if (EP)
+              acce[EP ? c : 0][e] += v;
+            else if (TAIL && c == KP - 1)
               acct[e] += v;
             else
               acc2[e][c / 2][c & 1] += v;
@@ -554,25 +625,27 @@ template <bool NANS, int KP>
 __global__ __launch_bounds__(2 * NMFK_TILE, NMFK_MINWAVES(KP)) void step_kernel(char *arena, const float *__restrict__ X,
                                                          const NmfkRun *__restrict__ runs,
                                                          const NmfkState *__restrict__ state,
-                                                         const NmfkStepArgs *__restrict__ gp, int it, int u0) {
+                                                         const NmfkStepArgs *__restrict__ gp, int it, int u0, int uf) {
   constexpr int LB = NMFK_LB_OF(KP);
   extern __shared__ double lds[];
-  const int u = u0 + blockIdx.y;
+  const int u = u0 + (uf ? blockIdx.x : blockIdx.y);
   if (!gp->force && !state[u].active) return;
-  step_body<KP, LB, NANS>(arena, X, gp, runs + u, it, lds);
+  step_body<KP, LB, NANS>(arena, X, gp, runs + u, it, lds, uf ? blockIdx.y : blockIdx.x);
 }
 
 // One launch for units of DIFFERENT ranks (all <= 16, so that they share the lane tile 64/256 * NMFK_LB): used when a
 // sweep has so few restarts per rank that per-rank launches leave the loop launch-bound (strong scaling over many
 // GPUs).  The register allocation is that of the widest case, which is irrelevant when the chip is not full anyway.
-#define NMFK_MULTI_CASE(KP) step_body<KP, NMFK_MULTI_LB, NANS>(arena, X, gp, runs + u, it, lds)
+#define NMFK_MULTI_CASE(KP) step_body<KP, NMFK_MULTI_LB, NANS>(arena, X, gp, runs + u, it, lds, bx)
 template <bool NANS>
 __global__ __launch_bounds__(2 * NMFK_TILE, 2) void step_kernel_multi(char *arena, const float *__restrict__ X,
                                                                       const NmfkRun *__restrict__ runs,
                                                                       const NmfkState *__restrict__ state,
-                                                                      const NmfkStepArgs *__restrict__ gp, int it, int u0) {
+                                                                      const NmfkStepArgs *__restrict__ gp, int it, int u0,
+                                                                      int uf) {
   extern __shared__ double lds[];
-  const int u = u0 + blockIdx.y;
+  const int u = u0 + (uf ? blockIdx.x : blockIdx.y);
+  const int bx = uf ? blockIdx.y : blockIdx.x;
   if (!gp->force && !state[u].active) return;
   switch (runs[u].kp) {
     case 1: NMFK_MULTI_CASE(1); break;   case 2: NMFK_MULTI_CASE(2); break;   case 3: NMFK_MULTI_CASE(3); break;
@@ -869,10 +942,12 @@ template <int KQ, int NB, int NT>
 __global__ __launch_bounds__(2 * NMFK_TILE) void mfma_wide_kernel(char *arena, const float *__restrict__ X,
                                                                  const NmfkRun *__restrict__ runs,
                                                                  const NmfkState *__restrict__ state,
-                                                                 const NmfkStepArgs *__restrict__ gp, int it, int u0) {
+                                                                 const NmfkStepArgs *__restrict__ gp, int it, int u0,
+                                                                 int uf) {
   extern __shared__ double lds[];  // den[64], red[8*64], then max(staging, cross-wave scratch)
   constexpr int KP = 4 * KQ, RS = KP + 4;  // staged row stride (floats): 16-byte aligned, off the 32-bank period
-  const int u = u0 + blockIdx.y;
+  const int u = u0 + (uf ? blockIdx.x : blockIdx.y);
+  const int bx = uf ? blockIdx.y : blockIdx.x;
   if (!gp->force && !state[u].active) return;
   const NmfkRun *__restrict__ rdp = runs + u;
   const int k = rdp->k;
@@ -880,7 +955,7 @@ __global__ __launch_bounds__(2 * NMFK_TILE) void mfma_wide_kernel(char *arena, c
   const int which = gp->which, ws = gp->wsplit, S = gp->S, L = gp->L, D = gp->D;
   const int nwaves = blockDim.x >> 6;
   const int lpw = 16 * NT * (ws > 1 ? 1 : nwaves);
-  const int tile = blockIdx.x / S, s = blockIdx.x - tile * S;
+  const int tile = bx / S, s = bx - tile * S;
   const int l0 = tile * lpw + (ws > 1 ? 0 : wave * 16 * NT);
 
   const float *__restrict__ Hcur = (const float *)(arena + NMFK_HOFF(*rdp, it));
@@ -1575,7 +1650,16 @@ __global__ void finish_state_kernel(NmfkFinishArgs g) {
 
 // ------------------------------------------------------------------------------------------------------
 // launchers
+//
+// Grid order of the half-step kernels (NMFK_UNIT_FAST): the UNIT is the fast grid dimension, the (lane tile, loop
+// split) index the slow one.  Workgroups are dealt to the 8 XCDs round-robin in linear order, so with the units
+// fastest (a) consecutive workgroups read the SAME tile of X for different restarts -- each XCD fetches a tile
+// from the Infinity Cache once per kernel and serves the other restarts from its own L2 -- and (b) unit u always
+// lands on XCD u mod 8, so its factors stay in one L2.  Tile-fastest order streams all of X (16.8 MB, 4 MB of L2 per
+// XCD) once per unit.  grid.y is limited to 65535: more tiles than that fall back to tile-fastest.
 // ------------------------------------------------------------------------------------------------------
+static inline int nmfk_unit_fast(int tiles) { return (NMFK_UNIT_FAST != 0) && tiles <= 65535; }
+#define NMFK_GRID(uf, tiles, cnt) ((uf) ? dim3((cnt), (tiles)) : dim3((tiles), (cnt)))
 void NMFK_NAME(nmfk_launch_init)(const NmfkInitArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(init_kernel, dim3(std::max(a.PW, a.PH), a.nunits), dim3(NMFK_TILE), 0, s, a);
 }
@@ -1588,16 +1672,17 @@ static void launch_step_kp(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int
   const int ws = a.wsplit;
   const int lpw = ws > 1 ? 64 : NMFK_TILE;
   const int ntile = (a.L + lpw * LB - 1) / (lpw * LB);
-  const dim3 grid(ntile * a.S, cnt), blk(ws > 1 ? 64 * ws : NMFK_TILE);
+  const int uf = nmfk_unit_fast(ntile * a.S);
+  const dim3 grid = NMFK_GRID(uf, ntile * a.S, cnt), blk(ws > 1 ? 64 * ws : NMFK_TILE);
   size_t scratch = ws > 1 ? (size_t)(ws - 1) * LB * KP * 64 * sizeof(T) : 0;
 #if NMFK_LDSB
   scratch = std::max(scratch, (size_t)(ws > 1 ? ws : 4) * 2 * 16 * KP * sizeof(T));
 #endif
   const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + scratch;
   if (a.has_nan)
-    hipLaunchKernelGGL((step_kernel<true, KP>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
+    hipLaunchKernelGGL((step_kernel<true, KP>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0, uf);
   else
-    hipLaunchKernelGGL((step_kernel<false, KP>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
+    hipLaunchKernelGGL((step_kernel<false, KP>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0, uf);
 }
 
 #define NMFK_LAUNCH_CASE(KP) launch_step_kp<KP>(a, dargs, u0, cnt, s)
@@ -1611,16 +1696,17 @@ void NMFK_NAME(nmfk_launch_step_multi)(const NmfkStepArgs &a, const NmfkStepArgs
   const int ws = a.wsplit;
   const int lpw = ws > 1 ? 64 : NMFK_TILE;
   const int ntile = (a.L + lpw * LB - 1) / (lpw * LB);
-  const dim3 grid(ntile * a.S, cnt), blk(ws > 1 ? 64 * ws : NMFK_TILE);
+  const int uf = nmfk_unit_fast(ntile * a.S);
+  const dim3 grid = NMFK_GRID(uf, ntile * a.S, cnt), blk(ws > 1 ? 64 * ws : NMFK_TILE);
   size_t scratch = ws > 1 ? (size_t)(ws - 1) * LB * 16 * 64 * sizeof(T) : 0;
 #if NMFK_LDSB
   scratch = std::max(scratch, (size_t)(ws > 1 ? ws : 4) * 2 * 16 * 16 * sizeof(T));
 #endif
   const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + scratch;
   if (a.has_nan)
-    hipLaunchKernelGGL((step_kernel_multi<true>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
+    hipLaunchKernelGGL((step_kernel_multi<true>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0, uf);
   else
-    hipLaunchKernelGGL((step_kernel_multi<false>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
+    hipLaunchKernelGGL((step_kernel_multi<false>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0, uf);
 }
 
 #ifdef NMFK_IS_F32
@@ -1649,11 +1735,12 @@ static void launch_mfma_wide(const NmfkStepArgs &a, const NmfkStepArgs *dargs, i
   const int ws = a.wsplit, nwaves = ws > 1 ? ws : 4;
   const int lpw = 16 * NT * (ws > 1 ? 1 : nwaves);
   const int ntile = (a.L + lpw - 1) / lpw;
-  const dim3 grid(ntile * a.S, cnt), blk(64 * nwaves);
+  const int uf = nmfk_unit_fast(ntile * a.S);
+  const dim3 grid = NMFK_GRID(uf, ntile * a.S, cnt), blk(64 * nwaves);
   const size_t stage = (size_t)nwaves * 16 * (4 * KQ + 4) * sizeof(float);
   const size_t cross = ws > 1 ? (size_t)(ws - 1) * NT * NB * 4 * 64 * sizeof(float) : 0;
   const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + std::max(stage, cross);
-  hipLaunchKernelGGL((mfma_wide_kernel<KQ, NB, NT>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0);
+  hipLaunchKernelGGL((mfma_wide_kernel<KQ, NB, NT>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0, uf);
 }
 
 int nmfk_mfma_wide_lane_tile(int wsplit) { return 16 * NMFK_WIDE_NT * (wsplit > 1 ? 1 : 4); }

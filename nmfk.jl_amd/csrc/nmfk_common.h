@@ -170,6 +170,9 @@ static inline int nmfk_padded_k(int k) {
 #ifndef NMFK_UNIT_FAST
 #define NMFK_UNIT_FAST 1     // half-step grids: unit = fast dimension (XCD / L2 locality of X tiles and factors)
 #endif
+#ifndef NMFK_PCHAINS
+#define NMFK_PCHAINS 1       // independent partial sums of <a, b> in the element-packed half-step (2, 4: no gain measured)
+#endif
 #ifndef NMFK_ADJ
 #define NMFK_ADJ 0           // 1: the two lane elements of a thread are adjacent, one 8-byte X load per step (measured 5-10 % slower)
 #endif

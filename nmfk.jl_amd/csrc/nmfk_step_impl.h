@@ -358,9 +358,19 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   };
   auto row = [&](int d, const T *bv, const float *xf) __attribute__((always_inline)) {
     if (EP) {
-      T2 p2 = splat2((T)0);
+      // NMFK_PCHAINS independent partial sums: a single chain of KP dependent FMAs leaves a wave waiting on its own
+      // previous result at every step
+      constexpr int NCH = KP >= 2 * NMFK_PCHAINS ? NMFK_PCHAINS : 1;
+      T2 pp[NCH];
 #pragma unroll
-      for (int c = 0; c < KP; ++c) p2 = fma2(ae[EP ? c : 0], splat2(bv[c]), p2);
+      for (int h = 0; h < NCH; ++h) pp[h] = splat2((T)0);
+#pragma unroll
+      for (int c = 0; c < KP; ++c) pp[c % NCH] = fma2(ae[EP ? c : 0], splat2(bv[c]), pp[c % NCH]);
+#pragma unroll
+      for (int h = NCH / 2; h > 0; h >>= 1)
+#pragma unroll
+        for (int i = 0; i < h; ++i) pp[i] = pp[i] + pp[i + h];
+      T2 p2 = pp[0];
       T2 x2 = {(T)xf[0], (T)xf[LB - 1]};
       if (NANS) {
 #pragma unroll

@@ -152,7 +152,9 @@ struct Sampler {
     }
     return used++;
   }
-  bool want(int it) const { return on && (it % 50) == 0; }  // sparse sampling: the events cost host time too
+  // sparse sampling (the events cost host time too); the period is coprime to the 10-iteration check cadence so that
+  // the samples cover every phase of it (every 50th iteration always follows a check block: biased short)
+  bool want(int it) const { return on && (it % 47) == 23; }
   size_t begin(hipStream_t s) {
     const size_t e = event();
     if (on) (void)hipEventRecord(ctx->events[e], s);

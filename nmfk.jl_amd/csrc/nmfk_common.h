@@ -168,7 +168,7 @@ static inline int nmfk_padded_k(int k) {
 #define NMFK_MERGE_GROUPS 2    // number of mixed-rank launch groups then
 #endif
 #ifndef NMFK_UNIT_FAST
-#define NMFK_UNIT_FAST 1     // half-step grids: unit = fast dimension (XCD / L2 locality of X tiles and factors)
+#define NMFK_UNIT_FAST 0     // half-step grids: 1 = unit is the fast dimension (see the launchers: measured worse for L2)
 #endif
 #ifndef NMFK_PCHAINS
 #define NMFK_PCHAINS 1       // independent partial sums of <a, b> in the element-packed half-step (2, 4: no gain measured)

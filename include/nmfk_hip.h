@@ -157,6 +157,23 @@ int nmfk_cluster_stats(nmfk_ctx *ctx, int k, int nsol, int64_t n, int64_t m, con
 /* normnan(X - W*H) with NaN -> skipped (Help:226-228): the re-checks at Exec:603, 664-667 and 212-222. */
 int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float *H, double *out);
 
+/* robust k-means ---------------------------------------------------------------------------------------------- */
+/* robustkmeans(X, k, repeats; maxiter, tol, compute_silhouettes_flag)  src/NMFkCluster.jl:172-246,
+ * without the JLD cache: `repeats` independent Clustering.kmeans(X, k; distance=CosineDist()) runs (k-means++
+ * seeding, Lloyd iterations; restated in oracle/nmfk_oracle.c), all concurrent on the GPU; the run with the lowest
+ * total cost wins (first wins ties, Clus:227) and its clusters are relabelled by decreasing size (sortclustering,
+ * Clus:264-292).  Random draws: the library's counter-based generator, u(seed + repeat, draw index).
+ *   X            d x n column-major, columns = samples (the reference's orientation)
+ *   assignments  n, 1-based, sorted labels;  centers d x k (sorted order, zero columns for clusters not found)
+ *   costs        n cosine distances to the own centre;  counts k (sorted);  totalcost = sum(costs)
+ *   nclusters    clusters found (< k: the reference warns, Clus:232-234)
+ *   all_costs    repeats total costs (may be NULL);  silhouettes n point silhouettes of the best run on
+ *                pairwise(CosineDist(), zerostoepsilon(X)) (Clus:204-213), NULL = compute_silhouettes_flag=false */
+int nmfk_robustkmeans(nmfk_ctx *ctx, int d, int64_t n, const float *X, int k, int repeats, int maxiter, double tol,
+                      uint64_t seed, int32_t *assignments, float *centers, float *costs, int32_t *counts,
+                      double *totalcost, int32_t *best_repeat, int32_t *iterations, int32_t *nclusters,
+                      double *all_costs, float *silhouettes);
+
 /* measurement ----------------------------------------------------------------------------------------------- */
 /* HIP-event timing of the MU kernels on the streams they are launched on (bench.py's roofline leg).
  * After a sweep with profiling enabled: names[i] / total_ms[i] / launches[i] / flops[i] for i < *count:

@@ -100,6 +100,25 @@ function frobenius(c::Context, W::Matrix{Float32}, H::Matrix{Float32})
 	return out[]
 end
 
+"robustkmeans(X, k, repeats) (src/NMFkCluster.jl:172-246) on the GPU; X: d x n, columns = samples"
+function robustkmeans(c::Context, X::Matrix{Float32}, k::Integer, repeats::Integer=1000; maxiter::Integer=1000,
+		tol::Number=1e-32, seed::Integer=0, compute_silhouettes_flag::Bool=false)
+	d, n = size(X)
+	assignments = Vector{Int32}(undef, n); centers = Matrix{Float32}(undef, d, k); costs = Vector{Float32}(undef, n)
+	counts = Vector{Int32}(undef, k); totalcost = Ref{Float64}(0)
+	best = Ref{Int32}(0); iters = Ref{Int32}(0); nclusters = Ref{Int32}(0)
+	sil = compute_silhouettes_flag ? Vector{Float32}(undef, n) : Float32[]
+	GC.@preserve X sil check(ccall((:nmfk_robustkmeans, libnmfk), Cint,
+		(Ptr{Cvoid}, Cint, Int64, Ptr{Float32}, Cint, Cint, Cint, Cdouble, UInt64, Ptr{Int32}, Ptr{Float32}, Ptr{Float32},
+		 Ptr{Int32}, Ref{Float64}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ptr{Float64}, Ptr{Float32}),
+		c.h, d, n, X, k, repeats, maxiter, tol, UInt64(seed), assignments, centers, costs, counts, totalcost, best, iters,
+		nclusters, C_NULL, compute_silhouettes_flag ? pointer(sil) : C_NULL))
+	nclusters[] < k && @warn("Robust k-means analysis could not find $k clusters! Only $(nclusters[]) clusters were found.")
+	res = (assignments=Int.(assignments), centers=centers[:, 1:nclusters[]], costs=costs, counts=Int.(counts[1:nclusters[]]),
+		totalcost=totalcost[], iterations=Int(iters[]))
+	return compute_silhouettes_flag ? (res, sil) : res
+end
+
 "getk (src/NMFkPostprocess.jl:7-41)"
 function getk(nkrange, robustness, cutoff=0.5)
 	all(isnan.(robustness)) && return 0

@@ -9,6 +9,7 @@ from ._lib import (COMPUTE_F32, COMPUTE_F64, STOP_CONSISTENCY, STOP_MAXITER, STO
                    NMFkError, build, default_params, device_count, lib)
 from .execute import execute, execute_run, getk, input_checks, run_seed, signalorder
 from . import parallel
+from .cluster import robustkmeans, sortclustering
 
-__all__ = ["execute", "execute_run", "getk", "signalorder", "input_checks", "run_seed", "Context", "NMFkError",
+__all__ = ["robustkmeans", "sortclustering", "execute", "execute_run", "getk", "signalorder", "input_checks", "run_seed", "Context", "NMFkError",
            "build", "lib", "device_count", "default_params", "parallel"]

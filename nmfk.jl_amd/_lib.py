@@ -80,6 +80,8 @@ def lib():
     L.nmfk_silhouette.argtypes = [vp, C.c_int, C.c_int, C.c_int64, fp, ip, fp, fp]
     L.nmfk_set_weight.argtypes = [vp, fp, C.c_int64, C.c_int64]
     L.nmfk_cluster_stats.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int64, fp, fp, ip, fp, fp, fp, fp]
+    L.nmfk_robustkmeans.argtypes = [vp, C.c_int, C.c_int64, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64, ip, fp, fp,
+                                    ip, C.POINTER(C.c_double), ip, ip, ip, C.c_void_p, C.c_void_p]
     L.nmfk_frobenius.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_double)]
     L.nmfk_set_profiling.argtypes = [vp, C.c_int]
     L.nmfk_get_profile.argtypes = [vp, C.c_int, C.c_void_p, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double),
@@ -283,6 +285,26 @@ class Context:
         _check(lib().nmfk_cluster_stats(self._h, k, nsol, n, m, wst.ctypes.data, hst.ctypes.data, lab.ctypes.data,
                                         Wm.ctypes.data, Hm.ctypes.data, Wv.ctypes.data, Hv.ctypes.data))
         return Wm.T, Hm.T, Wv.T, Hv.T
+
+    def robustkmeans(self, X, k, repeats=1000, maxiter=1000, tol=1e-32, seed=0, compute_silhouettes_flag=False):
+        """nmfk_robustkmeans (Clus:172-246).  X: d x n, columns = samples.  Returns a dict (assignments 1-based, sorted
+        by decreasing cluster size) and, with compute_silhouettes_flag, the point silhouettes of the best run."""
+        Xf = np.asfortranarray(X, dtype=np.float32)
+        d, n = Xf.shape
+        assign, counts = np.empty(n, np.int32), np.empty(k, np.int32)
+        centers, costs = np.empty((d, k), np.float32, order="F"), np.empty(n, np.float32)
+        allc = np.empty(repeats, np.float64)
+        sil = np.empty(n, np.float32) if compute_silhouettes_flag else None
+        tc = C.c_double()
+        br, it, kf = C.c_int32(), C.c_int32(), C.c_int32()
+        I = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        F = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        _check(lib().nmfk_robustkmeans(self._h, d, n, F(Xf), int(k), int(repeats), int(maxiter), float(tol), C.c_uint64(seed),
+                                       I(assign), F(centers), F(costs), I(counts), C.byref(tc), C.byref(br), C.byref(it),
+                                       C.byref(kf), allc.ctypes.data, None if sil is None else sil.ctypes.data))
+        res = dict(assignments=assign, centers=centers[:, :kf.value], costs=costs, counts=counts[:kf.value], totalcost=tc.value,
+                   iterations=it.value, best_repeat=br.value, all_costs=allc, nclusters=kf.value)
+        return (res, sil) if compute_silhouettes_flag else res
 
     def frobenius(self, W, H):
         """normnan(X - W*H) (Help:226-228)."""

@@ -1,0 +1,97 @@
+"""Host side of `NMFk.robustkmeans` (src/NMFkCluster.jl:138-246): the repeats run on the GPU
+(nmfk_robustkmeans), the selection over a range of k and the result cache stay on the host.
+
+Differences from the reference, all stated: the random draws come from the library's counter-based generator (Julia's
+stream is not reproducible), the silhouettes are only computed for the winning repeat (the reference computes them for
+every repeat and keeps the winner's: same result), and the cache payload is .npz instead of .jld."""
+import os
+import warnings
+
+import numpy as np
+
+from . import _lib
+
+
+def _context(ctx, device):
+    if ctx is not None:
+        return ctx
+    from .execute import _context as ec
+
+    return ec(device)
+
+
+def robustkmeans(X, krange, repeats=1000, *, best_method="worst_cliff", maxiter=1000, tol=1e-32, resultdir=".",
+                 casefilename="assignments", load=False, save=False, compute_silhouettes_flag=False, seed=0, ctx=None,
+                 device=None):
+    """robustkmeans(X, k::Integer, repeats) -> result dict [, silhouettes]   (Clus:172-246)
+    robustkmeans(X, krange, repeats) -> result dict of the selected k            (Clus:138-170), None when
+    krange[1] >= size(X, 2).  X: d x n, columns = samples; assignments are 1-based and sorted by cluster size."""
+    X = np.asarray(X)
+    if isinstance(krange, (int, np.integer)):
+        return _robust_k(X, int(krange), int(repeats), maxiter, tol, resultdir, casefilename, load, save,
+                         compute_silhouettes_flag, seed, _context(ctx, device))
+    ks = [int(k) for k in krange]
+    if best_method not in ("worst_cliff", "worst_cluster_cliff"):
+        raise ValueError("Unknown method: best_method must be :worst_cliff or :worst_cluster_cliff")
+    if ks[0] >= X.shape[1]:  # Clus:139-142
+        return None
+    c = _context(ctx, device)
+    res, worst, cworst = [], [], []
+    for k in ks:
+        if k >= X.shape[1]:  # Clus:149-152
+            res.append(None)
+            worst.append(np.nan)
+            cworst.append(np.nan)
+            continue
+        r, sil = _robust_k(X, k, int(repeats), maxiter, tol, resultdir, casefilename, load, save, True, seed, c)
+        a = r["assignments"]
+        first = list(dict.fromkeys(a.tolist()))
+        r.update(silhouettes=sil, mean_silhouette=float(np.mean(sil)), worst_silhouette=float(np.min(sil)),
+                 cluster_silhouettes=[float(np.mean(sil[a == j])) for j in first])
+        res.append(r)
+        worst.append(r["worst_silhouette"])
+        cworst.append(min(r["cluster_silhouettes"]))
+    v = worst if best_method == "worst_cliff" else cworst
+    drops = [v[i] - v[i + 1] for i in range(len(ks) - 1)]
+    ki = int(np.argmax(drops)) + 1  # Clus:160-162: findmax(...)[2] + 1
+    out = res[ki]
+    out["k"] = ks[ki]
+    return out
+
+
+def _robust_k(X, k, repeats, maxiter, tol, resultdir, casefilename, load, save, sil_flag, seed, ctx):
+    fn = os.path.join(resultdir, f"{casefilename}-{k}-{'_'.join(str(v) for v in X.shape)}-{repeats}.npz")  # Clus:174,237
+    if load and casefilename != "":
+        if os.path.isfile(fn):
+            with np.load(fn) as z:
+                if "assignments" in z and (not sil_flag or "best_silhouettes" in z):
+                    res = {key: z[key] for key in z.files if key != "best_silhouettes"}
+                    for key in ("totalcost", "iterations", "best_repeat", "nclusters"):
+                        if key in res:
+                            res[key] = res[key].item()
+                    return (res, z["best_silhouettes"]) if sil_flag else res
+            warnings.warn(f"Failed to load robust k-means results from '{fn}'; Robust k-means analysis will be executed ...")
+    out = ctx.robustkmeans(X, k, repeats, maxiter=maxiter, tol=tol, seed=seed, compute_silhouettes_flag=sil_flag)
+    res, sil = out if sil_flag else (out, None)
+    if res["nclusters"] < k:  # Clus:232-234
+        warnings.warn(f"Robust k-means analysis could not find {k} clusters! Only {res['nclusters']} clusters were found.")
+    if save and casefilename != "":
+        os.makedirs(resultdir, exist_ok=True)
+        payload = dict(res)
+        if sil_flag:
+            payload["best_silhouettes"] = sil
+        np.savez(fn, **payload)
+    return (res, sil) if sil_flag else res
+
+
+def sortclustering(c, rev=True):
+    """sortclustering(c::AbstractVector) (Clus:248-262): labels renumbered by decreasing (rev) cluster size, ties in
+    order of first appearance."""
+    c = np.asarray(c)
+    first = list(dict.fromkeys(c.tolist()))
+    counts = [int(np.sum(c == a)) for a in first]
+    order = sorted(range(len(first)), key=lambda i: -counts[i] if rev else counts[i])
+    out = np.empty(len(c), dtype=np.int64)
+    for new, i in enumerate(order):
+        out[c == first[i]] = new + 1
+    return out

@@ -398,6 +398,88 @@ NMFK_EXPORT int nmfk_fill_uniform(nmfk_ctx *ctx, uint64_t seed, uint64_t offset,
   return NMFK_OK;
 }
 
+NMFK_EXPORT int nmfk_robustkmeans(nmfk_ctx *ctx, int d, int64_t n64, const float *X, int k, int repeats, int maxiter,
+                                  double tol, uint64_t seed, int32_t *assignments, float *centers, float *costs,
+                                  int32_t *counts, double *totalcost, int32_t *best_repeat, int32_t *iterations,
+                                  int32_t *nclusters, double *all_costs, float *silhouettes) {
+  if (!ctx) return NMFK_ERR_BAD_ARG;
+  if (!X || !assignments || !centers || !costs || !counts || !totalcost) return fail(NMFK_ERR_BAD_ARG, "null argument");
+  if (d <= 0 || n64 <= 0 || n64 > (1 << 27) || repeats <= 0 || maxiter < 0) return fail(NMFK_ERR_BAD_ARG, "bad dimensions");
+  const int n = (int)n64;
+  if (k < 1 || k > n) return fail(NMFK_ERR_BAD_ARG, "k must be from 1:n");  // Clustering.kmeans argument check
+  if (k > NMFK_MAX_K || (size_t)d * k > 8192) return fail(NMFK_ERR_BAD_ARG, "k <= 64 and d*k <= 8192 supported");
+  HIPCHECK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  Bump B;
+  const size_t oX = B.take(sizeof(float) * (size_t)d * n), oZ = B.take(sizeof(float) * (size_t)d * n);
+  const size_t oA = B.take(sizeof(int32_t) * (size_t)repeats * n), oC = B.take(sizeof(float) * (size_t)repeats * n);
+  const size_t oW = B.take(sizeof(float) * (size_t)repeats * n), oCe = B.take(sizeof(float) * (size_t)repeats * d * k);
+  const size_t oCn = B.take(sizeof(int32_t) * (size_t)repeats * k), oT = B.take(sizeof(double) * repeats);
+  const size_t oI = B.take(sizeof(int32_t) * repeats), oV = B.take(sizeof(int32_t) * repeats);
+  const size_t oSa = B.take(sizeof(int32_t) * (size_t)n), oSc = B.take(sizeof(int32_t) * k), oS = B.take(sizeof(float) * (size_t)n);
+  if (ctx->scratch.ensure(B.off)) return fail(NMFK_ERR_HIP, "out of device memory (k-means workspace)");
+  char *S = ctx->scratch.p;
+  HIPCHECK(hipMemcpyAsync(S + oX, X, sizeof(float) * (size_t)d * n, hipMemcpyDefault, st));
+  nmfk_launch_kmeans((const float *)(S + oX), d, n, k, repeats, maxiter, tol, seed, (int32_t *)(S + oA), (float *)(S + oC),
+                     (float *)(S + oW), (float *)(S + oCe), (int32_t *)(S + oCn), (double *)(S + oT), (int32_t *)(S + oI),
+                     (int32_t *)(S + oV), st);
+  HIPCHECK(hipGetLastError());
+  std::vector<double> tot(repeats);
+  std::vector<int32_t> its(repeats);
+  HIPCHECK(hipMemcpyAsync(tot.data(), S + oT, sizeof(double) * repeats, hipMemcpyDeviceToHost, st));
+  HIPCHECK(hipMemcpyAsync(its.data(), S + oI, sizeof(int32_t) * repeats, hipMemcpyDeviceToHost, st));
+  HIPCHECK(hipStreamSynchronize(st));
+  int best = 0;
+  for (int r = 1; r < repeats; ++r)
+    if (tot[r] < tot[best]) best = r;  // Clus:227: strict <, the first of equal costs wins
+  if (all_costs) memcpy(all_costs, tot.data(), sizeof(double) * repeats);
+  std::vector<int32_t> a(n), cn(k);
+  std::vector<float> ce((size_t)d * k);
+  HIPCHECK(hipMemcpyAsync(a.data(), S + oA + sizeof(int32_t) * (size_t)best * n, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+  HIPCHECK(hipMemcpyAsync(costs, S + oC + sizeof(float) * (size_t)best * n, sizeof(float) * (size_t)n, hipMemcpyDefault, st));
+  HIPCHECK(hipMemcpyAsync(ce.data(), S + oCe + sizeof(float) * (size_t)best * d * k, sizeof(float) * (size_t)d * k, hipMemcpyDeviceToHost, st));
+  HIPCHECK(hipMemcpyAsync(cn.data(), S + oCn + sizeof(int32_t) * (size_t)best * k, sizeof(int32_t) * k, hipMemcpyDeviceToHost, st));
+  HIPCHECK(hipStreamSynchronize(st));
+  // sortclustering (Clus:264-292): clusters in order of first appearance, then stably by decreasing count
+  std::vector<int> first, newlab(k, 0);
+  {
+    std::vector<char> seen(k, 0);
+    for (int j = 0; j < n; ++j)
+      if (!seen[a[j]]) {
+        seen[a[j]] = 1;
+        first.push_back(a[j]);
+      }
+    std::stable_sort(first.begin(), first.end(), [&](int x, int y) { return cn[x] > cn[y]; });
+    for (size_t q = 0; q < first.size(); ++q) newlab[first[q]] = (int)q + 1;
+  }
+  const int kf = (int)first.size();
+  for (int j = 0; j < n; ++j) assignments[j] = newlab[a[j]];
+  for (int c = 0; c < k; ++c) {
+    counts[c] = c < kf ? cn[first[c]] : 0;
+    for (int i = 0; i < d; ++i) centers[i + (size_t)c * d] = c < kf ? ce[i + (size_t)first[c] * d] : 0.f;
+  }
+  *totalcost = tot[best];
+  if (best_repeat) *best_repeat = best;
+  if (iterations) *iterations = its[best];
+  if (nclusters) *nclusters = kf;
+  if (silhouettes) {
+    int amax = 0;
+    for (int j = 0; j < n; ++j) amax = std::max(amax, (int)assignments[j]);
+    if (amax > 1) {  // Clus:211-218
+      HIPCHECK(hipMemcpyAsync(S + oSa, assignments, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+      HIPCHECK(hipMemcpyAsync(S + oSc, counts, sizeof(int32_t) * k, hipMemcpyHostToDevice, st));
+      nmfk_launch_point_silhouettes((const float *)(S + oX), d, n, (const int32_t *)(S + oSa), (const int32_t *)(S + oSc), k,
+                                    (float *)(S + oZ), (float *)(S + oS), st);
+      HIPCHECK(hipGetLastError());
+      HIPCHECK(hipMemcpyAsync(silhouettes, S + oS, sizeof(float) * (size_t)n, hipMemcpyDefault, st));
+      HIPCHECK(hipStreamSynchronize(st));
+    } else {
+      for (int j = 0; j < n; ++j) silhouettes[j] = 0.f;
+    }
+  }
+  return NMFK_OK;
+}
+
 NMFK_EXPORT int nmfk_set_profiling(nmfk_ctx *ctx, int enabled) {
   if (!ctx) return fail(NMFK_ERR_BAD_ARG, "ctx is null");
   ctx->profiling = enabled != 0;

@@ -223,6 +223,11 @@ static inline int nmfk_padded_k(int k) {
                                 int u0, int cnt, hipStream_t s);                                                  \
   void nmfk_launch_finish_##SUF(const NmfkFinishArgs &a, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f32)
+void nmfk_launch_kmeans(const float *X, int d, int n, int k, int repeats, int maxiter, double tol, uint64_t seed,
+                        int32_t *assign, float *costs, float *work, float *centers, int32_t *counts, double *total,
+                        int32_t *iters, int32_t *conv, hipStream_t s);
+void nmfk_launch_point_silhouettes(const float *X, int d, int n, const int32_t *assign, const int32_t *cnt, int k, float *Z,
+                                   float *sil, hipStream_t s);
 void nmfk_launch_step_mfma_wide_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt,
                                     hipStream_t s);
 int nmfk_mfma_wide_lane_tile(int wsplit);

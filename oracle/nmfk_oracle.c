@@ -516,3 +516,267 @@ EXPORT void nmfk_or_cluster_stats(const double *Ws, const double *Hs, const int3
     }
   }
 }
+
+/* ------------------------------------------------------------------------------------------------------
+ * robustkmeans(X, k, repeats)  src/NMFkCluster.jl:172-246  
+ *
+ * The arithmetic lives in Clustering.jl (compat 0.14-0.15, Project.toml:55; un-vendored): kmeans(X, k; maxiter, tol,
+ * distance=CosineDist()) = k-means++ seeding (initseeds(:kmpp, X, k): squared Euclidean, the `distance` keyword is
+ * not forwarded to the seeding) + Lloyd iterations of _kmeans!: update_centers! (running sum of the member columns in
+ * column order, then / count; only clusters whose membership changed), repick_unused_centers (empty clusters: a
+ * column drawn with probability ~ its cost, k-means++ like), pairwise(distance, centers, X), update_assignments!
+ * (first minimum), objective = sum(costs), converged when |change| < tol.  Restated from the published algorithm;
+ * PARITY UNPINNED beyond the reference's own test (test/test_cluster_unit.jl:6-18: valid assignments), because
+ * Julia's RNG stream cannot be reproduced: the draws here come from the repo's counter-based generator
+ * (u(seed + repeat, draw index)), wsample = StatsBase.sample(Weights): t = u * sum(w), first i with cumsum >= t.
+ * robustkmeans keeps the repeat with the lowest total cost (first wins ties, Clus:227) and relabels the clusters by
+ * decreasing size (sortclustering, Clus:264-292).  Distances, centres and costs in T; cumulative sums and the
+ * objective in double.
+ * X: d x n column-major (columns = samples).
+ * ------------------------------------------------------------------------------------------------------ */
+#define DEF_KMEANS(SUF, T, SQRT)                                                                                        \
+  static inline T sqeuclid_##SUF(const T *a, const T *b, int d) {                                                       \
+    T s = 0;                                                                                                            \
+    for (int i = 0; i < d; i++) {                                                                                       \
+      T v = a[i] - b[i];                                                                                                \
+      s += v * v;                                                                                                       \
+    }                                                                                                                   \
+    return s;                                                                                                           \
+  }                                                                                                                     \
+  static int wsample_##SUF(const T *w, int n, double u) {                                                               \
+    double tot = 0;                                                                                                     \
+    for (int i = 0; i < n; i++) tot += (double)w[i];                                                                    \
+    const double t = u * tot;                                                                                           \
+    int i = 0;                                                                                                          \
+    double cw = (double)w[0];                                                                                           \
+    while (cw < t && i < n - 1) {                                                                                       \
+      i++;                                                                                                              \
+      cw += (double)w[i];                                                                                               \
+    }                                                                                                                   \
+    return i;                                                                                                           \
+  }                                                                                                                     \
+  /* one k-means run; returns the number of iterations */                                                               \
+  EXPORT int nmfk_or_kmeans_##SUF(const T *X, int d, int n, int k, int maxiter, double tol, uint64_t seed,             \
+                                  int32_t *assign, T *centers, T *costs, int32_t *counts, double *totalcost,            \
+                                  int32_t *converged_out) {                                                             \
+    uint64_t draw = 0;                                                                                                  \
+    T *mc = (T *)malloc(sizeof(T) * (size_t)n), *tc = (T *)malloc(sizeof(T) * (size_t)n);                               \
+    uint8_t *upd = (uint8_t *)malloc((size_t)k);                                                                        \
+    int32_t *unused = (int32_t *)malloc(sizeof(int32_t) * (size_t)k), *wc = (int32_t *)malloc(sizeof(int32_t) * (size_t)k); \
+    int nun = 0;                                                                                                        \
+    /* k-means++ seeding, squared Euclidean */                                                                          \
+    int p = (int)(nmfk_uniform(seed, draw++) * (double)n);                                                              \
+    if (p > n - 1) p = n - 1;                                                                                           \
+    for (int i = 0; i < d; i++) centers[i] = X[i + (size_t)p * d];                                                      \
+    if (k > 1) {                                                                                                        \
+      for (int j = 0; j < n; j++) mc[j] = sqeuclid_##SUF(X + (size_t)j * d, X + (size_t)p * d, d);                      \
+      mc[p] = 0;                                                                                                        \
+      for (int c = 1; c < k; c++) {                                                                                     \
+        p = wsample_##SUF(mc, n, nmfk_uniform(seed, draw++));                                                           \
+        for (int i = 0; i < d; i++) centers[i + (size_t)c * d] = X[i + (size_t)p * d];                                  \
+        for (int j = 0; j < n; j++) {                                                                                   \
+          const T v = sqeuclid_##SUF(X + (size_t)j * d, X + (size_t)p * d, d);                                          \
+          if (v < mc[j]) mc[j] = v;                                                                                     \
+        }                                                                                                               \
+        mc[p] = 0;                                                                                                      \
+      }                                                                                                                 \
+    }                                                                                                                   \
+    int it = 0, converged = 0;                                                                                          \
+    double objv = 0, prev = 0;                                                                                          \
+    for (int pass = 0;; pass++) { /* pass 0 = initial assignment */                                                     \
+      if (pass > 0) {                                                                                                   \
+        it++;                                                                                                           \
+        for (int c = 0; c < k; c++)                                                                                     \
+          if (upd[c]) wc[c] = 0;                                                                                        \
+        for (int j = 0; j < n; j++) { /* update_centers! */                                                             \
+          const int c = assign[j];                                                                                      \
+          if (!upd[c]) continue;                                                                                        \
+          if (wc[c] > 0)                                                                                                \
+            for (int i = 0; i < d; i++) centers[i + (size_t)c * d] += X[i + (size_t)j * d];                             \
+          else                                                                                                          \
+            for (int i = 0; i < d; i++) centers[i + (size_t)c * d] = X[i + (size_t)j * d];                              \
+          wc[c]++;                                                                                                      \
+        }                                                                                                               \
+        for (int c = 0; c < k; c++)                                                                                     \
+          if (upd[c])                                                                                                   \
+            for (int i = 0; i < d; i++) centers[i + (size_t)c * d] /= (T)wc[c];                                         \
+        if (nun > 0) { /* repick_unused_centers */                                                                      \
+          for (int j = 0; j < n; j++) tc[j] = costs[j];                                                                 \
+          for (int q = 0; q < nun; q++) {                                                                               \
+            const int c = unused[q];                                                                                    \
+            const int j = wsample_##SUF(tc, n, nmfk_uniform(seed, draw++));                                             \
+            tc[j] = 0;                                                                                                  \
+            for (int i = 0; i < d; i++) centers[i + (size_t)c * d] = X[i + (size_t)j * d];                              \
+            for (int jj = 0; jj < n; jj++) {                                                                            \
+              const T v = cosine_##SUF(X + (size_t)j * d, 1, X + (size_t)jj * d, 1, d);                                 \
+              if (v < tc[jj]) tc[jj] = v;                                                                               \
+            }                                                                                                           \
+          }                                                                                                             \
+        }                                                                                                               \
+      }                                                                                                                 \
+      /* update_assignments! */                                                                                         \
+      for (int c = 0; c < k; c++) {                                                                                     \
+        counts[c] = 0;                                                                                                  \
+        upd[c] = (pass == 0);                                                                                           \
+      }                                                                                                                 \
+      nun = 0;                                                                                                          \
+      for (int j = 0; j < n; j++) {                                                                                     \
+        int a = 0;                                                                                                      \
+        T cm = cosine_##SUF(centers, 1, X + (size_t)j * d, 1, d);                                                       \
+        for (int c = 1; c < k; c++) {                                                                                   \
+          const T ci = cosine_##SUF(centers + (size_t)c * d, 1, X + (size_t)j * d, 1, d);                               \
+          if (ci < cm) {                                                                                                \
+            a = c;                                                                                                      \
+            cm = ci;                                                                                                    \
+          }                                                                                                             \
+        }                                                                                                               \
+        if (pass == 0)                                                                                                  \
+          assign[j] = a;                                                                                                \
+        else if (assign[j] != a) {                                                                                      \
+          upd[a] = 1;                                                                                                   \
+          upd[assign[j]] = 1;                                                                                           \
+          assign[j] = a;                                                                                                \
+        }                                                                                                               \
+        costs[j] = cm;                                                                                                  \
+        counts[a]++;                                                                                                    \
+      }                                                                                                                 \
+      for (int c = 0; c < k; c++)                                                                                       \
+        if (counts[c] == 0) {                                                                                           \
+          unused[nun++] = c;                                                                                            \
+          upd[c] = 0;                                                                                                   \
+        }                                                                                                               \
+      prev = objv;                                                                                                      \
+      objv = 0;                                                                                                         \
+      for (int j = 0; j < n; j++) objv += (double)costs[j];                                                             \
+      if (pass > 0) {                                                                                                   \
+        const double ch = objv - prev;                                                                                  \
+        if (!(ch > tol) && (k == 1 || fabs(ch) < tol)) converged = 1;                                                   \
+      }                                                                                                                 \
+      if (converged || it >= maxiter) break;                                                                            \
+      /* (the reference's to_update[unused] .= true after the repick only selects which rows of the distance matrix   \
+       * are recomputed; all of them are recomputed here, same values) */                                               \
+    }                                                                                                                   \
+    *totalcost = objv;                                                                                                  \
+    *converged_out = converged;                                                                                         \
+    free(mc);                                                                                                           \
+    free(tc);                                                                                                           \
+    free(upd);                                                                                                          \
+    free(unused);                                                                                                       \
+    free(wc);                                                                                                           \
+    return it;                                                                                                          \
+  }
+DEF_KMEANS(f32, float, sqrtf)
+DEF_KMEANS(f64, double, sqrt)
+
+/* sortclustering(c::KmeansResult)  Clus:264-292: clusters relabelled 1..k' by decreasing size (stable: ties keep the
+ * order of first appearance).  assign: 0-based in, 1-based out; perm[new] = old cluster index; returns k'. */
+EXPORT int nmfk_or_sortclustering(int32_t *assign, int n, const int32_t *counts, int k, int32_t *perm) {
+  int32_t *first = (int32_t *)malloc(sizeof(int32_t) * (size_t)k), *seen = (int32_t *)calloc((size_t)k, sizeof(int32_t));
+  int nj = 0;
+  for (int j = 0; j < n; j++)
+    if (!seen[assign[j]]) {
+      seen[assign[j]] = 1;
+      first[nj++] = assign[j];
+    }
+  /* stable insertion sort of the appearance list by count, descending */
+  for (int a = 1; a < nj; a++) {
+    const int32_t v = first[a];
+    int b = a - 1;
+    while (b >= 0 && counts[first[b]] < counts[v]) {
+      first[b + 1] = first[b];
+      b--;
+    }
+    first[b + 1] = v;
+  }
+  for (int c = 0; c < k; c++) seen[c] = 0;
+  for (int a = 0; a < nj; a++) {
+    seen[first[a]] = a + 1;
+    perm[a] = first[a];
+  }
+  for (int j = 0; j < n; j++) assign[j] = seen[assign[j]];
+  free(first);
+  free(seen);
+  return nj;
+}
+
+/* robustkmeans(X, k, repeats)  Clus:172-246 (without the JLD cache): best of `repeats` runs, sorted.
+ * assign (n, 1-based), centers (d x k, sorted order), counts (k, sorted), costs (n).  Returns k' (clusters found). */
+#define DEF_ROBUST(SUF, T)                                                                                             \
+  EXPORT int nmfk_or_robustkmeans_##SUF(const T *X, int d, int n, int k, int repeats, int maxiter, double tol,         \
+                                        uint64_t seed, int32_t *assign, T *centers, T *costs, int32_t *counts,         \
+                                        double *totalcost, int32_t *best_repeat, int32_t *iterations,                  \
+                                        double *all_costs /* repeats or NULL */) {                                     \
+    int32_t *a = (int32_t *)malloc(sizeof(int32_t) * (size_t)n), *cn = (int32_t *)malloc(sizeof(int32_t) * (size_t)k);  \
+    T *ce = (T *)malloc(sizeof(T) * (size_t)d * k), *co = (T *)malloc(sizeof(T) * (size_t)n);                           \
+    double best = 0;                                                                                                   \
+    for (int r = 0; r < repeats; r++) {                                                                                \
+      double tc;                                                                                                       \
+      int32_t conv;                                                                                                    \
+      const int it = nmfk_or_kmeans_##SUF(X, d, n, k, maxiter, tol, seed + (uint64_t)r, a, ce, co, cn, &tc, &conv);     \
+      if (all_costs) all_costs[r] = tc;                                                                                \
+      if (r == 0 || tc < best) { /* Clus:227 */                                                                        \
+        best = tc;                                                                                                     \
+        *best_repeat = r;                                                                                              \
+        *iterations = it;                                                                                              \
+        memcpy(assign, a, sizeof(int32_t) * (size_t)n);                                                                \
+        memcpy(centers, ce, sizeof(T) * (size_t)d * k);                                                                \
+        memcpy(costs, co, sizeof(T) * (size_t)n);                                                                      \
+        memcpy(counts, cn, sizeof(int32_t) * (size_t)k);                                                               \
+      }                                                                                                                \
+    }                                                                                                                  \
+    *totalcost = best;                                                                                                 \
+    int32_t *perm = (int32_t *)malloc(sizeof(int32_t) * (size_t)k);                                                    \
+    const int kf = nmfk_or_sortclustering(assign, n, counts, k, perm);                                                 \
+    memcpy(ce, centers, sizeof(T) * (size_t)d * k);                                                                    \
+    memcpy(cn, counts, sizeof(int32_t) * (size_t)k);                                                                   \
+    for (int c = 0; c < k; c++) {                                                                                      \
+      counts[c] = c < kf ? cn[perm[c]] : 0;                                                                            \
+      for (int i = 0; i < d; i++) centers[i + (size_t)c * d] = c < kf ? ce[i + (size_t)perm[c] * d] : (T)0;            \
+    }                                                                                                                  \
+    free(a);                                                                                                           \
+    free(cn);                                                                                                          \
+    free(ce);                                                                                                          \
+    free(co);                                                                                                          \
+    free(perm);                                                                                                        \
+    return kf;                                                                                                         \
+  }
+DEF_ROBUST(f32, float)
+DEF_ROBUST(f64, double)
+
+/* Clustering.silhouettes(assignments, counts, dists) with dists = pairwise(CosineDist(), zerostoepsilon(X); dims=2)
+ * (Clus:204-213).  assign 1-based; e2 = eps(T)^2.  Point i: a = mean distance to the OTHER members of its cluster,
+ * b = min over other clusters of the mean distance; s = (b - a) / max(a, b); singleton cluster: 0. */
+#define DEF_SIL(SUF, T, E2)                                                                                            \
+  EXPORT void nmfk_or_point_silhouettes_##SUF(const T *X, int d, int n, const int32_t *assign, int k, T *sil) {         \
+    T *Z = (T *)malloc(sizeof(T) * (size_t)d * n);                                                                     \
+    for (size_t i = 0; i < (size_t)d * n; i++) Z[i] = X[i] < (T)(E2) ? (T)(E2) : X[i];                                 \
+    int32_t *cnt = (int32_t *)calloc((size_t)k, sizeof(int32_t));                                                      \
+    for (int j = 0; j < n; j++) cnt[assign[j] - 1]++;                                                                  \
+    T *s = (T *)malloc(sizeof(T) * (size_t)k);                                                                         \
+    for (int i = 0; i < n; i++) {                                                                                      \
+      for (int c = 0; c < k; c++) s[c] = 0;                                                                            \
+      for (int j = 0; j < n; j++)                                                                                      \
+        if (j != i) s[assign[j] - 1] += cosine_##SUF(Z + (size_t)i * d, 1, Z + (size_t)j * d, 1, d);                   \
+      const int ci = assign[i] - 1;                                                                                    \
+      if (cnt[ci] <= 1) {                                                                                              \
+        sil[i] = 0;                                                                                                    \
+        continue;                                                                                                      \
+      }                                                                                                                \
+      const T a = s[ci] / (T)(cnt[ci] - 1);                                                                            \
+      T b = 0;                                                                                                         \
+      int have = 0;                                                                                                    \
+      for (int c = 0; c < k; c++) {                                                                                    \
+        if (c == ci || cnt[c] == 0) continue;                                                                          \
+        const T v = s[c] / (T)cnt[c];                                                                                  \
+        if (!have || v < b) b = v;                                                                                     \
+        have = 1;                                                                                                      \
+      }                                                                                                                \
+      const T mx = a > b ? a : b;                                                                                      \
+      sil[i] = have ? (b - a) / mx : 0;                                                                                \
+    }                                                                                                                  \
+    free(Z);                                                                                                           \
+    free(cnt);                                                                                                         \
+    free(s);                                                                                                           \
+  }
+DEF_SIL(f32, float, 1.4210854715202004e-14)
+DEF_SIL(f64, double, 4.930380657631324e-32)

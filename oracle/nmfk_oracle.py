@@ -71,6 +71,14 @@ def lib():
             getattr(L, "nmfk_or_finalize_" + suf).restype = None
         L.nmfk_or_cluster_stats.argtypes = [dp, dp, ip, C.c_int64, C.c_int64, C.c_int64, C.c_int64, dp, dp, dp, dp]
         L.nmfk_or_cluster_stats.restype = None
+        for suf, ct in (("f32", C.c_float), ("f64", C.c_double)):
+            tp = C.POINTER(ct)
+            getattr(L, "nmfk_or_kmeans_" + suf).argtypes = [tp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64,
+                                                            ip, tp, tp, ip, dp, ip]
+            getattr(L, "nmfk_or_robustkmeans_" + suf).argtypes = [tp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                                  C.c_double, C.c_uint64, ip, tp, tp, ip, dp, ip, ip, dp]
+            getattr(L, "nmfk_or_point_silhouettes_" + suf).argtypes = [tp, C.c_int, C.c_int, ip, C.c_int, tp]
+            getattr(L, "nmfk_or_point_silhouettes_" + suf).restype = None
         _LIB = L
     return _LIB
 
@@ -412,3 +420,86 @@ def run_seed(seed, nk, run):
     """Seed of restart `run` (0-based) for rank nk: the same rule the product's host code uses, so oracle and
     GPU start from identical factors.  (Reference: seed = kwseed + i per run, Exec:536.)"""
     return (int(seed) * 1000003 + nk * 1009 + run + 1) & 0x7FFFFFFFFFFFFFFF
+
+
+# ---------------------------------------------------------------------------------------------------------
+# robustkmeans (Clus:138-246; SURVEY 8f row 4).  X: d x n, columns = samples (as in the reference).
+# ---------------------------------------------------------------------------------------------------------
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def kmeans(X, k, maxiter=1000, tol=1e-32, seed=0):
+    """One Clustering.kmeans(X, k; distance=CosineDist()) run (restated, see nmfk_oracle.c).  0-based assignments."""
+    X = np.asarray(X)
+    npT, cT, suf = _T(tbits_of(X))
+    Xf = np.asfortranarray(X, dtype=npT)
+    d, n = Xf.shape
+    assign, counts = np.zeros(n, np.int32), np.zeros(k, np.int32)
+    centers, costs = np.zeros((d, k), npT, order="F"), np.zeros(n, npT)
+    tc, conv = C.c_double(0), C.c_int32(0)
+    tp = C.POINTER(cT)
+    it = getattr(lib(), "nmfk_or_kmeans_" + suf)(Xf.ctypes.data_as(tp), d, n, k, maxiter, tol, C.c_uint64(seed), _ip(assign),
+                                                 centers.ctypes.data_as(tp), costs.ctypes.data_as(tp), _ip(counts),
+                                                 C.byref(tc), C.byref(conv))
+    return dict(assignments=assign, centers=centers, costs=costs, counts=counts, totalcost=tc.value, iterations=it,
+                converged=bool(conv.value))
+
+
+def robustkmeans_k(X, k, repeats=1000, maxiter=1000, tol=1e-32, seed=0, compute_silhouettes_flag=False):
+    """robustkmeans(X, k::Integer, repeats) (Clus:172-246 without the JLD cache): best of `repeats` by total cost,
+    clusters relabelled by decreasing size.  Returns a dict (assignments 1-based) [, silhouettes of the best run]."""
+    X = np.asarray(X)
+    npT, cT, suf = _T(tbits_of(X))
+    Xf = np.asfortranarray(X, dtype=npT)
+    d, n = Xf.shape
+    assign, counts = np.zeros(n, np.int32), np.zeros(k, np.int32)
+    centers, costs = np.zeros((d, k), npT, order="F"), np.zeros(n, npT)
+    allc = np.zeros(repeats, np.float64)
+    tc, br, it = C.c_double(0), C.c_int32(0), C.c_int32(0)
+    tp = C.POINTER(cT)
+    kf = getattr(lib(), "nmfk_or_robustkmeans_" + suf)(Xf.ctypes.data_as(tp), d, n, k, repeats, maxiter, tol, C.c_uint64(seed),
+                                                       _ip(assign), centers.ctypes.data_as(tp), costs.ctypes.data_as(tp),
+                                                       _ip(counts), C.byref(tc), C.byref(br), C.byref(it), _dp(allc))
+    res = dict(assignments=assign, centers=centers[:, :kf], costs=costs, counts=counts[:kf], totalcost=tc.value,
+               iterations=it.value, best_repeat=br.value, all_costs=allc, nclusters=kf)
+    if not compute_silhouettes_flag:
+        return res
+    if assign.max() > 1:  # Clus:211-218
+        sil = np.zeros(n, npT)
+        getattr(lib(), "nmfk_or_point_silhouettes_" + suf)(Xf.ctypes.data_as(tp), d, n, _ip(assign), k, sil.ctypes.data_as(tp))
+    else:
+        sil = np.zeros(n, npT)
+    return res, sil
+
+
+def robustkmeans(X, krange, repeats=1000, best_method="worst_cliff", **kw):
+    """robustkmeans(X, krange, repeats) (Clus:138-170): the k after the largest drop of the worst point silhouette
+    (:worst_cliff) or of the worst cluster-mean silhouette (:worst_cluster_cliff)."""
+    X = np.asarray(X)
+    krange = [int(k) for k in krange]
+    if krange[0] >= X.shape[1]:
+        return None
+    res, worst, cworst = [], [], []
+    for k in krange:
+        if k >= X.shape[1]:  # Clus:149-152 (`continue` leaves undefined entries in the reference)
+            res.append(None)
+            worst.append(np.nan)
+            cworst.append(np.nan)
+            continue
+        r, sil = robustkmeans_k(X, k, repeats, compute_silhouettes_flag=True, **kw)
+        r["silhouettes"] = sil
+        r["mean_silhouette"] = float(np.mean(sil))
+        r["worst_silhouette"] = float(np.min(sil))
+        a = r["assignments"]
+        first = list(dict.fromkeys(a.tolist()))
+        r["cluster_silhouettes"] = [float(np.mean(sil[a == j])) for j in first]
+        res.append(r)
+        worst.append(r["worst_silhouette"])
+        cworst.append(min(r["cluster_silhouettes"]))
+    v = worst if best_method == "worst_cliff" else cworst
+    if best_method not in ("worst_cliff", "worst_cluster_cliff"):
+        raise ValueError("Unknown method: best_method must be :worst_cliff or :worst_cluster_cliff")
+    drops = [v[i] - v[i + 1] for i in range(len(krange) - 1)]
+    ki = int(np.argmax(drops)) + 1  # findmax: first maximum
+    return res[ki], krange[ki], res

@@ -17,7 +17,7 @@ base = None
 for nr in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     c, chunks = N.parallel.plan_shards(ks, R, nr)  # [(kidx, restarts, owner)]
     times = []
-    for g in range(nr):
+    for g in range(1 if os.environ.get("RANK_SIM_FIRST") else nr):  # RANK_SIM_FIRST=1: rank 0's share only
         mine = [ch for ch in chunks if ch[2] == g]
         lks = [ks[q] for q, *_ in mine]
         sd = np.stack([seeds[q, rs + [rs[-1]] * (c - len(rs))] for q, rs, _ in mine])

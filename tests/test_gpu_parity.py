@@ -606,3 +606,78 @@ def test_sparse_rejects_what_it_cannot_do(NMFk, ctx):
     with pytest.raises(NMFk.NMFkError, match="dense path") as e:
         ctx.set_X_sparse(X)
     assert e.value.code == 6
+
+
+# ---------------------------------------------------------------------------------------------------------
+# robustkmeans (Clus:138-246): every repeat reproduces the oracle bit for bit
+# ---------------------------------------------------------------------------------------------------------
+def _kmeans_cases(oracle):
+    from test_oracle_units import _direction_clusters
+
+    rnd = lambda seed, d, n: np.asfortranarray(oracle.uniform_fill(seed, 0, d * n).reshape(n, d).T)
+    return [
+        ("planted 3 directions", _direction_clusters(oracle, 5, 40, 3, seed=7).astype(np.float32), 3, 40),
+        ("planted, k too large (re-seeded / small clusters)", _direction_clusters(oracle, 4, 30, 2, seed=8).astype(np.float32), 6, 40),
+        ("uniform noise, d=16", rnd(21, 16, 700).astype(np.float32), 7, 24),
+        ("uniform noise, d=3, more samples than threads", rnd(22, 3, 1500).astype(np.float32), 4, 16),
+        ("duplicates => empty clusters", np.asfortranarray(np.repeat(rnd(23, 4, 5), 20, axis=1).astype(np.float32)), 8, 24),
+        ("k = 1", rnd(24, 6, 50).astype(np.float32), 1, 3),
+    ]
+
+
+def test_robustkmeans_bit_exact_vs_oracle(NMFk, ctx, oracle):
+    for name, X, k, reps in _kmeans_cases(oracle):
+        ref, sil_ref = oracle.robustkmeans_k(X, k, reps, seed=77, compute_silhouettes_flag=True)
+        got, sil = ctx.robustkmeans(X, k, reps, seed=77, compute_silhouettes_flag=True)
+        assert np.array_equal(got["all_costs"], ref["all_costs"]), name  # every repeat, bit for bit
+        for key in ("assignments", "counts", "centers", "costs"):
+            assert np.array_equal(got[key], ref[key]), (name, key)
+        for key in ("totalcost", "iterations", "best_repeat", "nclusters"):
+            assert got[key] == ref[key], (name, key)
+        np.testing.assert_allclose(sil, sil_ref, atol=1e-6, err_msg=name)
+
+
+def test_robustkmeans_reference_test_vector_and_maxiter(NMFk, ctx, oracle):
+    X = np.array([[1.0, 1.1, 10.0, 10.1], [1.0, 0.9, 10.0, 9.9]], dtype=np.float32)  # test/test_cluster_unit.jl:6-18
+    r = NMFk.robustkmeans(X, 2, 5, maxiter=50, tol=1e-8, ctx=ctx)
+    assert len(r["assignments"]) == 4 and sorted(set(r["assignments"].tolist())) == [1, 2] and r["centers"].shape[1] == 2
+    ref = oracle.robustkmeans_k(X, 2, 5, maxiter=50, tol=1e-8)
+    assert np.array_equal(r["assignments"], ref["assignments"]) and r["totalcost"] == ref["totalcost"]
+    Xn = _kmeans_cases(oracle)[2][1]
+    for mi in (0, 1, 2):  # iteration cap
+        a, b = ctx.robustkmeans(Xn, 5, 6, maxiter=mi, seed=3), oracle.robustkmeans_k(Xn, 5, 6, maxiter=mi, seed=3)
+        assert a["iterations"] == b["iterations"] <= mi and np.array_equal(a["all_costs"], b["all_costs"])
+    with pytest.raises(NMFk.NMFkError):
+        ctx.robustkmeans(X, 5, 3)  # k > n (Clustering.kmeans: ArgumentError)
+
+
+def test_robustkmeans_krange_and_cache(NMFk, ctx, oracle, tmp_path):
+    from test_oracle_units import _direction_clusters
+
+    X = _direction_clusters(oracle, 5, 20, 3, seed=9).astype(np.float32)
+    got = NMFk.robustkmeans(X, [2, 3, 4, 5], 20, ctx=ctx, seed=5)
+    best, kbest, allr = oracle.robustkmeans(X, [2, 3, 4, 5], 20, seed=5)
+    assert got["k"] == kbest and np.array_equal(got["assignments"], best["assignments"])
+    assert abs(got["worst_silhouette"] - best["worst_silhouette"]) < 1e-6
+    assert NMFk.robustkmeans(X[:, :2], [2, 3], 5, ctx=ctx) is None
+    # result cache (Clus:173-199, 236-244; .npz payload)
+    r1, s1 = NMFk.robustkmeans(X, 3, 10, ctx=ctx, save=True, resultdir=str(tmp_path), casefilename="Hmatrix",
+                               compute_silhouettes_flag=True)
+    assert os.path.isfile(tmp_path / "Hmatrix-3-5_60-10.npz")
+    r2, s2 = NMFk.robustkmeans(X, 3, 10, ctx=ctx, load=True, seed=999, resultdir=str(tmp_path), casefilename="Hmatrix",
+                               compute_silhouettes_flag=True)
+    assert np.array_equal(r1["assignments"], r2["assignments"]) and np.array_equal(s1, s2) and r2["totalcost"] == r1["totalcost"]
+
+
+def test_robustkmeans_rows_of_W_at_bench_size(NMFk, ctx, oracle):
+    """The postprocess use (NMFkPostprocess.jl:182): cluster the 8192 rows of a W (n x k) into k groups, 1000 repeats."""
+    n, k = 8192, 6
+    base = np.eye(k, dtype=np.float32)[:, ctx.fill_uniform(31, 0, n).__mul__(k).astype(int) % k]  # a planted group per row
+    Wt = (base * (0.5 + ctx.fill_uniform(32, 0, n))[None, :] + 0.05 * ctx.fill_uniform(33, 0, k * n).reshape(n, k).T).astype(np.float32)
+    r = ctx.robustkmeans(Wt, k, 1000, seed=1)
+    planted = base.argmax(axis=0)
+    assert r["nclusters"] == k and r["counts"].sum() == n
+    for c in range(1, k + 1):  # every found cluster is one planted group
+        assert len(set(planted[r["assignments"] == c].tolist())) == 1
+    one = oracle.kmeans(np.asfortranarray(Wt), k, seed=1 + r["best_repeat"])  # the winning repeat alone on the CPU
+    assert one["totalcost"] == r["totalcost"]

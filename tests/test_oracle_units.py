@@ -172,3 +172,65 @@ def test_rng_properties(oracle):
     assert abs(u.mean() - 0.5) < 5e-3 and abs(u.var() - 1 / 12) < 2e-3
     assert (oracle.uniform_fill(42, 10, 5) == u[10:15]).all()
     assert (oracle.uniform_fill(43, 0, 5) != u[:5]).all()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# robustkmeans (Clus:138-246)
+# ---------------------------------------------------------------------------------------------------------
+def _direction_clusters(oracle, d, per, nc, seed, noise=0.05):
+    """nc groups of `per` samples, each along its own direction (cosine distance separates them), random lengths."""
+    u = oracle.uniform_fill(seed, 0, d * nc + 2 * per * nc + d * per * nc)
+    dirs = 0.1 + np.eye(d)[:, :nc] if nc <= d else u[:d * nc].reshape(d, nc)
+    cols = []
+    for c in range(nc):
+        length = 0.5 + 1.5 * u[d * nc + c * per:d * nc + (c + 1) * per]
+        nz = u[d * nc + 2 * per * nc + c * d * per:d * nc + 2 * per * nc + (c + 1) * d * per].reshape(d, per)
+        cols.append(dirs[:, [c]] * length[None, :] + noise * nz)
+    X = np.concatenate(cols, axis=1)
+    perm = np.argsort(oracle.uniform_fill(seed + 1, 0, X.shape[1]))  # shuffle the columns
+    return np.asfortranarray(X[:, perm])
+
+
+def test_kmeans_reference_test_vector(oracle):
+    """test/test_cluster_unit.jl:6-18: valid assignments on the 2 x 4 example (k = 2, 5 repeats, maxiter 50, tol 1e-8)."""
+    X = np.array([[1.0, 1.1, 10.0, 10.1], [1.0, 0.9, 10.0, 9.9]])
+    r = oracle.robustkmeans_k(X, 2, 5, maxiter=50, tol=1e-8)
+    assert len(r["assignments"]) == 4 and sorted(set(r["assignments"].tolist())) == [1, 2]
+    assert r["centers"].shape == (2, 2)
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_kmeans_invariants(oracle, T):
+    X = _direction_clusters(oracle, 5, 30, 3, seed=7).astype(T)
+    r = oracle.kmeans(X, 3, seed=11)
+    a = r["assignments"]
+    assert r["converged"] and r["iterations"] >= 1 and (np.bincount(a, minlength=3) == r["counts"]).all()
+    for c in range(3):  # centres = mean of the members; costs = cosine distance to the own centre
+        np.testing.assert_allclose(r["centers"][:, c], X[:, a == c].mean(axis=1), rtol=2e-6)
+    own = np.array([oracle.cosine_dist_np(r["centers"][:, a[j]].astype(np.float64), X[:, j].astype(np.float64)) for j in range(X.shape[1])])
+    np.testing.assert_allclose(r["costs"], own, atol=2e-6)
+    assert abs(r["totalcost"] - r["costs"].astype(np.float64).sum()) < 1e-9
+    other = np.array([[oracle.cosine_dist_np(r["centers"][:, c].astype(np.float64), X[:, j].astype(np.float64)) for c in range(3)]
+                      for j in range(X.shape[1])])
+    assert (other.min(axis=1) >= own - 1e-6).all()  # every sample sits in its nearest cluster
+
+
+def test_robustkmeans_finds_planted_clusters_and_sorts_by_size(oracle):
+    X = np.concatenate([_direction_clusters(oracle, 4, 25, 3, seed=3), _direction_clusters(oracle, 4, 10, 1, seed=5)], axis=1)
+    r, sil = oracle.robustkmeans_k(X, 3, 30, compute_silhouettes_flag=True)
+    assert r["nclusters"] == 3 and (np.diff(r["counts"]) <= 0).all() and r["counts"].sum() == X.shape[1]
+    assert (np.bincount(r["assignments"])[1:] == r["counts"]).all()
+    assert r["totalcost"] == r["all_costs"].min() and r["best_repeat"] == int(np.argmin(r["all_costs"]))
+    Z = np.maximum(X, np.finfo(np.float64).eps ** 2)
+    D = np.array([[oracle.cosine_dist_np(Z[:, i], Z[:, j]) for j in range(X.shape[1])] for i in range(X.shape[1])])
+    np.testing.assert_allclose(sil, oracle.silhouettes_np(r["assignments"], D), atol=1e-12)
+    assert sil.min() > 0.5
+
+
+def test_robustkmeans_krange_selection(oracle):
+    X = _direction_clusters(oracle, 5, 20, 3, seed=9)
+    best, kbest, allr = oracle.robustkmeans(X, [2, 3, 4, 5], 20)
+    worst = [r["worst_silhouette"] for r in allr]
+    assert kbest == [2, 3, 4, 5][int(np.argmax([worst[i] - worst[i + 1] for i in range(3)])) + 1]  # Clus:160
+    assert worst[1] > 0.8 > worst[2]  # three planted directions: the cliff is between k = 3 and k = 4
+    assert oracle.robustkmeans(X[:, :2], [2, 3], 5) is None  # Clus:139-142

@@ -771,6 +771,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   NmfkSseArgs sa;
   sa.arena = A;
   sa.Xc = ctx->Xc;
+  sa.Xr = ctx->Xr;
   sa.Wgt = ctx->Wgt;
   sa.n = n;
   sa.m = m;
@@ -826,6 +827,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // exchange data before the clustering step, so no cross-stream synchronisation is needed inside the loop.
   const int ngroups = (int)groups.size();
   auto use_wide = [&](const Group &G) { return use_wide_k(G.k); };
+  const bool wide_sse = !(getenv("NMFK_MFMA_SSE") && atoi(getenv("NMFK_MFMA_SSE")) == 0);
   auto use_mfma = [&](const Group &G) { return use_mfma_k(G.k); };
   int max_streams = 8;
   if (const char *e = getenv("NMFK_STREAMS")) max_streams = std::max(1, std::min(64, atoi(e)));
@@ -933,6 +935,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             nmfk_launch_sp_obj_f32(&spw, n, m, (it + 1) & 1, 0, P.weight, G.begin, G.count, gs);
         } else if (f64) {
           nmfk_launch_sse_f64(sa, G.begin, G.count, gs);
+        } else if (use_wide(G) && sa.Wgt == nullptr && wide_sse) {
+          nmfk_launch_sse_mfma_wide_f32(sa, G.kp, G.begin, G.count, gs);
         } else {
           nmfk_launch_sse_f32(sa, G.begin, G.count, gs);
         }

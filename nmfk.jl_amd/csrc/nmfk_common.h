@@ -67,6 +67,7 @@ struct NmfkStepArgs {
 struct NmfkSseArgs {
   char *arena;
   const float *Xc;  // column-major copy, element (i, j) at Xc[i + j*n]
+  const float *Xr;  // row-major copy, element (i, j) at Xr[j + i*m] (the MFMA objective kernel of ranks > 16)
   const float *Wgt; // optional n x m weight array (column-major) of the monitored objective (Mult:74), or null
   int32_t n, m;
   int32_t hsel;     // which H buffer parity to read; -1 => per-unit final buffer (state.iters&1)
@@ -231,6 +232,7 @@ void nmfk_launch_point_silhouettes(const float *X, int d, int n, const int32_t *
 void nmfk_launch_step_mfma_wide_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt,
                                     hipStream_t s);
 int nmfk_mfma_wide_lane_tile(int wsplit);
+void nmfk_launch_sse_mfma_wide_f32(const NmfkSseArgs &a, int kp, int u0, int cnt, hipStream_t s);
 void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f64)
 

@@ -1184,6 +1184,105 @@ __global__ __launch_bounds__(2 * NMFK_TILE) void mfma_wide_kernel(char *arena, c
   }
 }
 
+
+// Monitored objective (Mult:74) for ranks above 16 on the matrix pipe: the W half-step's first product only,
+// P = H' W' tile by tile, then sum((x - p)^2 * weight^2) in fp64.  fp32, no missing data, scalar weight; lanes = rows of X.
+template <int KQ>
+__global__ __launch_bounds__(NMFK_TILE) void mfma_sse_kernel(NmfkSseArgs g, int u0) {
+  extern __shared__ double lds[];  // [8] block-sum scratch, then one 16 x KP staging buffer per wave
+  constexpr int KP = 4 * KQ, RS = KP + 4, NT = 4, NB = (KP + 15) / 16;
+  const int u = u0 + blockIdx.y;
+  const NmfkState st = g.state[u];
+  if (!g.force && !st.active) return;
+  const NmfkRun *__restrict__ rdp = g.runs + u;
+  const int sel = g.hsel >= 0 ? g.hsel : ((st.active ? g.total_iters : st.iters) & 1);
+  const float *__restrict__ B = (const float *)(g.arena + NMFK_HOFF(*rdp, sel));
+  const float *__restrict__ A = (const float *)(g.arena + rdp->oWt);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, c16 = lane & 15;
+  const int L = g.n, D = g.m;
+  const int l0 = blockIdx.x * NMFK_TILE + wave * 64;
+  float afrag[NT][KQ];
+  int lt[NT];
+  bool lv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int l = l0 + 16 * t + c16;
+    lv[t] = l < L;
+    lt[t] = lv[t] ? l : 0;
+#pragma unroll
+    for (int sq = 0; sq < KQ; ++sq) afrag[t][sq] = lv[t] ? A[KQ * gq + sq + (int64_t)lt[t] * KP] : 0.0f;
+  }
+  float *stage = (float *)(lds + 8) + wave * (16 * RS);
+  const float *xbase[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) xbase[t] = g.Xr + (int64_t)lt[t] * D + 4 * gq;
+  int wofs[NB];
+  bool wv[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int pi = lane + 64 * q;
+    wv[q] = pi < 4 * KP;
+    wofs[q] = ((4 * pi) / KP) * RS + (4 * pi) % KP;
+  }
+  const float wgt = (float)g.weight;
+  double ss = 0.0;
+  const int nch = (D + 15) >> 4;
+  auto load = [&](int dch, f32x4_t (&xv)[NT], f32x4_t (&bv)[NB]) __attribute__((always_inline)) {
+    const int dx = (dch + 16 <= D) ? dch : (min(dch + 4 * gq, D - 4) - 4 * gq);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xv[t] = *(const f32x4_u *)(xbase[t] + dx);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      bv[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (wv[q]) bv[q] = *(const f32x4_u *)(B + (int64_t)dch * KP + 4 * (lane + 64 * q));
+    }
+  };
+  auto step = [&](int ci, const f32x4_t (&xc)[NT], const f32x4_t (&bc)[NB], f32x4_t (&xn)[NT], f32x4_t (&bn)[NB])
+                  __attribute__((always_inline)) {
+    const int dch = 16 * ci;
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      if (wv[q]) *(f32x4_t *)(stage + wofs[q]) = bc[q];
+    if (ci + 1 < nch) load(dch + 16, xn, bn);
+    __builtin_amdgcn_wave_barrier();
+    const bool full = dch + 16 <= D;
+    float bP[KQ];
+    {
+      const float *pr = stage + (full ? c16 : min(c16, D - 1 - dch)) * RS + KQ * gq;
+#pragma unroll
+      for (int sq = 0; sq < KQ; ++sq) bP[sq] = pr[sq];
+    }
+    f32x4_t p[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sq = 0; sq < KQ; ++sq)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bP[sq], afrag[t][sq], p[t], 0, 0, 0);
+    const int shift = full ? 0 : (dch + 4 * gq) - min(dch + 4 * gq, D - 4);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = r + shift;
+        const float xx = rr <= 0 ? xc[t][0] : rr == 1 ? xc[t][1] : rr == 2 ? xc[t][2] : xc[t][3];
+        const float e = (xx - p[t][r]) * wgt;
+        const bool use = lv[t] && (dch + 4 * gq + r < D);
+        ss += use ? (double)e * (double)e : 0.0;
+      }
+    __builtin_amdgcn_wave_barrier();
+  };
+  {
+    f32x4_t x0[NT], x1[NT], b0[NB], b1[NB];
+    load(0, x0, b0);
+    for (int ci = 0; ci < nch; ci += 2) {
+      step(ci, x0, b0, x1, b1);
+      if (ci + 1 < nch) step(ci + 1, x1, b1, x0, b0);
+    }
+  }
+  ss = block_sum(ss, lds);
+  if (tid == 0) ((double *)(g.arena + rdp->ossepart))[blockIdx.x] = ss;
+}
 #endif
 
 // ------------------------------------------------------------------------------------------------------
@@ -1751,6 +1850,21 @@ static void launch_mfma_wide(const NmfkStepArgs &a, const NmfkStepArgs *dargs, i
   const size_t cross = ws > 1 ? (size_t)(ws - 1) * NT * NB * 4 * 64 * sizeof(float) : 0;
   const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + std::max(stage, cross);
   hipLaunchKernelGGL((mfma_wide_kernel<KQ, NB, NT>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0, uf);
+}
+
+// objective of ranks above 16 on the matrix pipe (fp32, dense, no missing data, scalar weight)
+void nmfk_launch_sse_mfma_wide_f32(const NmfkSseArgs &a, int kp, int u0, int cnt, hipStream_t s) {
+  const int ntile = (a.n + NMFK_TILE - 1) / NMFK_TILE;
+  const dim3 grid(ntile, cnt), blk(NMFK_TILE);
+  const size_t ldsb = sizeof(double) * 8 + sizeof(float) * 4 * 16 * (size_t)(kp + 4);
+#define NMFK_SSE_MFMA(KQ) hipLaunchKernelGGL((mfma_sse_kernel<KQ>), grid, blk, ldsb, s, a, u0)
+  switch (kp) {
+    case 20: NMFK_SSE_MFMA(5); break;   case 24: NMFK_SSE_MFMA(6); break;   case 28: NMFK_SSE_MFMA(7); break;
+    case 32: NMFK_SSE_MFMA(8); break;   case 40: NMFK_SSE_MFMA(10); break;  case 48: NMFK_SSE_MFMA(12); break;
+    case 56: NMFK_SSE_MFMA(14); break;  case 64: NMFK_SSE_MFMA(16); break;
+    default: break;
+  }
+#undef NMFK_SSE_MFMA
 }
 
 int nmfk_mfma_wide_lane_tile(int wsplit) { return 16 * NMFK_WIDE_NT * (wsplit > 1 ? 1 : 4); }

@@ -106,6 +106,31 @@ def test_wide_ranks_fp32_mfma_path(NMFk, ctx, oracle, k, shape):
         np.testing.assert_allclose(res["H"][r].sum(axis=1), 1.0, atol=1e-4)
 
 
+@pytest.mark.parametrize("k", [20, 33, 64])
+@pytest.mark.parametrize("shape", [(300, 70), (130, 2100)])
+def test_wide_rank_objective_on_the_matrix_pipe(NMFk, ctx, oracle, k, shape):
+    """The monitored objective of ranks > 16 (mfma_sse_kernel, Mult:74) decides the tol stop (Mult:75-78): bracket its
+    value at the first check between tol = SSE*(1 -/+ 1e-5), SSE taken from the final (VALU) objective of a
+    10-iteration run; and the same stop decisions as with the VALU objective kernel (NMFK_MFMA_SSE=0)."""
+    n, m = shape
+    X = (0.05 + oracle.uniform_fill(14, 0, n * m)).reshape(n, m).astype(np.float32)
+    ctx.set_X(X)
+    seeds = _seeds(NMFk, 6, [k], 2)
+    sse10 = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=10, **NOSTOP)[k]["objvalue"].astype(np.float64) ** 2
+    hi = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=30, tol=float(sse10.max() * (1 + 1e-5)), **NOSTOP)[k]
+    lo = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=30, tol=float(sse10.min() * (1 - 1e-5)), **NOSTOP)[k]
+    assert (hi["iters"] == 10).all() and (hi["reason"] == NMFk.STOP_TOL).all()
+    assert (lo["iters"] > 10).all()
+    a = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=200)[k]  # default stop rule
+    os.environ["NMFK_MFMA_SSE"] = "0"
+    try:
+        b = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=200)[k]
+    finally:
+        del os.environ["NMFK_MFMA_SSE"]
+    assert np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["reason"], b["reason"])
+    np.testing.assert_allclose(a["objvalue"], b["objvalue"], rtol=1e-6)
+
+
 def test_wide_rank_mfma_matches_valu_kernel_large(NMFk, ctx):
     """The two fp32 half-step kernels for k > 16 (MFMA, default; VALU with NMFK_MFMA_WIDE=0) agree at a size where
     the lane dimension alone fills the chip (no wave split) and with a grid-level split (few lane tiles)."""

@@ -567,7 +567,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if (ctx->sparse) return NMFK_TILE;
     if (use_wide_k(k)) return nmfk_mfma_wide_lane_tile(ws);
     if (use_mfma_k(k)) return ws == 4 ? 64 : NMFK_TILE;
-    if (merge > 0 && k <= 16) return (ws > 1 ? 64 : NMFK_TILE) * NMFK_MULTI_LB;
+    if (merge > 0 && k <= NMFK_MULTI_MAXK) return (ws > 1 ? 64 : NMFK_TILE) * NMFK_MULTI_LB;
     return (ws > 1 ? 64 : NMFK_TILE) * NMFK_LB_OF(nmfk_padded_k(k));
   };
   int max_ws = 8;  // the experimental MFMA variant is written for 4-wave workgroups
@@ -622,7 +622,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ulist.reserve(nunits);
   for (int oi = 0; oi < nk; ++oi) {
     const int q = order[oi], k = ks[q];
-    if (merge > 0 && k <= 16) continue;
+    if (merge > 0 && k <= NMFK_MULTI_MAXK) continue;
     groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns});
     for (int r = 0; r < nruns; ++r) ulist.push_back({q, r});
   }
@@ -630,7 +630,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     Group G{0, 0, (int)ulist.size(), 0};
     for (int oi = 0; oi < nk; ++oi) {
       const int q = order[oi];
-      if (ks[q] > 16) continue;
+      if (ks[q] > NMFK_MULTI_MAXK) continue;
       for (int r = g; r < nruns; r += merge, ++G.count) ulist.push_back({q, r});
     }
     if (G.count > 0) groups.push_back(G);

@@ -183,6 +183,12 @@ static inline int nmfk_padded_k(int k) {
 #ifndef NMFK_XBUF
 #define NMFK_XBUF 1          // X entries through buffer loads (scalar address arithmetic); 0 = global loads
 #endif
+#ifndef NMFK_MULTI_MAXK
+#define NMFK_MULTI_MAXK 16    // widest rank served by the mixed-rank kernel (8, 12, 14 or 16); wider ranks keep their own launches
+#endif
+#ifndef NMFK_MULTI_MINWAVES
+#define NMFK_MULTI_MINWAVES 2 // waves per SIMD requested for the mixed-rank kernel
+#endif
 #ifndef NMFK_MULTI_LB
 #define NMFK_MULTI_LB 2      // lane elements per thread of the mixed-rank kernel (1 measured 50 % slower: the wave-uniform rows are shared)
 #endif

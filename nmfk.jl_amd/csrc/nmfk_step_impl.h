@@ -648,7 +648,7 @@ __global__ __launch_bounds__(2 * NMFK_TILE, NMFK_MINWAVES(KP)) void step_kernel(
 // GPUs).  The register allocation is that of the widest case, which is irrelevant when the chip is not full anyway.
 #define NMFK_MULTI_CASE(KP) step_body<KP, NMFK_MULTI_LB, NANS>(arena, X, gp, runs + u, it, lds, bx)
 template <bool NANS>
-__global__ __launch_bounds__(2 * NMFK_TILE, 2) void step_kernel_multi(char *arena, const float *__restrict__ X,
+__global__ __launch_bounds__(2 * NMFK_TILE, NMFK_MULTI_MINWAVES) void step_kernel_multi(char *arena, const float *__restrict__ X,
                                                                       const NmfkRun *__restrict__ runs,
                                                                       const NmfkState *__restrict__ state,
                                                                       const NmfkStepArgs *__restrict__ gp, int it, int u0,
@@ -660,10 +660,17 @@ __global__ __launch_bounds__(2 * NMFK_TILE, 2) void step_kernel_multi(char *aren
   switch (runs[u].kp) {
     case 1: NMFK_MULTI_CASE(1); break;   case 2: NMFK_MULTI_CASE(2); break;   case 3: NMFK_MULTI_CASE(3); break;
     case 4: NMFK_MULTI_CASE(4); break;   case 5: NMFK_MULTI_CASE(5); break;   case 6: NMFK_MULTI_CASE(6); break;
-    case 7: NMFK_MULTI_CASE(7); break;   case 8: NMFK_MULTI_CASE(8); break;   case 9: NMFK_MULTI_CASE(9); break;
-    case 10: NMFK_MULTI_CASE(10); break; case 11: NMFK_MULTI_CASE(11); break; case 12: NMFK_MULTI_CASE(12); break;
-    case 13: NMFK_MULTI_CASE(13); break; case 14: NMFK_MULTI_CASE(14); break; case 15: NMFK_MULTI_CASE(15); break;
-    case 16: NMFK_MULTI_CASE(16); break;
+    case 7: NMFK_MULTI_CASE(7); break;   case 8: NMFK_MULTI_CASE(8); break;
+#if NMFK_MULTI_MAXK >= 12
+    case 9: NMFK_MULTI_CASE(9); break;   case 10: NMFK_MULTI_CASE(10); break; case 11: NMFK_MULTI_CASE(11); break;
+    case 12: NMFK_MULTI_CASE(12); break;
+#endif
+#if NMFK_MULTI_MAXK >= 14
+    case 13: NMFK_MULTI_CASE(13); break; case 14: NMFK_MULTI_CASE(14); break;
+#endif
+#if NMFK_MULTI_MAXK >= 16
+    case 15: NMFK_MULTI_CASE(15); break; case 16: NMFK_MULTI_CASE(16); break;
+#endif
     default: break;
   }
 }

@@ -131,6 +131,23 @@ def test_wide_rank_objective_on_the_matrix_pipe(NMFk, ctx, oracle, k, shape):
     np.testing.assert_allclose(a["objvalue"], b["objvalue"], rtol=1e-6)
 
 
+def test_wide_ranks_fallbacks_to_the_vector_kernel(NMFk, ctx, oracle):
+    """k > 16 where the MFMA kernel does not apply: a dimension below 16, and missing data (NaN) -- the wide VALU
+    instantiations (padded rank) must serve both, fp32, against the oracle."""
+    for (n, m, k, nan) in [(40, 12, 20, False), (12, 90, 17, False), (150, 64, 24, True)]:
+        X = (0.05 + oracle.uniform_fill(15, 0, n * m)).reshape(n, m).astype(np.float32)
+        if nan:
+            X[3::11, 2::7] = np.nan
+        ctx.set_X(X)
+        seeds = _seeds(NMFk, 6, [k], 2)
+        res = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=20, **NOSTOP)[k]
+        for r in range(2):
+            W0, H0 = oracle.init_factors(int(seeds[0, r]), n, m, k)
+            ref = oracle.singlerun(X, k, W0, H0, maxiter=20, **NOSTOP)
+            assert _rel(res["W"][r] @ res["H"][r], ref["W"] @ ref["H"], X) <= 1e-4
+            assert abs(res["objvalue"][r] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
+
+
 def test_wide_rank_mfma_matches_valu_kernel_large(NMFk, ctx):
     """The two fp32 half-step kernels for k > 16 (MFMA, default; VALU with NMFK_MFMA_WIDE=0) agree at a size where
     the lane dimension alone fills the chip (no wave split) and with a grid-level split (few lane tiles)."""

@@ -259,7 +259,8 @@ NMFK_EXPORT int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, 
   if (!ctx || !X) return fail(NMFK_ERR_BAD_ARG, "ctx or X is null");
   if (n <= 0 || m <= 0) return fail(NMFK_ERR_BAD_ARG, "Input array has a zero dimension!");  // Exec:242-244
   if (ldx < n) return fail(NMFK_ERR_BAD_ARG, "ldx < n");
-  if (n > 0x7fffff00 || m > 0x7fffff00) return fail(NMFK_ERR_UNSUPPORTED, "dimension exceeds int32 range");
+  // the half-step kernels address X with 32-bit byte offsets inside a group of <= 4 rows (buffer loads)
+  if (n > (1 << 27) || m > (1 << 27)) return fail(NMFK_ERR_UNSUPPORTED, "dimension exceeds 2^27");
   HIPCHECK(hipSetDevice(ctx->device));
   const size_t bytes = (size_t)n * (size_t)m * sizeof(float);
   if (ctx->Xc) (void)hipFree(ctx->Xc);

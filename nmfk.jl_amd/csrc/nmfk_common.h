@@ -187,7 +187,7 @@ static inline int nmfk_padded_k(int k) {
 #define NMFK_MULTI_MAXK 16    // widest rank served by the mixed-rank kernel (8, 12, 14 or 16); wider ranks keep their own launches
 #endif
 #ifndef NMFK_MULTI_MINWAVES
-#define NMFK_MULTI_MINWAVES 2 // waves per SIMD requested for the mixed-rank kernel
+#define NMFK_MULTI_MINWAVES 3 // waves per SIMD requested for the mixed-rank kernel (2: 179 VGPRs, 12 % slower; 4: spills, 65 % slower)
 #endif
 #ifndef NMFK_MULTI_LB
 #define NMFK_MULTI_LB 2      // lane elements per thread of the mixed-rank kernel (1 measured 50 % slower: the wave-uniform rows are shared)

@@ -168,6 +168,9 @@ static inline int nmfk_padded_k(int k) {
 #ifndef NMFK_MERGE_GROUPS
 #define NMFK_MERGE_GROUPS 2    // number of mixed-rank launch groups then
 #endif
+#ifndef NMFK_XCD_REMAP
+#define NMFK_XCD_REMAP 1     // wide-rank MFMA kernel: restarts of one lane tile on one XCD (L2 sharing of X at large sizes)
+#endif
 #ifndef NMFK_UNIT_FAST
 #define NMFK_UNIT_FAST 0     // half-step grids: 1 = unit is the fast dimension (see the launchers: measured worse for L2)
 #endif

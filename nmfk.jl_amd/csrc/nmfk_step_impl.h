@@ -963,8 +963,20 @@ __global__ __launch_bounds__(2 * NMFK_TILE) void mfma_wide_kernel(char *arena, c
                                                                  int uf) {
   extern __shared__ double lds[];  // den[64], red[8*64], then max(staging, cross-wave scratch)
   constexpr int KP = 4 * KQ, RS = KP + 4;  // staged row stride (floats): 16-byte aligned, off the 32-bank period
-  const int u = u0 + (uf ? blockIdx.x : blockIdx.y);
-  const int bx = uf ? blockIdx.y : blockIdx.x;
+  int u = u0 + (uf ? blockIdx.x : blockIdx.y);
+  int bx = uf ? blockIdx.y : blockIdx.x;
+#if NMFK_XCD_REMAP
+  // Large X (tile slice of an XCD >> its 4 MB L2): workgroups are dealt to the XCDs round-robin in linear order, so
+  // make the restarts of ONE lane tile consecutive workgroups of ONE XCD -- they run together and share the tile's X
+  // rows through that L2 instead of fetching them once per restart.  linear id -> (xcd, slot); slot -> (tile group,
+  // unit); tile = 8 * group + xcd.
+  if (!uf && (gridDim.x & 7) == 0) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x, nu = gridDim.y;
+    const int xcd = lin & 7, slot = lin >> 3;
+    u = u0 + slot % nu;
+    bx = (slot / nu) * 8 + xcd;
+  }
+#endif
   if (!gp->force && !state[u].active) return;
   const NmfkRun *__restrict__ rdp = runs + u;
   const int k = rdp->k;

@@ -87,6 +87,8 @@ struct nmfk_ctx {
   // workspaces
   DevBuf arena;    // sweep
   DevBuf scratch;  // set_X staging, clustering
+  DevBuf xtile;    // tiled copies of X for the split-operand MFMA half-step (built on first use after set_X)
+  uint64_t xgen = 0, xtile_gen = ~(uint64_t)0;
   void *pinned = nullptr;
   size_t pinned_cap = 0;
   // profiling
@@ -240,6 +242,7 @@ NMFK_EXPORT int nmfk_destroy(nmfk_ctx *ctx) {
   free_sparse(ctx);
   ctx->arena.release();
   ctx->scratch.release();
+  ctx->xtile.release();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -281,6 +284,7 @@ NMFK_EXPORT int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, 
   HIPCHECK(hipMemcpyAsync(Xin, X, ((size_t)ldx * (size_t)(m - 1) + (size_t)n) * sizeof(float), hipMemcpyDefault,
                           ctx->stream));
   nmfk_launch_preprocess(Xin, ldx, n, m, (float)lambda, ctx->Xc, ctx->Xr, counts, ctx->stream);
+  ctx->xgen++;
   HIPCHECK(hipGetLastError());
   unsigned long long h[3] = {0, 0, 0};
   HIPCHECK(hipMemcpyAsync(h, counts, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -558,16 +562,28 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   if (const char *e = getenv("NMFK_MFMA_MINK")) mfma_mink = atoi(e);
   auto use_wide_k = [&](int k) { return wide_ok && k > 16; };
   auto use_mfma_k = [&](int k) { return wide_ok_nowide && k <= 16 && mfma_mink > 0 && k >= mfma_mink; };
+  // ranks in [hyb_mink, 16]: split-operand MFMA half-step (nmfk_step_hyb.hip), experimental and off by default:
+  // 1.26x faster than the packed-VALU kernel at k = 16 on a GPU filled with one rank (256 restarts), but slower inside
+  // the mixed sweep; enable with NMFK_HYB=1
+  int hyb_on = 0, hyb_mink = 5;
+  if (const char *e = getenv("NMFK_HYB")) hyb_on = atoi(e);
+  if (const char *e = getenv("NMFK_HYB_MINK")) hyb_mink = std::max(1, atoi(e));
   int merge = -1;
   if (const char *e = getenv("NMFK_MERGE")) merge = atoi(e);
   if (merge < 0) merge = nruns <= NMFK_MERGE_MAX_RUNS ? std::min(nruns, NMFK_MERGE_GROUPS) : 0;
   if (ctx->sparse || mfma_mink > 0) merge = 0;
   merge = std::min(merge, nruns);
+  auto use_hyb_k = [&](int k) {
+    // (its buffer loads address X with 32-bit byte offsets from the array base)
+    return hyb_on && wide_ok_nowide && mfma_mink == 0 && merge == 0 && k <= 16 && k >= hyb_mink &&
+           (int64_t)n * m * 4 < ((int64_t)1 << 32) - 4096;
+  };
   // lane elements per workgroup (= per sum-table slot) of the half-step kernel a rank runs
   auto lane_tile = [&](int k, int ws) {
     if (ctx->sparse) return NMFK_TILE;
     if (use_wide_k(k)) return nmfk_mfma_wide_lane_tile(ws);
     if (use_mfma_k(k)) return ws == 4 ? 64 : NMFK_TILE;
+    if (use_hyb_k(k)) return nmfk_hyb_lane_tile(ws);
     if (merge > 0 && k <= NMFK_MULTI_MAXK) return (ws > 1 ? 64 : NMFK_TILE) * NMFK_MULTI_LB;
     return (ws > 1 ? 64 : NMFK_TILE) * NMFK_LB_OF(nmfk_padded_k(k));
   };
@@ -588,6 +604,10 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     const int maxS = std::max(1, D / (64 * g.wsplit));
     g.S = std::max(1, std::min(S, maxS));
     g.dchunk = (D + g.S - 1) / g.S;
+    if (g.S > 1) {  // split points on multiples of 16 (the MFMA kernels read X in 16-step blocks)
+      g.dchunk = (g.dchunk + 15) & ~15;
+      g.S = (D + g.dchunk - 1) / g.dchunk;
+    }
     g.fused = g.S == 1;
     g.slots = 1;  // slots of the sum tables = the most lane tiles any rank's kernel uses
     for (int q = 0; q < nk; ++q) g.slots = std::max(g.slots, (L + lane_tile(ks[q], g.wsplit) - 1) / lane_tile(ks[q], g.wsplit));
@@ -658,6 +678,18 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         // slots the unit's kernels write: the fused half-step one per lane tile, the grid-parallel helpers any count
         rd.nsH = gh.fused ? (m + lane_tile(k, gh.wsplit) - 1) / lane_tile(k, gh.wsplit) : PH;
         rd.nsW = gw.fused ? (n + lane_tile(k, gw.wsplit) - 1) / lane_tile(k, gw.wsplit) : PW;
+        rd.hyb = rd.ldWf = rd.ldHf = rd.pad0 = 0;
+        rd.oWbf = rd.oHbf = rd.oWft = rd.oHft = 0;
+        if (use_hyb_k(k)) {
+          const int KS = k <= 8 ? 8 : 16;
+          rd.hyb = KS;
+          rd.ldWf = ((n + 15) & ~15) + 16;
+          rd.ldHf = ((m + 15) & ~15) + 16;
+          rd.oWbf = (int64_t)B.take(sizeof(uint16_t) * 3 * KS * ((size_t)n + 16));
+          rd.oHbf = (int64_t)B.take(sizeof(uint16_t) * 3 * KS * ((size_t)m + 16));
+          rd.oWft = (int64_t)B.take(sizeof(float) * KS * (size_t)rd.ldWf);
+          rd.oHft = (int64_t)B.take(sizeof(float) * KS * (size_t)rd.ldHf);
+        }
       }
     }
   }
@@ -721,6 +753,18 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     nmfk_launch_init_f64(ia, st);
   else
     nmfk_launch_init_f32(ia, st);
+  bool any_hyb = false;
+  for (int q = 0; q < nk; ++q) any_hyb = any_hyb || use_hyb_k(ks[q]);
+  const size_t tile_h = (size_t)((m + 15) / 16) * ((n + 15) / 16) * 256, tile_w = tile_h;  // floats
+  if (any_hyb) {
+    nmfk_launch_hyb_forms(A, d_runs, n, m, 0, 3, 0, nunits, st);
+    if (ctx->xtile_gen != ctx->xgen) {
+      if (ctx->xtile.ensure(sizeof(float) * (tile_h + tile_w))) return fail(NMFK_ERR_HIP, "out of device memory (tiled X)");
+      nmfk_launch_hyb_tile(ctx->Xc, m, n, (float *)ctx->xtile.p, st);           // H half-step: lanes = columns
+      nmfk_launch_hyb_tile(ctx->Xr, n, m, (float *)ctx->xtile.p + tile_h, st);  // W half-step: lanes = rows
+      ctx->xtile_gen = ctx->xgen;
+    }
+  }
   HIPCHECK(hipGetLastError());
   {
     int32_t flag = 0;
@@ -733,6 +777,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   hs.arena = A;
   hs.X = ctx->Xr;
   hs.Xalt = ctx->Xc;
+  hs.Xtile = any_hyb ? (const float *)ctx->xtile.p : nullptr;
   hs.ld = m;
   hs.L = m;
   hs.D = n;
@@ -753,6 +798,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   NmfkStepArgs ws = hs;
   ws.X = ctx->Xc;
   ws.Xalt = ctx->Xr;
+  ws.Xtile = any_hyb ? (const float *)ctx->xtile.p + tile_h : nullptr;
   ws.ld = n;
   ws.L = n;
   ws.D = m;
@@ -830,6 +876,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   auto use_wide = [&](const Group &G) { return use_wide_k(G.k); };
   const bool wide_sse = !(getenv("NMFK_MFMA_SSE") && atoi(getenv("NMFK_MFMA_SSE")) == 0);
   auto use_mfma = [&](const Group &G) { return use_mfma_k(G.k); };
+  auto use_hyb = [&](const Group &G) { return G.kp != 0 && use_hyb_k(G.k); };
   int max_streams = 8;
   if (const char *e = getenv("NMFK_STREAMS")) max_streams = std::max(1, std::min(64, atoi(e)));
   const int NS = std::min(ngroups, max_streams);
@@ -890,6 +937,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_step_mfma_wide_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         else if (use_mfma(G))
           nmfk_launch_step_mfma_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
+        else if (use_hyb(G))
+          nmfk_launch_step_hyb_f32(hs, d_hs, G.k <= 8 ? 8 : 16, G.begin, G.count, gs);
         else
           nmfk_launch_step_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         if (timed) prof.end(e0, PK_HSTEP, j, it, gs);
@@ -898,6 +947,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             nmfk_launch_reduce_f64(hs, G.begin, G.count, gs);
           else
             nmfk_launch_reduce_f32(hs, G.begin, G.count, gs);
+          if (use_hyb(G)) nmfk_launch_hyb_forms(A, d_runs, n, m, (it + 1) & 1, 2, G.begin, G.count, gs);
         }
       }
       if (!P.Wfixed) {  // Mult:69-71
@@ -917,6 +967,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_step_mfma_wide_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         else if (use_mfma(G))
           nmfk_launch_step_mfma_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
+        else if (use_hyb(G))
+          nmfk_launch_step_hyb_f32(ws, d_ws, G.k <= 8 ? 8 : 16, G.begin, G.count, gs);
         else
           nmfk_launch_step_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         if (timed) prof.end(e0, PK_WSTEP, j, it, gs);
@@ -925,6 +977,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             nmfk_launch_reduce_f64(ws, G.begin, G.count, gs);
           else
             nmfk_launch_reduce_f32(ws, G.begin, G.count, gs);
+          if (use_hyb(G)) nmfk_launch_hyb_forms(A, d_runs, n, m, (it + 1) & 1, 1, G.begin, G.count, gs);
         }
       }
       if (check) {
@@ -945,6 +998,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_check_f64(ca, G.begin, G.count, gs);
         else
           nmfk_launch_check_f32(ca, G.begin, G.count, gs);
+        // the clamp (Mult:99-100) rewrote both factors
+        if (use_hyb(G)) nmfk_launch_hyb_forms(A, d_runs, n, m, (it + 1) & 1, 3, G.begin, G.count, gs);
       }
     }
     total_iters = it + 1;

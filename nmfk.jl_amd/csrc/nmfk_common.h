@@ -24,6 +24,12 @@ struct NmfkRun {
   int64_t ocanon;    // int32[m] canonical co-clustering partition of the previous check (Mult:101-116)
   uint64_t seed;
   int32_t nsW, nsH;  // slots of the sum tables this unit's kernels write (<= PW, PH); the others stay zero
+  // split-operand MFMA half-step (nmfk_step_hyb.hip): hyb = split width KS (8 or 16; 0 = unit does not use it)
+  int32_t hyb;
+  int32_t ldWf, ldHf;  // row lengths of the transposed copies (multiple of 16, >= length + 16, zero padded)
+  int32_t pad0;
+  int64_t oWbf, oHbf;  // bf16[(len + 16)][3][KS] split rows (x = h + m + l), padding rows zero
+  int64_t oWft, oHft;  // float[KS][ld] transposed copies
 };
 
 // Stop-rule state machine of NMFmultiplicative (Mult:57-63), one per unit, device resident.
@@ -47,6 +53,7 @@ struct NmfkStepArgs {
   char *arena;
   const float *X;   // element (l, d) at X[l + d*ld]
   const float *Xalt;  // the other copy: element (l, d) at Xalt[d + l*D] (loop dimension contiguous; MFMA variant)
+  const float *Xtile; // Xalt in 16 x 16 blocks in MFMA lane order (nmfk_step_hyb.hip), or null
   int64_t ld;
   int32_t L, D;
   int32_t S;        // grid-level splits of the loop dimension (S > 1 => fused = 0, reduce kernel finishes)
@@ -241,6 +248,11 @@ void nmfk_launch_point_silhouettes(const float *X, int d, int n, const int32_t *
 void nmfk_launch_step_mfma_wide_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt,
                                     hipStream_t s);
 int nmfk_mfma_wide_lane_tile(int wsplit);
+int nmfk_hyb_lane_tile(int wsplit);
+void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int ks, int u0, int cnt, hipStream_t s);
+void nmfk_launch_hyb_tile(const float *src, int L, int D, float *out, hipStream_t s);
+void nmfk_launch_hyb_forms(char *arena, const NmfkRun *runs, int n, int m, int hpar, int mask, int u0, int cnt,
+                           hipStream_t s);
 void nmfk_launch_sse_mfma_wide_f32(const NmfkSseArgs &a, int kp, int u0, int cnt, hipStream_t s);
 void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f64)

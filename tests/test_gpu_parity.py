@@ -166,6 +166,40 @@ def test_wide_rank_mfma_matches_valu_kernel_large(NMFk, ctx):
         np.testing.assert_allclose(a["objvalue"], b["objvalue"], rtol=1e-4)
 
 
+@pytest.mark.parametrize("shape,k,R", [((64, 32), 5, 6), ((300, 70), 7, 6), ((257, 129), 16, 5), ((130, 2100), 9, 5),
+                                       ((2100, 96), 13, 5), ((1030, 530), 12, 40)])
+def test_split_operand_mfma_half_step_opt_in(NMFk, ctx, oracle, shape, k, R):
+    """NMFK_HYB=1: ranks 5..16 on the split-operand MFMA half-step (nmfk_step_hyb.hip: W*H in three-term bf16 splits,
+    numerators in fp32 MFMA).  Same tolerance against the Float64 oracle as the packed-VALU fp32 kernel; ragged loop
+    ranges, loop splits with the reduce kernel (few units) and the staged path (many units) are all covered."""
+    n, m = shape
+    X = oracle.uniform_fill(11, 0, n * m).reshape(n, m).astype(np.float32)
+    ctx.set_X(X)
+    seeds = _seeds(NMFk, 5, [k], R)
+    iters = 40
+    os.environ["NMFK_HYB"] = "1"
+    os.environ["NMFK_MERGE"] = "0"
+    try:
+        a = ctx.mu_sweep([k], R, seeds=seeds, maxiter=iters, **NOSTOP)[k]
+        W0, H0 = oracle.init_factors(int(seeds[0, 0]), n, m, k)
+        fx = ctx.mu_sweep([k], 1, Winit={k: W0[None].astype(np.float32)}, Hinit={k: H0[None].astype(np.float32)},
+                          maxiter=iters, normalize=0, Hfixed=1, **NOSTOP)[k]
+    finally:
+        del os.environ["NMFK_HYB"], os.environ["NMFK_MERGE"]
+    b = ctx.mu_sweep([k], R, seeds=seeds, maxiter=iters, **NOSTOP)[k]
+    for r in range(min(R, 3)):
+        W0, H0 = oracle.init_factors(int(seeds[0, r]), n, m, k)
+        ref = oracle.singlerun(X, k, W0, H0, maxiter=iters, nthreads=8, **NOSTOP)
+        assert a["iters"][r] == iters
+        assert _rel(a["W"][r] @ a["H"][r], ref["W"] @ ref["H"], X) <= 1e-4
+        assert abs(a["objvalue"][r] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
+    for r in range(R):  # and it stays within fp32 noise of the default kernel for every restart
+        assert _rel(a["W"][r] @ a["H"][r], b["W"][r] @ b["H"][r], X) <= 5e-6
+    W0, H0 = oracle.init_factors(int(seeds[0, 0]), n, m, k)
+    ref = oracle.singlerun(X, k, W0, H0, maxiter=iters, modifymatrices=False, Hfixed=True, **NOSTOP)
+    assert _rel(fx["W"][0] @ fx["H"][0], ref["W"] @ ref["H"], X) <= 1e-4
+
+
 @pytest.mark.parametrize("compute", ["f32", "f64"])
 def test_merged_launch_groups_bitwise_equal(NMFk, ctx, oracle, compute):
     """Few restarts per rank: ranks <= 16 share mixed-rank launches (step_kernel_multi, NMFK_MERGE).  Same arithmetic per

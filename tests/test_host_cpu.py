@@ -1,5 +1,6 @@
 """CPU-only tests of the product's host side: the C-ABI library loads and exports every symbol the header
 declares, fails loudly without a GPU, and the host logic (getk, signalorder, input checks) mirrors the reference."""
+import os
 import re
 
 import numpy as np
@@ -119,3 +120,64 @@ def test_x_hash_sidecar(NMFk, tmp_path):
     with pytest.warns(UserWarning, match="hash mismatch"):
         check_x_hash(X + 1, xf)
     assert hash_sha256_hex(X.reshape(4, 3)) != h and hash_sha256_hex(X.astype(np.float64)) != h
+
+
+def _split_top(s):
+    """split a comma-separated list at nesting depth 0"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def test_julia_shim_binds_the_declared_c_abi():
+    """julia/NMFkHIP.jl cannot run here (no julia in the image): check statically that every ccall names an entry point
+    that include/nmfk_hip.h declares and the library exports, with the same number of arguments and matching scalar
+    widths (Cint <-> int, Int64 <-> int64_t, Cdouble <-> double, pointers <-> pointers)."""
+    import ctypes
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "nmfk_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for mm in re.finditer(r"\b(?:int|const char \*)\s*(nmfk_\w+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S):
+        args = [a for a in _split_top(" ".join(mm.group(2).split())) if a != "void"]
+        protos[mm.group(1)] = args
+    jl = open(os.path.join(root, "julia", "NMFkHIP.jl")).read()
+    lib = ctypes.CDLL(os.path.join(root, "nmfk.jl_amd", "libnmfk_hip.so"))
+    calls = list(re.finditer(r"ccall\(\(:(\w+),\s*libnmfk\),\s*(\w+),\s*\(", jl))
+    assert len(calls) >= 8
+    for mm in calls:
+        name = mm.group(1)
+        assert name in protos, f"{name} is not declared in include/nmfk_hip.h"
+        assert hasattr(lib, name), f"{name} is not exported by libnmfk_hip.so"
+        i, depth, start = mm.end(), 1, mm.end()  # argument-type tuple: up to its closing parenthesis
+        while depth:
+            depth += {"(": 1, ")": -1}.get(jl[i], 0)
+            i += 1
+        jtypes = _split_top(jl[start:i - 1])
+        cargs = protos[name]
+        assert len(jtypes) == len(cargs), (name, jtypes, cargs)
+        for jt, ca in zip(jtypes, cargs):
+            is_ptr = "*" in ca or "[" in ca
+            if is_ptr:
+                assert jt.startswith(("Ptr{", "Ref{")) or jt == "Cstring", (name, jt, ca)
+            elif "uint64_t" in ca:
+                assert jt in ("UInt64",), (name, jt, ca)
+            elif "int64_t" in ca:
+                assert jt in ("Int64", "Clonglong"), (name, jt, ca)
+            elif "double" in ca:
+                assert jt in ("Cdouble", "Float64"), (name, jt, ca)
+            elif re.search(r"\bint\b", ca):
+                assert jt in ("Cint", "Int32"), (name, jt, ca)

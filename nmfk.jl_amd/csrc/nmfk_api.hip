@@ -562,20 +562,35 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   if (const char *e = getenv("NMFK_MFMA_MINK")) mfma_mink = atoi(e);
   auto use_wide_k = [&](int k) { return wide_ok && k > 16; };
   auto use_mfma_k = [&](int k) { return wide_ok_nowide && k <= 16 && mfma_mink > 0 && k >= mfma_mink; };
-  // ranks in [hyb_mink, 16]: split-operand MFMA half-step (nmfk_step_hyb.hip), experimental and off by default:
-  // 1.26x faster than the packed-VALU kernel at k = 16 on a GPU filled with one rank (256 restarts), but slower inside
-  // the mixed sweep; enable with NMFK_HYB=1
-  int hyb_on = 0, hyb_mink = 5;
-  if (const char *e = getenv("NMFK_HYB")) hyb_on = atoi(e);
+  // ranks in [hyb_mink, 16]: split-operand MFMA half-step (nmfk_step_hyb.hip).  Its cost does not depend on the rank
+  // and ONE instantiation serves all ranks, so it pays where the sweep has few restarts per rank (8-GPU strong scaling):
+  // there the ranks >= 6 run as one mixed-rank launch group on it (MU loop of one rank's share at 8 GPUs 3.98 -> 3.16 s)
+  // and only the small ranks stay on the merged packed-VALU kernel.  With many restarts per rank it is 1.3x faster than
+  // the packed-VALU kernel at k = 16 on a GPU filled with one rank but slower inside the mixed sweep, so
+  // it stays off there.  NMFK_HYB=0 / 1 forces it off / on (on: per-rank launches for ranks >= NMFK_HYB_MINK = 5).
+  int hyb_on = -1, hyb_mink = -1;
+  if (const char *e = getenv("NMFK_HYB")) hyb_on = atoi(e) != 0;
   if (const char *e = getenv("NMFK_HYB_MINK")) hyb_mink = std::max(1, atoi(e));
+  int hyb_groups = 1;  // merged sweeps: number of mixed-rank launch groups of the split-operand MFMA kernel
+  if (const char *e = getenv("NMFK_HYB_GROUPS")) hyb_groups = std::max(1, atoi(e));
   int merge = -1;
-  if (const char *e = getenv("NMFK_MERGE")) merge = atoi(e);
+  const bool merge_env = getenv("NMFK_MERGE") != nullptr;
+  if (merge_env) merge = atoi(getenv("NMFK_MERGE"));
   if (merge < 0) merge = nruns <= NMFK_MERGE_MAX_RUNS ? std::min(nruns, NMFK_MERGE_GROUPS) : 0;
   if (ctx->sparse || mfma_mink > 0) merge = 0;
   merge = std::min(merge, nruns);
+  if (hyb_on < 0) {  // automatic: merged sweeps only (an explicit NMFK_MERGE keeps the packed-VALU groups)
+    hyb_on = merge > 0 && !merge_env;
+    if (hyb_on && hyb_mink < 0) hyb_mink = 6;
+    bool any = false;
+    for (int q = 0; q < nk; ++q)
+      any = any || (wide_ok_nowide && ks[q] <= 16 && ks[q] >= hyb_mink && (int64_t)n * m * 4 < ((int64_t)1 << 32) - 4096);
+    if (hyb_on && any) merge = 1;  // the few small ranks left: one packed-VALU group (126 vs 130 ms per 400 iterations)
+  }
+  if (hyb_mink < 0) hyb_mink = 5;
   auto use_hyb_k = [&](int k) {
     // (its buffer loads address X with 32-bit byte offsets from the array base)
-    return hyb_on && wide_ok_nowide && mfma_mink == 0 && merge == 0 && k <= 16 && k >= hyb_mink &&
+    return hyb_on && wide_ok_nowide && mfma_mink == 0 && k <= 16 && k >= hyb_mink &&
            (int64_t)n * m * 4 < ((int64_t)1 << 32) - 4096;
   };
   // lane elements per workgroup (= per sum-table slot) of the half-step kernel a rank runs
@@ -584,7 +599,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if (use_wide_k(k)) return nmfk_mfma_wide_lane_tile(ws);
     if (use_mfma_k(k)) return ws == 4 ? 64 : NMFK_TILE;
     if (use_hyb_k(k)) return nmfk_hyb_lane_tile(ws);
-    if (merge > 0 && k <= NMFK_MULTI_MAXK) return (ws > 1 ? 64 : NMFK_TILE) * NMFK_MULTI_LB;
+    if (merge > 0 && k <= NMFK_MULTI_MAXK && !use_hyb_k(k)) return (ws > 1 ? 64 : NMFK_TILE) * NMFK_MULTI_LB;
     return (ws > 1 ? 64 : NMFK_TILE) * NMFK_LB_OF(nmfk_padded_k(k));
   };
   int max_ws = 8;  // the experimental MFMA variant is written for 4-wave workgroups
@@ -633,6 +648,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   std::vector<size_t> o_Wi(nk, 0), o_Hi(nk, 0), o_Wo(nk), o_Ho(nk), o_frob(nk), o_iters(nk), o_reason(nk);
   struct Group {
     int k, kp, begin, count;
+    int hyb;  // split width of the split-operand MFMA kernel (8 / 16) when the group runs on it, else 0
   };
   // Launch groups = contiguous unit ranges.  Default: one group per rank (units sorted by k descending), each with its
   // own kernel instantiation and stream.  With few restarts per rank the per-rank launches are tiny and the loop is
@@ -644,14 +660,26 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   for (int oi = 0; oi < nk; ++oi) {
     const int q = order[oi], k = ks[q];
     if (merge > 0 && k <= NMFK_MULTI_MAXK) continue;
-    groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns});
+    groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns, use_hyb_k(k) ? (k <= 8 ? 8 : 16) : 0});
     for (int r = 0; r < nruns; ++r) ulist.push_back({q, r});
   }
-  for (int g = 0; g < merge; ++g) {
-    Group G{0, 0, (int)ulist.size(), 0};
+  // merged sweeps: the ranks of the split-operand MFMA kernel (its cost does not depend on the rank, one instantiation
+  // serves them all at split width 16) form mixed-rank groups of their own, the other ranks <= 16 the VALU ones
+  const int hg = merge > 0 ? std::min(hyb_groups, nruns) : 0;
+  for (int g = 0; g < hg; ++g) {
+    Group G{0, 0, (int)ulist.size(), 0, 16};
     for (int oi = 0; oi < nk; ++oi) {
       const int q = order[oi];
-      if (ks[q] > NMFK_MULTI_MAXK) continue;
+      if (ks[q] > NMFK_MULTI_MAXK || !use_hyb_k(ks[q])) continue;
+      for (int r = g; r < nruns; r += hg, ++G.count) ulist.push_back({q, r});
+    }
+    if (G.count > 0) groups.push_back(G);
+  }
+  for (int g = 0; g < merge; ++g) {
+    Group G{0, 0, (int)ulist.size(), 0, 0};
+    for (int oi = 0; oi < nk; ++oi) {
+      const int q = order[oi];
+      if (ks[q] > NMFK_MULTI_MAXK || use_hyb_k(ks[q])) continue;
       for (int r = g; r < nruns; r += merge, ++G.count) ulist.push_back({q, r});
     }
     if (G.count > 0) groups.push_back(G);
@@ -681,7 +709,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         rd.hyb = rd.ldWf = rd.ldHf = rd.pad0 = 0;
         rd.oWbf = rd.oHbf = rd.oWft = rd.oHft = 0;
         if (use_hyb_k(k)) {
-          const int KS = k <= 8 ? 8 : 16;
+          const int KS = (merge > 0 || k > 8) ? 16 : 8;
           rd.hyb = KS;
           rd.ldWf = ((n + 15) & ~15) + 16;
           rd.ldHf = ((m + 15) & ~15) + 16;
@@ -876,7 +904,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   auto use_wide = [&](const Group &G) { return use_wide_k(G.k); };
   const bool wide_sse = !(getenv("NMFK_MFMA_SSE") && atoi(getenv("NMFK_MFMA_SSE")) == 0);
   auto use_mfma = [&](const Group &G) { return use_mfma_k(G.k); };
-  auto use_hyb = [&](const Group &G) { return G.kp != 0 && use_hyb_k(G.k); };
+  auto use_hyb = [&](const Group &G) { return G.hyb != 0; };
   int max_streams = 8;
   if (const char *e = getenv("NMFK_STREAMS")) max_streams = std::max(1, std::min(64, atoi(e)));
   const int NS = std::min(ngroups, max_streams);
@@ -927,6 +955,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_sp_step_f64(&sph, G.kp, G.begin, G.count, gs);
         else if (sparse)
           nmfk_launch_sp_step_f32(&sph, G.kp, G.begin, G.count, gs);
+        else if (use_hyb(G))
+          nmfk_launch_step_hyb_f32(hs, d_hs, G.hyb, G.begin, G.count, gs);
         else if (G.kp == 0 && f64)
           nmfk_launch_step_multi_f64(hs, d_hs, G.begin, G.count, gs);
         else if (G.kp == 0)
@@ -937,8 +967,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_step_mfma_wide_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         else if (use_mfma(G))
           nmfk_launch_step_mfma_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
-        else if (use_hyb(G))
-          nmfk_launch_step_hyb_f32(hs, d_hs, G.k <= 8 ? 8 : 16, G.begin, G.count, gs);
         else
           nmfk_launch_step_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         if (timed) prof.end(e0, PK_HSTEP, j, it, gs);
@@ -957,6 +985,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_sp_step_f64(&spw, G.kp, G.begin, G.count, gs);
         else if (sparse)
           nmfk_launch_sp_step_f32(&spw, G.kp, G.begin, G.count, gs);
+        else if (use_hyb(G))
+          nmfk_launch_step_hyb_f32(ws, d_ws, G.hyb, G.begin, G.count, gs);
         else if (G.kp == 0 && f64)
           nmfk_launch_step_multi_f64(ws, d_ws, G.begin, G.count, gs);
         else if (G.kp == 0)
@@ -967,8 +997,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_step_mfma_wide_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         else if (use_mfma(G))
           nmfk_launch_step_mfma_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
-        else if (use_hyb(G))
-          nmfk_launch_step_hyb_f32(ws, d_ws, G.k <= 8 ? 8 : 16, G.begin, G.count, gs);
         else
           nmfk_launch_step_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         if (timed) prof.end(e0, PK_WSTEP, j, it, gs);

@@ -200,6 +200,34 @@ def test_split_operand_mfma_half_step_opt_in(NMFk, ctx, oracle, shape, k, R):
     assert _rel(fx["W"][0] @ fx["H"][0], ref["W"] @ ref["H"], X) <= 1e-4
 
 
+def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle):
+    """Sweeps with <= 4 restarts per rank (a rank's share at 8 GPUs): by default the ranks 6..16 run as ONE mixed-rank
+    launch group on the split-operand MFMA half-step, the smaller ranks on the merged packed-VALU kernel, wider ranks on
+    their own kernels.  Against the oracle (same tolerance as everywhere) and against the all-VALU grouping (NMFK_HYB=0)."""
+    n, m = 700, 130
+    X = (0.05 + oracle.uniform_fill(33, 0, n * m)).reshape(n, m).astype(np.float32)
+    ctx.set_X(X)
+    ks, R, iters = [2, 3, 5, 6, 8, 13, 16, 20], 4, 40
+    seeds = _seeds(NMFk, 11, ks, R)
+    a = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
+    os.environ["NMFK_HYB"] = "0"
+    try:
+        b = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
+    finally:
+        del os.environ["NMFK_HYB"]
+    for q, k in enumerate(ks):
+        for r in range(R):
+            e = _rel(a[k]["W"][r] @ a[k]["H"][r], b[k]["W"][r] @ b[k]["H"][r], X)
+            assert e <= 5e-6, (k, r, e)
+            if k < 6 or k > 16:
+                assert e == 0.0  # not on the MFMA group: the same kernels in both runs
+        W0, H0 = oracle.init_factors(int(seeds[q, 0]), n, m, k)
+        ref = oracle.singlerun(X, k, W0, H0, maxiter=iters, **NOSTOP)
+        assert _rel(a[k]["W"][0] @ a[k]["H"][0], ref["W"] @ ref["H"], X) <= 1e-4
+        assert abs(a[k]["objvalue"][0] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
+    assert max(_rel(a[13]["W"][r] @ a[13]["H"][r], b[13]["W"][r] @ b[13]["H"][r], X) for r in range(R)) > 0.0  # it did run
+
+
 @pytest.mark.parametrize("compute", ["f32", "f64"])
 def test_merged_launch_groups_bitwise_equal(NMFk, ctx, oracle, compute):
     """Few restarts per rank: ranks <= 16 share mixed-rank launches (step_kernel_multi, NMFK_MERGE).  Same arithmetic per

@@ -181,3 +181,42 @@ def test_julia_shim_binds_the_declared_c_abi():
                 assert jt in ("Cdouble", "Float64"), (name, jt, ca)
             elif re.search(r"\bint\b", ca):
                 assert jt in ("Cint", "Int32"), (name, jt, ca)
+
+
+def test_three_term_bf16_split_is_fp32_accurate():
+    """The numerics behind nmfk_step_hyb.hip, modelled in numpy: x = h + m + l with bf16 terms (round to nearest even,
+    residuals exact in fp32), inner products from the six term products of weight >= 2^-16 (hh, hm, mh, mm, hl, lh),
+    each exact in an fp32 accumulator.  The result is as close to the Float64 inner product as plain fp32 arithmetic."""
+    def bf16(x):  # round-to-nearest-even to 8 significand bits, kept as float32
+        u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16
+        return u.astype(np.uint32).view(np.float32)
+
+    def split3(x):
+        h = bf16(x)
+        r1 = (x - h).astype(np.float32)
+        m = bf16(r1)
+        r2 = (r1 - m).astype(np.float32)
+        return h, m, bf16(r2)
+
+    rng = np.random.default_rng(5)
+    k = 16
+    a = (rng.random((4096, k)) * rng.choice([1e-3, 1.0, 30.0], size=(4096, 1))).astype(np.float32)
+    b = rng.random((4096, k)).astype(np.float32)
+    ah, am, al = split3(a)
+    bh, bm, bl = split3(b)
+    # the residuals of the split are exact: h + m + l reproduces x to the last bf16 rounding of l (<= 2^-25 relative)
+    assert np.max(np.abs((ah.astype(np.float64) + am + al) - a) / a) <= 2.0 ** -24
+    exact = np.sum(a.astype(np.float64) * b.astype(np.float64), axis=1)
+    six = sum(np.sum(x.astype(np.float64) * y.astype(np.float64), axis=1)
+              for x, y in ((ah, bh), (ah, bm), (am, bh), (am, bm), (ah, bl), (al, bh)))
+    six32 = six.astype(np.float32)  # the accumulator is fp32
+    plain32 = np.zeros(4096, dtype=np.float32)
+    for c in range(k):
+        plain32 = (plain32 + a[:, c] * b[:, c]).astype(np.float32)
+    err_six = np.max(np.abs(six32 - exact) / exact)
+    err_plain = np.max(np.abs(plain32 - exact) / exact)
+    assert err_six <= 2.0 ** -22 and err_six <= 4 * err_plain
+    # a two-term split (the usual "bf16x3") would NOT be enough: 2^-16 relative
+    two = sum(np.sum(x.astype(np.float64) * y.astype(np.float64), axis=1) for x, y in ((ah, bh), (ah, bm), (am, bh)))
+    assert np.max(np.abs(two - exact) / exact) > 2.0 ** -19

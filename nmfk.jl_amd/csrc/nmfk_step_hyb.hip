@@ -451,7 +451,11 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
   double *sumA = (double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)) + (int64_t)tile * k;
   double *red = den + 16;  // [8][16]
   float vs[4] = {0.f, 0.f, 0.f, 0.f};
+#ifdef HYB_DBG_NOFIN
+  if (owner && acc[0][0] == 12345.f) {
+#else
   if (owner) {
+#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       if (lv[t]) {

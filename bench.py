@@ -30,8 +30,9 @@ PEAK_HBM_GBPS = 8000.0
 
 
 def _pmc_traffic():
-    """HBM bytes per launch of the dominant per-rank kernel, step_kernel<16> with 32 restarts (FETCH_SIZE x 2 +
-    WRITE_SIZE, collected in separate rocprofv3 --pmc runs of this command: profiles/r01/traffic.json); None if absent."""
+    """HBM bytes per launch of the dominant kernel (hyb_step_kernel<16,2,8>, 256 factorizations per launch):
+    FETCH_SIZE x 2 + WRITE_SIZE, collected in separate rocprofv3 --pmc runs of this command (scripts/profile_bench.sh,
+    scripts/make_traffic.py -> profiles/r01/traffic.json); None if absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as fh:
             t = json.load(fh)
@@ -175,16 +176,42 @@ def main():
                                     "TFLOPs_while_sharing_the_GPU": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
             dom = max(per_kp, key=lambda k_: prof[k_]["ms"]) if per_kp else None
             xbytes = sum(float(np.sum(iters_by_k[k])) for k in ks) * 2.0 * args.n * args.m * 4.0 * args.steps / max(world, 1)
-            line["roofline"] = {
-                "kernel": "step_kernel<KP> (half-step numerators + fused finish; all ranks, concurrent streams)",
-                "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
-                "traffic": _pmc_traffic(), "mu_loop_gpu_ms": loop["ms"], "dominant_rank_kernel": dom, "per_rank_kernel": per_kp,
-                "note": "flops = 4*n*m*k per half-step per ACTIVE restart (W*H and the product with the ratio; SURVEY 8d: "
-                        "8*n*m*k per iteration). fp32 vector and fp32 MFMA share the 157.3 TFLOP/s peak on gfx950; the "
-                        "kernel issues packed fp32 FMAs (v_pk_fma_f32). HBM view: X is L2/Infinity-Cache resident "
-                        "(2 x 16.8 MB), so the algorithmic X bytes below are served on-die, not by HBM.",
-                "hbm_algorithmic_GBps": xbytes / (loop["ms"] * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
-            }
+            whole = {"achieved": tf, "frac": tf / PEAK_FP32_TFLOPS, "mu_loop_gpu_ms": loop["ms"],
+                     "note": "algorithmic flops of ALL half-step launches / GPU time of the whole MU loop (HIP events)"}
+            if dom is not None and dom.endswith("<mfma>"):
+                # Two-phase sweep: the ranks 9..16 run first, as ONE mixed-rank launch group (256 factorizations per
+                # launch) with the GPU to themselves, so the sampled launch durations of that kernel are exclusive GPU time.
+                h, w = prof["h_step<mfma>"], prof["w_step<mfma>"]
+                tfd = (h["flops"] + w["flops"]) / ((h["ms"] + w["ms"]) * 1e-3) / 1e12
+                line["roofline"] = {
+                    "kernel": "hyb_step_kernel<16,2,8> (nmfk_step_hyb.hip): H and W half-step launches of the mixed-rank group "
+                              "(ranks 9..16 x 32 restarts = 256 factorizations per launch), alone on the GPU in phase 1 of the sweep",
+                    "bound": "mfma", "achieved": tfd, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tfd / PEAK_FP32_TFLOPS,
+                    "traffic": _pmc_traffic(),
+                    "avg_launch_ms": {"h_step": h["ms"] / h["launches"], "w_step": w["ms"] / w["launches"]},
+                    "sampled_launches": h["launches"] + w["launches"],
+                    "whole_mu_loop": whole, "per_rank_kernel": per_kp,
+                    "note": "flops = 4*n*m*k per half-step per ACTIVE restart (W*H and the product with the ratio; SURVEY 8d: "
+                            "8*n*m*k per iteration), launch durations from HIP events on the launching stream (every 47th "
+                            "iteration). The kernel computes W*H on the bf16 matrix pipe from exact three-term bf16 splits "
+                            "(fp32-accurate) and the numerators on the fp32 matrix pipe; the peak quoted is the fp32 MFMA = "
+                            "fp32 vector peak of gfx950. The other ranks (2..8) run afterwards on step_kernel<KP> (packed "
+                            "fp32 FMAs, concurrent streams); X is L2/Infinity-Cache resident, HBM is not the bound.",
+                    "hbm_algorithmic_GBps": xbytes / (loop["ms"] * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
+                }
+            else:
+                line["roofline"] = {
+                    "kernel": "step_kernel<KP> (half-step numerators + fused finish; all ranks, concurrent streams)",
+                    "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
+                    "traffic": _pmc_traffic(), "mu_loop_gpu_ms": loop["ms"], "dominant_rank_kernel": dom, "per_rank_kernel": per_kp,
+                    "note": "flops = 4*n*m*k per half-step per ACTIVE restart (W*H and the product with the ratio; SURVEY 8d: "
+                            "8*n*m*k per iteration). fp32 vector and fp32 MFMA share the 157.3 TFLOP/s peak on gfx950; the "
+                            "kernels issue packed fp32 FMAs (v_pk_fma_f32) or, for the mixed-rank group of few-restart sweeps, "
+                            "MFMAs. The rank groups run concurrently, so a launch's duration is not exclusive GPU time and the "
+                            "fraction is the aggregate over the MU loop. HBM view: X is L2/Infinity-Cache resident "
+                            "(2 x 16.8 MB), so the algorithmic X bytes below are served on-die, not by HBM.",
+                    "hbm_algorithmic_GBps": xbytes / (loop["ms"] * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
+                }
         if not args.no_cpu_baseline:
             threads = min(32, len(os.sched_getaffinity(0)))
             line["cpu_baseline"] = cpu_baseline(X, ks, args.nruns, iters_by_k, threads)

@@ -579,14 +579,29 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   if (merge < 0) merge = nruns <= NMFK_MERGE_MAX_RUNS ? std::min(nruns, NMFK_MERGE_GROUPS) : 0;
   if (ctx->sparse || mfma_mink > 0) merge = 0;
   merge = std::min(merge, nruns);
-  if (hyb_on < 0) {  // automatic: merged sweeps only (an explicit NMFK_MERGE keeps the packed-VALU groups)
-    hyb_on = merge > 0 && !merge_env;
-    if (hyb_on && hyb_mink < 0) hyb_mink = 6;
-    bool any = false;
+  // Two-phase sweep (many restarts per rank): the ranks >= 9 run FIRST, as one mixed-rank group on the split-operand
+  // MFMA kernel with the GPU to themselves (enough units to fill it: its fp32 MFMAs and the packed FMAs of the other
+  // ranks' kernels share the multipliers, so the two kinds must not run side by side), then the other ranks on their
+  // per-rank packed-VALU launches.  Bench sweep, 200 iterations: 401.8 -> 245.3 + 126.6 ms.  NMFK_HYB_PHASES=0 / 1.
+  bool hyb_phases = false;
+  const bool hyb_fits = wide_ok_nowide && mfma_mink == 0 && (int64_t)n * m * 4 < ((int64_t)1 << 32) - 4096;
+  if (hyb_on < 0) {  // automatic (an explicit NMFK_MERGE keeps the packed-VALU groups)
+    const int mk = hyb_mink >= 0 ? hyb_mink : (merge > 0 ? 6 : 9);
+    int hyb_units = 0;
     for (int q = 0; q < nk; ++q)
-      any = any || (wide_ok_nowide && ks[q] <= 16 && ks[q] >= hyb_mink && (int64_t)n * m * 4 < ((int64_t)1 << 32) - 4096);
-    if (hyb_on && any) merge = 1;  // the few small ranks left: one packed-VALU group (126 vs 130 ms per 400 iterations)
+      if (hyb_fits && ks[q] <= 16 && ks[q] >= mk) hyb_units += nruns;
+    if (merge > 0 && !merge_env) {  // few restarts per rank: merged sweep, the ranks >= 6 as one group beside the small ones
+      hyb_on = 1;
+      if (hyb_units > 0) merge = 1;  // the few small ranks left: one packed-VALU group (126 vs 130 ms per 400 iterations)
+    } else if (merge == 0 && !merge_env && hyb_units >= 256) {  // (16 restarts per rank: 221 vs 216 ms, no gain)
+      hyb_on = 1;
+      hyb_phases = true;
+    } else {
+      hyb_on = 0;
+    }
+    hyb_mink = mk;
   }
+  if (const char *e = getenv("NMFK_HYB_PHASES")) hyb_phases = hyb_on && merge == 0 && atoi(e) != 0;
   if (hyb_mink < 0) hyb_mink = 5;
   auto use_hyb_k = [&](int k) {
     // (its buffer loads address X with 32-bit byte offsets from the array base)
@@ -605,12 +620,15 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   int max_ws = 8;  // the experimental MFMA variant is written for 4-wave workgroups
   if (const char *e = getenv("NMFK_MFMA_MINK")) max_ws = atoi(e) > 0 ? 4 : 8;
   if (const char *e = getenv("NMFK_MAX_WSPLIT")) max_ws = atoi(e) >= 8 ? 8 : 4;
-  auto geometry = [&](int L, int D) {
+  // phases of a two-phase sweep run one after the other, so each gets the geometry that fills the chip with ITS units
+  auto phase_of_k = [&](int k) { return hyb_phases && !use_hyb_k(k) ? 1 : 0; };
+  auto geometry = [&](int L, int D, int phase) {
     Geo g;
-    auto wgs = [&](int ws) {  // workgroups of one half-step over all units
+    auto wgs = [&](int ws) {  // workgroups of one half-step over all units of the phase
       int64_t t = 0;
-      for (int q = 0; q < nk; ++q) t += (int64_t)((L + lane_tile(ks[q], ws) - 1) / lane_tile(ks[q], ws)) * nruns;
-      return t;
+      for (int q = 0; q < nk; ++q)
+        if (phase_of_k(ks[q]) == phase) t += (int64_t)((L + lane_tile(ks[q], ws) - 1) / lane_tile(ks[q], ws)) * nruns;
+      return std::max<int64_t>(t, 1);
     };
     g.wsplit = 1;
     if (wgs(1) < target) g.wsplit = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
@@ -625,16 +643,20 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     }
     g.fused = g.S == 1;
     g.slots = 1;  // slots of the sum tables = the most lane tiles any rank's kernel uses
-    for (int q = 0; q < nk; ++q) g.slots = std::max(g.slots, (L + lane_tile(ks[q], g.wsplit) - 1) / lane_tile(ks[q], g.wsplit));
+    for (int q = 0; q < nk; ++q)
+      if (phase_of_k(ks[q]) == phase)
+        g.slots = std::max(g.slots, (L + lane_tile(ks[q], g.wsplit) - 1) / lane_tile(ks[q], g.wsplit));
     return g;
   };
-  Geo gh = geometry(m, n), gw = geometry(n, m);
+  Geo ghp[2] = {geometry(m, n, 0), geometry(m, n, hyb_phases ? 1 : 0)};
+  Geo gwp[2] = {geometry(n, m, 0), geometry(n, m, hyb_phases ? 1 : 0)};
   if (ctx->sparse) {  // gather kernels: one lane element per thread, always finished in-kernel
-    gh = Geo{1, 1, n, 1, (m + NMFK_TILE - 1) / NMFK_TILE};
-    gw = Geo{1, 1, m, 1, (n + NMFK_TILE - 1) / NMFK_TILE};
+    ghp[0] = ghp[1] = Geo{1, 1, n, 1, (m + NMFK_TILE - 1) / NMFK_TILE};
+    gwp[0] = gwp[1] = Geo{1, 1, m, 1, (n + NMFK_TILE - 1) / NMFK_TILE};
   }
-  const int Sh = gh.S, Sw = gw.S;
-  const int PH = gh.slots, PW = gw.slots;  // slots of the sum tables: rowsum(H) is produced by the H half-step
+  const int Sh = std::max(ghp[0].S, ghp[1].S), Sw = std::max(gwp[0].S, gwp[1].S);  // (sizes the partial-numerator buffers)
+  // slots of the sum tables (rowsum(H) is produced by the H half-step): one table size for all units
+  const int PH = std::max(ghp[0].slots, ghp[1].slots), PW = std::max(gwp[0].slots, gwp[1].slots);
   const int tiles_n = (n + NMFK_TILE - 1) / NMFK_TILE;  // objective kernel tiles
 
   // arena layout
@@ -642,13 +664,14 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   const size_t o_runs = B.take(sizeof(NmfkRun) * nunits);
   const size_t o_state = B.take(sizeof(NmfkState) * nunits);
   const size_t o_flag = B.take(256);
-  const size_t o_args = B.take(2 * sizeof(NmfkStepArgs));
+  const size_t o_args = B.take(4 * sizeof(NmfkStepArgs));
   const size_t o_ptrs = B.take(sizeof(void *) * 7 * nk);
   std::vector<NmfkRun> runs(nunits);
   std::vector<size_t> o_Wi(nk, 0), o_Hi(nk, 0), o_Wo(nk), o_Ho(nk), o_frob(nk), o_iters(nk), o_reason(nk);
   struct Group {
     int k, kp, begin, count;
-    int hyb;  // split width of the split-operand MFMA kernel (8 / 16) when the group runs on it, else 0
+    int hyb;    // split width of the split-operand MFMA kernel (8 / 16) when the group runs on it, else 0
+    int phase;  // groups of phase 0 run to the end before those of phase 1 start
   };
   // Launch groups = contiguous unit ranges.  Default: one group per rank (units sorted by k descending), each with its
   // own kernel instantiation and stream.  With few restarts per rank the per-rank launches are tiny and the loop is
@@ -660,14 +683,15 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   for (int oi = 0; oi < nk; ++oi) {
     const int q = order[oi], k = ks[q];
     if (merge > 0 && k <= NMFK_MULTI_MAXK) continue;
-    groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns, use_hyb_k(k) ? (k <= 8 ? 8 : 16) : 0});
+    if (hyb_phases && use_hyb_k(k)) continue;
+    groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns, use_hyb_k(k) ? (k <= 8 ? 8 : 16) : 0, hyb_phases ? 1 : 0});
     for (int r = 0; r < nruns; ++r) ulist.push_back({q, r});
   }
   // merged sweeps: the ranks of the split-operand MFMA kernel (its cost does not depend on the rank, one instantiation
   // serves them all at split width 16) form mixed-rank groups of their own, the other ranks <= 16 the VALU ones
-  const int hg = merge > 0 ? std::min(hyb_groups, nruns) : 0;
+  const int hg = (merge > 0 || hyb_phases) ? std::min(hyb_groups, nruns) : 0;
   for (int g = 0; g < hg; ++g) {
-    Group G{0, 0, (int)ulist.size(), 0, 16};
+    Group G{0, 0, (int)ulist.size(), 0, 16, 0};
     for (int oi = 0; oi < nk; ++oi) {
       const int q = order[oi];
       if (ks[q] > NMFK_MULTI_MAXK || !use_hyb_k(ks[q])) continue;
@@ -676,7 +700,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if (G.count > 0) groups.push_back(G);
   }
   for (int g = 0; g < merge; ++g) {
-    Group G{0, 0, (int)ulist.size(), 0, 0};
+    Group G{0, 0, (int)ulist.size(), 0, 0, 0};
     for (int oi = 0; oi < nk; ++oi) {
       const int q = order[oi];
       if (ks[q] > NMFK_MULTI_MAXK || use_hyb_k(ks[q])) continue;
@@ -704,12 +728,13 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         rd.ocanon = (int64_t)B.take(sizeof(int32_t) * (size_t)m);
         rd.seed = seeds ? seeds[(size_t)q * nruns + r] : 0;
         // slots the unit's kernels write: the fused half-step one per lane tile, the grid-parallel helpers any count
+        const Geo &gh = ghp[phase_of_k(k)], &gw = gwp[phase_of_k(k)];
         rd.nsH = gh.fused ? (m + lane_tile(k, gh.wsplit) - 1) / lane_tile(k, gh.wsplit) : PH;
         rd.nsW = gw.fused ? (n + lane_tile(k, gw.wsplit) - 1) / lane_tile(k, gw.wsplit) : PW;
         rd.hyb = rd.ldWf = rd.ldHf = rd.pad0 = 0;
         rd.oWbf = rd.oHbf = rd.oWft = rd.oHft = 0;
         if (use_hyb_k(k)) {
-          const int KS = (merge > 0 || k > 8) ? 16 : 8;
+          const int KS = (merge > 0 || hyb_phases || k > 8) ? 16 : 8;
           rd.hyb = KS;
           rd.ldWf = ((n + 15) & ~15) + 16;
           rd.ldHf = ((m + 15) & ~15) + 16;
@@ -809,10 +834,10 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   hs.ld = m;
   hs.L = m;
   hs.D = n;
-  hs.S = Sh;
-  hs.dchunk = gh.dchunk;
-  hs.wsplit = gh.wsplit;
-  hs.fused = gh.fused;
+  hs.S = ghp[0].S;
+  hs.dchunk = ghp[0].dchunk;
+  hs.wsplit = ghp[0].wsplit;
+  hs.fused = ghp[0].fused;
   hs.PW = PW;
   hs.PH = PH;
   hs.which = 0;
@@ -830,17 +855,28 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ws.ld = n;
   ws.L = n;
   ws.D = m;
-  ws.S = Sw;
-  ws.dchunk = gw.dchunk;
-  ws.wsplit = gw.wsplit;
-  ws.fused = gw.fused;
+  ws.S = gwp[0].S;
+  ws.dchunk = gwp[0].dchunk;
+  ws.wsplit = gwp[0].wsplit;
+  ws.fused = gwp[0].fused;
   ws.which = 1;
+  // one pair of half-step argument blocks per phase (they differ in the launch geometry only)
+  NmfkStepArgs hsP[2] = {hs, hs}, wsP[2] = {ws, ws};
+  hsP[1].S = ghp[1].S;
+  hsP[1].dchunk = ghp[1].dchunk;
+  hsP[1].wsplit = ghp[1].wsplit;
+  hsP[1].fused = ghp[1].fused;
+  wsP[1].S = gwp[1].S;
+  wsP[1].dchunk = gwp[1].dchunk;
+  wsP[1].wsplit = gwp[1].wsplit;
+  wsP[1].fused = gwp[1].fused;
 
-  // device copies of the two half-step argument blocks (constant over the sweep; `it` is passed by value)
-  const NmfkStepArgs *d_hs = (const NmfkStepArgs *)(A + o_args), *d_ws = d_hs + 1;
+  // device copies of the half-step argument blocks (constant over the sweep; `it` is passed by value)
+  const NmfkStepArgs *d_hsP[2] = {(const NmfkStepArgs *)(A + o_args), (const NmfkStepArgs *)(A + o_args) + 2};
+  const NmfkStepArgs *d_wsP[2] = {d_hsP[0] + 1, d_hsP[1] + 1};
   {
-    NmfkStepArgs both[2] = {hs, ws};
-    HIPCHECK(hipMemcpy(A + o_args, both, sizeof(both), hipMemcpyHostToDevice));
+    NmfkStepArgs all4[4] = {hsP[0], wsP[0], hsP[1], wsP[1]};
+    HIPCHECK(hipMemcpy(A + o_args, all4, sizeof(all4), hipMemcpyHostToDevice));
   }
 
   NmfkSseArgs sa;
@@ -934,19 +970,31 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   const bool guard0 = P.maxiter > 0 && P.maxbaditers > 0 && P.maxreattempts > 0;
   NmfkState *snap[2] = {(NmfkState *)ctx->pinned, (NmfkState *)ctx->pinned + nunits};
   int total_iters = 0;
-  int nchecks = 0;
-  bool all_done = !guard0;
   const int maxiter = guard0 ? (int)P.maxiter : 0;
   double host_wait_s = 0;  // time the host spent waiting for the GPU inside the loop (NMFK_HOST_TIMING=1 prints it)
   const auto loop_w0 = std::chrono::steady_clock::now();
+  int nphases = 1;
+  for (const Group &G : groups) nphases = std::max(nphases, G.phase + 1);
+  std::vector<char> in_phase(nunits);
+  for (int phase = 0; phase < nphases; ++phase) {
+  // (units still active when a phase's loop ends ran all `maxiter` iterations, so one total_iters serves every phase)
+  for (int u = 0; u < nunits; ++u) in_phase[u] = 0;
+  for (const Group &G : groups)
+    if (G.phase == phase)
+      for (int u = G.begin; u < G.begin + G.count; ++u) in_phase[u] = 1;
+  int nchecks = 0;
+  bool all_done = !guard0;
   for (int it = 0; it < maxiter && !all_done; ++it) {
     const bool check = (it + 1) % 10 == 0;  // Mult:73
     const bool timed = prof.want(it);
-    hs.it = ws.it = it;
+    hsP[0].it = hsP[1].it = wsP[0].it = wsP[1].it = it;
     sa.hsel = (it + 1) & 1;
     ca.it = it;
     for (int j = 0; j < ngroups; ++j) {
       const Group &G = groups[j];
+      if (G.phase != phase) continue;
+      const NmfkStepArgs &hs = hsP[G.phase], &ws = wsP[G.phase];
+      const NmfkStepArgs *d_hs = d_hsP[G.phase], *d_ws = d_wsP[G.phase];
       hipStream_t gs = ctx->gstreams[j % NS];
       if (!P.Hfixed) {  // Mult:66-68
         const size_t e0 = timed ? prof.begin(gs) : 0;
@@ -1030,7 +1078,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         if (use_hyb(G)) nmfk_launch_hyb_forms(A, d_runs, n, m, (it + 1) & 1, 3, G.begin, G.count, gs);
       }
     }
-    total_iters = it + 1;
+    total_iters = std::max(total_iters, it + 1);
     if (check) {
       const int slot = nchecks & 1;
       if (nchecks > 0) {  // inspect the PREVIOUS check while this one is still queued
@@ -1038,7 +1086,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         HIPCHECK(hipEventSynchronize(snap_ev[slot ^ 1]));
         host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
         bool any = false;
-        for (int u = 0; u < nunits; ++u) any = any || snap[slot ^ 1][u].active;
+        for (int u = 0; u < nunits; ++u) any = any || (in_phase[u] && snap[slot ^ 1][u].active);
         if (!any) all_done = true;
       }
       for (int j = 0; j < NS; ++j) {
@@ -1050,6 +1098,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       nchecks++;
     }
   }
+  if (phase + 1 < nphases) {  // the next phase starts on an empty GPU
+    for (int j = 0; j < NS; ++j) HIPCHECK(hipStreamSynchronize(ctx->gstreams[j]));
+    HIPCHECK(hipStreamSynchronize(poll));
+  }
+  }  // phases
   if (getenv("NMFK_HOST_TIMING"))
     fprintf(stderr, "[nmfk] loop: %d iterations, %d groups, host %.3f s of which waiting for the GPU %.3f s\n", total_iters,
             ngroups, std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_w0).count(), host_wait_s);
@@ -1178,7 +1231,10 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       for (int u = G.begin; u < G.begin + G.count; ++u)
         active_k += sm.it < h_iters[runs[u].kidx][runs[u].ridx] ? runs[u].k : 0;
       char name[64];
-      snprintf(name, sizeof(name), "%s<%d>", sm.kind == PK_HSTEP ? "h_step" : "w_step", G.kp);
+      if (G.kp == 0 && G.hyb)  // mixed-rank group on the split-operand MFMA kernel
+        snprintf(name, sizeof(name), "%s<mfma>", sm.kind == PK_HSTEP ? "h_step" : "w_step");
+      else
+        snprintf(name, sizeof(name), "%s<%d>", sm.kind == PK_HSTEP ? "h_step" : "w_step", G.kp);
       auto &E = ctx->prof[name];
       E.ms += ms;
       E.launches += 1;

@@ -200,6 +200,54 @@ def test_split_operand_mfma_half_step_opt_in(NMFk, ctx, oracle, shape, k, R):
     assert _rel(fx["W"][0] @ fx["H"][0], ref["W"] @ ref["H"], X) <= 1e-4
 
 
+def test_two_phase_sweep_many_restarts(NMFk, ctx, oracle):
+    """Sweeps with >= 256 units of ranks 9..16 (the bench sweep): those ranks run first, as one mixed-rank group on the
+    split-operand MFMA half-step, then the other ranks on their per-rank kernels (nmfk_mu_sweep, two phases with their own
+    launch geometry).  Fixed budget against the oracle and against the one-phase packed-VALU sweep (NMFK_HYB=0); then the
+    default stop rule, where the units of a phase stop at different times."""
+    n, m = 600, 260
+    ks, R, iters = [3] + list(range(9, 17)), 32, 30
+    X = (0.05 + oracle.uniform_fill(41, 0, n * m)).reshape(n, m).astype(np.float32)
+    ctx.set_X(X)
+    seeds = _seeds(NMFk, 13, ks, R)
+    a = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
+    os.environ["NMFK_HYB"] = "0"
+    try:
+        b = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
+    finally:
+        del os.environ["NMFK_HYB"]
+    worst = 0.0
+    for k in ks:
+        assert (a[k]["iters"] == iters).all()
+        for r in range(R):
+            e = _rel(a[k]["W"][r] @ a[k]["H"][r], b[k]["W"][r] @ b[k]["H"][r], X)
+            assert e <= 5e-6, (k, r, e)
+            worst = max(worst, e) if k >= 9 else worst
+    assert worst > 0.0  # the ranks >= 9 did run on the other kernel
+    for k, r in ((9, 0), (16, 31), (3, 5)):
+        W0, H0 = oracle.init_factors(int(seeds[ks.index(k), r]), n, m, k)
+        ref = oracle.singlerun(X, k, W0, H0, maxiter=iters, **NOSTOP)
+        assert _rel(a[k]["W"][r] @ a[k]["H"][r], ref["W"] @ ref["H"], X) <= 1e-4
+        assert abs(a[k]["objvalue"][r] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
+    # default stop rule on a planted rank-3 matrix: restarts stop at different checks, phase by phase
+    W0 = oracle.uniform_fill(42, 0, n * 3).reshape(n, 3)
+    H0 = oracle.uniform_fill(43, 0, 3 * m).reshape(3, m)
+    Xp = (W0 @ H0 + 0.01 * oracle.uniform_fill(44, 0, n * m).reshape(n, m)).astype(np.float32)
+    ctx.set_X(Xp)
+    loose = dict(maxiter=400, tolOF=2.0, maxbaditers=2, maxreattempts=1)  # stops once a check improves the SSE by < 2
+    a = ctx.mu_sweep(ks, R, seeds=seeds, **loose)
+    os.environ["NMFK_HYB"] = "0"
+    try:
+        b = ctx.mu_sweep(ks, R, seeds=seeds, **loose)
+    finally:
+        del os.environ["NMFK_HYB"]
+    for k in ks:
+        assert (a[k]["reason"] != 0).all() and (a[k]["iters"] <= 400).all() and (a[k]["iters"] % 10 == 0).all()
+        assert (np.abs(a[k]["iters"] - b[k]["iters"]) <= 10).all()  # fp32 noise may move a stop by one check
+        np.testing.assert_allclose(a[k]["objvalue"], b[k]["objvalue"], rtol=5e-2)
+    assert len({int(i) for k in ks for i in a[k]["iters"]}) > 2  # they did stop at different times
+
+
 def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle):
     """Sweeps with <= 4 restarts per rank (a rank's share at 8 GPUs): by default the ranks 6..16 run as ONE mixed-rank
     launch group on the split-operand MFMA half-step, the smaller ranks on the merged packed-VALU kernel, wider ranks on

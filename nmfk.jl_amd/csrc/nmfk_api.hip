@@ -586,14 +586,18 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   bool hyb_phases = false;
   const bool hyb_fits = wide_ok_nowide && mfma_mink == 0 && (int64_t)n * m * 4 < ((int64_t)1 << 32) - 4096;
   if (hyb_on < 0) {  // automatic (an explicit NMFK_MERGE keeps the packed-VALU groups)
-    const int mk = hyb_mink >= 0 ? hyb_mink : (merge > 0 ? 6 : 9);
+    // first rank of the group: 9 with 32 restarts per rank (381 vs 406 ms per 200 iterations), 12 with 16 (313 vs 331 ms
+    // per 300; 9: 221 vs 216 per 200), none with 8 (151 vs 120)
+    // (24 restarts: 9 -> 331, 12 -> 303 vs 320 ms one phase; 20: 281 / 259 vs 274; 12 restarts: no difference)
+    const int mk = hyb_mink >= 0 ? hyb_mink : (nruns <= 8 ? 6 : (nruns >= 32 ? 9 : 12));
     int hyb_units = 0;
     for (int q = 0; q < nk; ++q)
       if (hyb_fits && ks[q] <= 16 && ks[q] >= mk) hyb_units += nruns;
-    if (merge > 0 && !merge_env) {  // few restarts per rank: merged sweep, the ranks >= 6 as one group beside the small ones
+    const bool few = !merge_env && !ctx->sparse && mfma_mink == 0 && nruns <= 8 && hyb_units > 0;  // (8 restarts: 177-179 vs 186 ms)
+    if ((merge > 0 && !merge_env) || few) {  // few restarts per rank: merged sweep, the ranks >= 6 as one group beside the small ones
       hyb_on = 1;
       if (hyb_units > 0) merge = 1;  // the few small ranks left: one packed-VALU group (126 vs 130 ms per 400 iterations)
-    } else if (merge == 0 && !merge_env && hyb_units >= 256) {  // (16 restarts per rank: 221 vs 216 ms, no gain)
+    } else if (merge == 0 && !merge_env && nruns >= 16 && hyb_units >= 64) {
       hyb_on = 1;
       hyb_phases = true;
     } else {

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NMFK_TILE) void init_kernel(NmfkInitArgs g) {  // g
     s.have_old = 0;
     s.active = 1;
     s.reason = 0;
-    s.pad = 0;
+    s.clamped = 0;
     g.state[u] = s;
   }
 }
@@ -1597,6 +1597,7 @@ __global__ void check_a_kernel(NmfkCheckArgs g, int u0, int cnt) {
   double obj = 0;
   for (int t = 0; t < g.ntile_n; ++t) obj += NMFK_PTR(const double, g, rd.ossepart)[t];
   st->last_obj = obj;
+  st->clamped = 0;  // set by clamp_kernel (next in the stream) when it changes a value
   if (obj < g.tol) {  // Mult:75-78: leaves the loop before the clamp
     st->active = 0;
     st->reason = NMFK_STOP_TOL;
@@ -1643,7 +1644,10 @@ __global__ __launch_bounds__(NMFK_TILE) void clamp_kernel(NmfkCheckArgs g, int u
     slot_range(len, P, b, l0, l1);
     for (int64_t e = (int64_t)l0 * kp + tid; e < (int64_t)l1 * kp; e += NMFK_TILE) {
       const T v = F[e];
-      if ((int)(e % kp) < k && v < eps) F[e] = eps;
+      if ((int)(e % kp) < k && v < eps) {
+        F[e] = eps;
+        g.state[u].clamped = 1;  // (benign race: every writer stores 1)
+      }
     }
     __syncthreads();
     range_signal_sums(F, kp, k, l0, l1, tab + (int64_t)b * kp, sh);

@@ -248,6 +248,26 @@ def test_two_phase_sweep_many_restarts(NMFk, ctx, oracle):
     assert len({int(i) for k in ks for i in a[k]["iters"]}) > 2  # they did stop at different times
 
 
+def test_mfma_group_refreshes_its_operand_forms_after_a_clamp(NMFk, ctx, oracle):
+    """Initial factors with exact zeros stay zero under the multiplicative update until the clamp of a check lifts them to
+    eps(Float64) (Mult:99-100); the split-operand MFMA kernel then has to rebuild its bf16 / transposed operand forms of
+    those units (and only of those: hyb_forms_kernel is skipped for the others).  Oracle parity over three checks."""
+    n, m, k, R = 300, 70, 7, 3
+    X = oracle.uniform_fill(11, 0, n * m).reshape(n, m).astype(np.float32)
+    ctx.set_X(X)
+    W0, H0 = oracle.init_factors(123, n, m, k)
+    W0[::3, 1] = 0.0
+    H0[2, ::4] = 0.0
+    Wi = {k: np.broadcast_to(W0.astype(np.float32), (R, n, k)).copy()}
+    Hi = {k: np.broadcast_to(H0.astype(np.float32), (R, k, m)).copy()}
+    Wi[k][1:] = oracle.init_factors(124, n, m, k)[0].astype(np.float32)  # the other restarts have nothing to clamp
+    res = ctx.mu_sweep([k], R, Winit=Wi, Hinit=Hi, maxiter=35, **NOSTOP)[k]
+    ref = oracle.singlerun(X, k, W0.astype(np.float32), H0.astype(np.float32), maxiter=35, **NOSTOP)
+    assert _rel(res["W"][0] @ res["H"][0], ref["W"] @ ref["H"], X) <= 1e-4
+    assert abs(res["objvalue"][0] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
+    assert (res["W"][0][::3, 1] > 0).all()  # lifted by the clamp, then updated
+
+
 def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle):
     """Sweeps with <= 4 restarts per rank (a rank's share at 8 GPUs): by default the ranks 6..16 run as ONE mixed-rank
     launch group on the split-operand MFMA half-step, the smaller ranks on the merged packed-VALU kernel, wider ranks on

@@ -945,6 +945,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   const bool wide_sse = !(getenv("NMFK_MFMA_SSE") && atoi(getenv("NMFK_MFMA_SSE")) == 0);
   auto use_mfma = [&](const Group &G) { return use_mfma_k(G.k); };
   auto use_hyb = [&](const Group &G) { return G.hyb != 0; };
+  const bool hyb_sse = !(getenv("NMFK_HYB_SSE") && atoi(getenv("NMFK_HYB_SSE")) == 0);  // objective of those groups on the matrix pipe
   int max_streams = 8;
   if (const char *e = getenv("NMFK_STREAMS")) max_streams = std::max(1, std::min(64, atoi(e)));
   const int NS = std::min(ngroups, max_streams);
@@ -1069,6 +1070,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             nmfk_launch_sp_obj_f32(&spw, n, m, (it + 1) & 1, 0, P.weight, G.begin, G.count, gs);
         } else if (f64) {
           nmfk_launch_sse_f64(sa, G.begin, G.count, gs);
+        } else if (use_hyb(G) && sa.Wgt == nullptr && hyb_sse) {
+          nmfk_launch_hyb_sse(A, wsP[0].Xtile, d_runs, d_state, n, m, P.weight, G.hyb, G.begin, G.count, gs);
         } else if (use_wide(G) && sa.Wgt == nullptr && wide_sse) {
           nmfk_launch_sse_mfma_wide_f32(sa, G.kp, G.begin, G.count, gs);
         } else {

@@ -250,6 +250,8 @@ void nmfk_launch_step_mfma_wide_f32(const NmfkStepArgs &a, const NmfkStepArgs *d
 int nmfk_mfma_wide_lane_tile(int wsplit);
 int nmfk_hyb_lane_tile(int wsplit);
 void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int ks, int u0, int cnt, hipStream_t s);
+void nmfk_launch_hyb_sse(char *arena, const float *Xtile_w, const NmfkRun *runs, const NmfkState *state, int n, int m,
+                         double weight, int ks, int u0, int cnt, hipStream_t s);
 void nmfk_launch_hyb_tile(const float *src, int L, int D, float *out, hipStream_t s);
 void nmfk_launch_hyb_forms(char *arena, const NmfkRun *runs, const NmfkState *state_if_clamped, int n, int m, int hpar,
                            int mask, int u0, int cnt, hipStream_t s);

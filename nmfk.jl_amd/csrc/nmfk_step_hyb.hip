@@ -502,6 +502,84 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Monitored objective (Mult:74) of the units of the split-operand MFMA group: sum(((X - W*H) * weight)^2) with W*H from
+// the same three-term bf16 products as the half-step (fp32-accurate), residuals squared and accumulated in fp64.
+// Dense X without missing entries, scalar weight.  Lanes = rows of X (W orientation: tiled copy Xt of the W half-step,
+// loop over the columns = rows of H's split form).  Grid ((n + 255) / 256, units), 256 threads: a wave owns 4 tiles of
+// 16 rows; one partial per workgroup in ossepart[] like sse_kernel.
+// ------------------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(NMFK_TILE) void hyb_sse_kernel(char *arena, const float *__restrict__ Xt,
+                                                            const NmfkRun *__restrict__ runs,
+                                                            const NmfkState *__restrict__ state, int n, int m, double weight,
+                                                            int u0) {
+  __shared__ double sh[8];
+  constexpr int NT = 4, NM = KS == 16 ? 3 : 2, SUBMASK = KS == 16 ? 1 : 0, ROWB = 3 * KS * 2;
+  const int u = u0 + blockIdx.y;
+  if (!state[u].active) return;
+  const NmfkRun *__restrict__ rdp = runs + u;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int L = n, D = m, nD16 = (D + 15) >> 4, nL16 = (L + 15) >> 4;
+  const int l0 = blockIdx.x * NMFK_TILE + wave * 64;
+  const char *__restrict__ Abf = arena + rdp->oWbf;  // lane factor W
+  const char *__restrict__ Bbf = arena + rdp->oHbf;  // loop factor H
+  bf16x8_t bop[NT][NM];
+  bool lv[NT];
+  uint32_t xoff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int l = l0 + 16 * t + c16;
+    lv[t] = l < L;
+    const int lt = lv[t] ? l : 0;
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+      const int sb = hyb_sb<KS>(j, g);
+      u32x4_t w = {0u, 0u, 0u, 0u};
+      if (lv[t] && sb >= 0) w = *(const u32x4_t *)(Abf + ((int64_t)lt * 3 + sb) * (KS * 2) + 16 * (g & SUBMASK));
+      bop[t][j] = __builtin_bit_cast(bf16x8_t, w);
+    }
+    xoff[t] = (uint32_t)(((int64_t)min((l0 >> 4) + t, nL16 - 1) * nD16 * 256 + lane * 4) * 4);
+  }
+  uint32_t aoff[NM];
+#pragma unroll
+  for (int j = 0; j < NM; ++j) aoff[j] = (uint32_t)(c16 * ROWB + hyb_sa<KS>(j, g) * (KS * 2) + 16 * (g & SUBMASK));
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)Xt, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void *)Bbf, 0, -1, 0x00020000);
+  double ssum = 0.0;
+  for (int dch = 0; dch < D; dch += 16) {  // (the split rows are zero-padded by 16, the tiled X by whole blocks)
+    f32x4_t xv[NT], p[NT];
+    u32x4_t av[NM];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      xv[t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, xoff[t], dch * 64, 0));
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+      av[j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsa, aoff[j], dch * ROWB, 0));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[j]), bop[t][j], p[t], 0, 0, 0);
+    const bool full = dch + 16 <= D;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = xv[t][r] - p[t][r];
+        const double e2 = (double)e * (double)e;
+        ssum += (lv[t] && (full || dch + 4 * g + r < D)) ? e2 : 0.0;
+      }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ssum += __shfl_down(ssum, o, 64);
+  if (lane == 0) sh[wave] = ssum;
+  __syncthreads();
+  if (tid == 0) ((double *)(arena + rdp->ossepart))[blockIdx.x] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) * weight * weight;
+}
+
 }  // namespace
 
 #ifndef NMFK_HYB_NT
@@ -540,4 +618,14 @@ void nmfk_launch_hyb_tile(const float *src, int L, int D, float *out, hipStream_
   const int64_t total = (int64_t)((L + 15) / 16) * ((D + 15) / 16) * 256;
   const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (total + NMFK_TILE - 1) / NMFK_TILE));
   hipLaunchKernelGGL(hyb_tile_kernel, dim3(nb), dim3(NMFK_TILE), 0, s, src, L, D, out);
+}
+
+// monitored objective of the units [u0, u0 + cnt) of a group on the split-operand MFMA kernel (active units only)
+void nmfk_launch_hyb_sse(char *arena, const float *Xtile_w, const NmfkRun *runs, const NmfkState *state, int n, int m,
+                         double weight, int ks, int u0, int cnt, hipStream_t s) {
+  const dim3 grid((n + NMFK_TILE - 1) / NMFK_TILE, cnt), blk(NMFK_TILE);
+  if (ks == 8)
+    hipLaunchKernelGGL((hyb_sse_kernel<8>), grid, blk, 0, s, arena, Xtile_w, runs, state, n, m, weight, u0);
+  else
+    hipLaunchKernelGGL((hyb_sse_kernel<16>), grid, blk, 0, s, arena, Xtile_w, runs, state, n, m, weight, u0);
 }

@@ -268,6 +268,30 @@ def test_mfma_group_refreshes_its_operand_forms_after_a_clamp(NMFk, ctx, oracle)
     assert (res["W"][0][::3, 1] > 0).all()  # lifted by the clamp, then updated
 
 
+def test_mfma_group_monitored_objective(NMFk, ctx, oracle):
+    """The objective the stop rule monitors (Mult:74) comes from hyb_sse_kernel for the units of the MFMA group: bracket it
+    with the tolerance test of Mult:75-78 -- with tol just above the oracle's SSE after 10 iterations every restart must
+    stop there with STOP_TOL, with tol just below none may."""
+    n, m, k, R = 530, 200, 13, 4
+    X = (0.05 + oracle.uniform_fill(51, 0, n * m)).reshape(n, m).astype(np.float32)
+    ctx.set_X(X)
+    seeds = _seeds(NMFk, 17, [k], R)
+    sse = []
+    for r in range(R):
+        W0, H0 = oracle.init_factors(int(seeds[0, r]), n, m, k)
+        ref = oracle.singlerun(X, k, W0, H0, maxiter=10, **NOSTOP)
+        sse.append(float(np.sum((X.astype(np.float64) - ref["W"] @ ref["H"]) ** 2)))  # modifymatrices does not change W*H
+    hi = ctx.mu_sweep([k], R, seeds=seeds, maxiter=40, tol=max(sse) * (1 + 2e-5))[k]
+    lo = ctx.mu_sweep([k], R, seeds=seeds, maxiter=40, tol=min(sse) * 0.5)[k]
+    assert (hi["iters"] == 10).all() and (hi["reason"] == NMFk.STOP_TOL).all()
+    assert (lo["iters"] > 10).all()
+    for r in range(R):  # one at a time, tightly: stops iff tol > its own SSE
+        one = ctx.mu_sweep([k], R, seeds=seeds, maxiter=20, tol=sse[r] * (1 - 2e-5))[k]
+        assert one["iters"][r] > 10
+        one = ctx.mu_sweep([k], R, seeds=seeds, maxiter=20, tol=sse[r] * (1 + 2e-5))[k]
+        assert one["iters"][r] == 10 and one["reason"][r] == NMFk.STOP_TOL
+
+
 def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle):
     """Sweeps with <= 4 restarts per rank (a rank's share at 8 GPUs): by default the ranks 6..16 run as ONE mixed-rank
     launch group on the split-operand MFMA half-step, the smaller ranks on the merged packed-VALU kernel, wider ranks on

@@ -814,7 +814,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   for (int q = 0; q < nk; ++q) any_hyb = any_hyb || use_hyb_k(ks[q]);
   const size_t tile_h = (size_t)((m + 15) / 16) * ((n + 15) / 16) * 256, tile_w = tile_h;  // floats
   if (any_hyb) {
-    nmfk_launch_hyb_forms(A, d_runs, nullptr, n, m, 0, 3, 0, nunits, st);
+    nmfk_launch_hyb_forms(A, d_runs, n, m, 0, 3, 0, nunits, st);
     if (ctx->xtile_gen != ctx->xgen) {
       if (ctx->xtile.ensure(sizeof(float) * (tile_h + tile_w))) return fail(NMFK_ERR_HIP, "out of device memory (tiled X)");
       nmfk_launch_hyb_tile(ctx->Xc, m, n, (float *)ctx->xtile.p, st);           // H half-step: lanes = columns
@@ -1028,7 +1028,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             nmfk_launch_reduce_f64(hs, G.begin, G.count, gs);
           else
             nmfk_launch_reduce_f32(hs, G.begin, G.count, gs);
-          if (use_hyb(G)) nmfk_launch_hyb_forms(A, d_runs, nullptr, n, m, (it + 1) & 1, 2, G.begin, G.count, gs);
+          if (use_hyb(G)) nmfk_launch_hyb_forms(A, d_runs, n, m, (it + 1) & 1, 2, G.begin, G.count, gs);
         }
       }
       if (!P.Wfixed) {  // Mult:69-71
@@ -1058,7 +1058,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             nmfk_launch_reduce_f64(ws, G.begin, G.count, gs);
           else
             nmfk_launch_reduce_f32(ws, G.begin, G.count, gs);
-          if (use_hyb(G)) nmfk_launch_hyb_forms(A, d_runs, nullptr, n, m, (it + 1) & 1, 1, G.begin, G.count, gs);
+          if (use_hyb(G)) nmfk_launch_hyb_forms(A, d_runs, n, m, (it + 1) & 1, 1, G.begin, G.count, gs);
         }
       }
       if (check) {
@@ -1081,8 +1081,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_check_f64(ca, G.begin, G.count, gs);
         else
           nmfk_launch_check_f32(ca, G.begin, G.count, gs);
-        // the clamp (Mult:99-100) rewrote both factors
-        if (use_hyb(G)) nmfk_launch_hyb_forms(A, d_runs, d_state, n, m, (it + 1) & 1, 3, G.begin, G.count, gs);
       }
     }
     total_iters = std::max(total_iters, it + 1);

@@ -43,7 +43,7 @@ struct NmfkState {
   int32_t have_old;  // consold is not the initial falses(m,m)
   int32_t active;    // still inside the while loop
   int32_t reason;    // NMFK_STOP_*
-  int32_t clamped;   // the clamp of the last check (Mult:99-100) changed a value of this unit's factors
+  int32_t pad;
 };
 
 // Arguments of one half-step over all units.  lane dimension L (contiguous in the X copy used), loop
@@ -253,8 +253,8 @@ void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, 
 void nmfk_launch_hyb_sse(char *arena, const float *Xtile_w, const NmfkRun *runs, const NmfkState *state, int n, int m,
                          double weight, int ks, int u0, int cnt, hipStream_t s);
 void nmfk_launch_hyb_tile(const float *src, int L, int D, float *out, hipStream_t s);
-void nmfk_launch_hyb_forms(char *arena, const NmfkRun *runs, const NmfkState *state_if_clamped, int n, int m, int hpar,
-                           int mask, int u0, int cnt, hipStream_t s);
+void nmfk_launch_hyb_forms(char *arena, const NmfkRun *runs, int n, int m, int hpar, int mask, int u0, int cnt,
+                           hipStream_t s);
 void nmfk_launch_sse_mfma_wide_f32(const NmfkSseArgs &a, int kp, int u0, int cnt, hipStream_t s);
 void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f64)

@@ -61,17 +61,14 @@ __device__ __forceinline__ void split3(float v, uint32_t &h, uint32_t &m, uint32
 }
 
 // ------------------------------------------------------------------------------------------------------
-// bf16 split rows and transposed fp32 copy of a factor from its fp32 rows (after init, clamp and reduce; the fused
-// half-step writes them itself).  Grid (slices, units); mask bit 0: W, bit 1: H (buffer parity hpar).
+// bf16 split rows and transposed fp32 copy of a factor from its fp32 rows (after init and reduce; the fused half-step
+// writes them itself and clamp_kernel patches the entries it lifts to eps).  Grid (slices, units); mask bit 0: W, bit 1: H (buffer parity hpar).
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NMFK_TILE) void hyb_forms_kernel(char *arena, const NmfkRun *__restrict__ runs,
-                                                             const NmfkState *__restrict__ state_if_clamped, int n, int m,
+__global__ __launch_bounds__(NMFK_TILE) void hyb_forms_kernel(char *arena, const NmfkRun *__restrict__ runs, int n, int m,
                                                              int hpar, int mask, int u0) {
   const NmfkRun *__restrict__ rdp = runs + u0 + blockIdx.y;
   const int KS = rdp->hyb, k = rdp->k, kp = rdp->kp;
   if (KS == 0) return;
-  // after a check: only the units whose factors the clamp actually changed (almost never: 0.8 ms per check saved)
-  if (state_if_clamped && !state_if_clamped[u0 + blockIdx.y].clamped) return;
   for (int f = 0; f < 2; ++f) {
     if (!((mask >> f) & 1)) continue;
     const int L = f == 0 ? n : m, ld = f == 0 ? rdp->ldWf : rdp->ldHf;
@@ -607,10 +604,10 @@ void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, 
     hipLaunchKernelGGL((hyb_step_kernel<16, NT, NW>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0);
 }
 
-void nmfk_launch_hyb_forms(char *arena, const NmfkRun *runs, const NmfkState *state_if_clamped, int n, int m, int hpar,
-                           int mask, int u0, int cnt, hipStream_t s) {
+void nmfk_launch_hyb_forms(char *arena, const NmfkRun *runs, int n, int m, int hpar, int mask, int u0, int cnt,
+                           hipStream_t s) {
   const int nb = std::max(1, std::min(32, (std::max(n, m) + 16 + NMFK_TILE - 1) / NMFK_TILE));
-  hipLaunchKernelGGL(hyb_forms_kernel, dim3(nb, cnt), dim3(NMFK_TILE), 0, s, arena, runs, state_if_clamped, n, m, hpar, mask, u0);
+  hipLaunchKernelGGL(hyb_forms_kernel, dim3(nb, cnt), dim3(NMFK_TILE), 0, s, arena, runs, n, m, hpar, mask, u0);
 }
 
 // tiled copy of X (element (l, d) at src[d + l*D]) for nmfk_launch_step_hyb_f32; out: roundup16(L) * roundup16(D) floats

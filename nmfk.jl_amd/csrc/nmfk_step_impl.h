@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NMFK_TILE) void init_kernel(NmfkInitArgs g) {  // g
     s.have_old = 0;
     s.active = 1;
     s.reason = 0;
-    s.clamped = 0;
+    s.pad = 0;
     g.state[u] = s;
   }
 }
@@ -1597,7 +1597,6 @@ __global__ void check_a_kernel(NmfkCheckArgs g, int u0, int cnt) {
   double obj = 0;
   for (int t = 0; t < g.ntile_n; ++t) obj += NMFK_PTR(const double, g, rd.ossepart)[t];
   st->last_obj = obj;
-  st->clamped = 0;  // set by clamp_kernel (next in the stream) when it changes a value
   if (obj < g.tol) {  // Mult:75-78: leaves the loop before the clamp
     st->active = 0;
     st->reason = NMFK_STOP_TOL;
@@ -1646,7 +1645,14 @@ __global__ __launch_bounds__(NMFK_TILE) void clamp_kernel(NmfkCheckArgs g, int u
       const T v = F[e];
       if ((int)(e % kp) < k && v < eps) {
         F[e] = eps;
-        g.state[u].clamped = 1;  // (benign race: every writer stores 1)
+        if (rd.hyb) {  // unit of the split-operand MFMA kernel: patch its operand forms (eps = 2^-52 is a bf16 number)
+          const int l = (int)(e / kp), c = (int)(e % kp), KS = rd.hyb;
+          unsigned short *bf = (unsigned short *)(g.arena + (f == 0 ? rd.oWbf : rd.oHbf)) + (int64_t)l * 3 * KS + c;
+          bf[0] = 0x2580;  // 2^-52
+          bf[KS] = 0;
+          bf[2 * KS] = 0;
+          ((float *)(g.arena + (f == 0 ? rd.oWft : rd.oHft)))[(int64_t)c * (f == 0 ? rd.ldWf : rd.ldHf) + l] = (float)eps;
+        }
       }
     }
     __syncthreads();

@@ -248,10 +248,10 @@ def test_two_phase_sweep_many_restarts(NMFk, ctx, oracle):
     assert len({int(i) for k in ks for i in a[k]["iters"]}) > 2  # they did stop at different times
 
 
-def test_mfma_group_refreshes_its_operand_forms_after_a_clamp(NMFk, ctx, oracle):
+def test_mfma_group_operand_forms_follow_the_clamp(NMFk, ctx, oracle):
     """Initial factors with exact zeros stay zero under the multiplicative update until the clamp of a check lifts them to
-    eps(Float64) (Mult:99-100); the split-operand MFMA kernel then has to rebuild its bf16 / transposed operand forms of
-    those units (and only of those: hyb_forms_kernel is skipped for the others).  Oracle parity over three checks."""
+    eps(Float64) (Mult:99-100); clamp_kernel patches the bf16 / transposed operand forms of the split-operand MFMA kernel
+    for exactly those entries (eps = 2^-52 is a bf16 number).  Oracle parity over three checks."""
     n, m, k, R = 300, 70, 7, 3
     X = oracle.uniform_fill(11, 0, n * m).reshape(n, m).astype(np.float32)
     ctx.set_X(X)

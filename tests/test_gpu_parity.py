@@ -290,6 +290,11 @@ def test_mfma_group_monitored_objective(NMFk, ctx, oracle):
         assert one["iters"][r] > 10
         one = ctx.mu_sweep([k], R, seeds=seeds, maxiter=20, tol=sse[r] * (1 + 2e-5))[k]
         assert one["iters"][r] == 10 and one["reason"][r] == NMFk.STOP_TOL
+    # a scalar weight scales the monitored objective by weight^2 (Mult:74)
+    w2 = ctx.mu_sweep([k], R, seeds=seeds, maxiter=20, weight=2.0, tol=4.0 * max(sse) * (1 + 2e-5))[k]
+    assert (w2["iters"] == 10).all() and (w2["reason"] == NMFk.STOP_TOL).all()
+    w2 = ctx.mu_sweep([k], R, seeds=seeds, maxiter=20, weight=2.0, tol=4.0 * min(sse) * (1 - 2e-5))[k]
+    assert (w2["iters"] > 10).all()
 
 
 def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle):

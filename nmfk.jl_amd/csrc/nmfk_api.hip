@@ -591,13 +591,18 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     // (24 restarts: 9 -> 331, 12 -> 303 vs 320 ms one phase; 20: 281 / 259 vs 274; 12 restarts: no difference)
     const int mk = hyb_mink >= 0 ? hyb_mink : (nruns <= 8 ? 6 : (nruns >= 32 ? 9 : 12));
     int hyb_units = 0;
+    double hyb_score = 0;  // ~ what the group saves: the packed-VALU cost of a unit grows with k, the group's does not
     for (int q = 0; q < nk; ++q)
-      if (hyb_fits && ks[q] <= 16 && ks[q] >= mk) hyb_units += nruns;
+      if (hyb_fits && ks[q] <= 16 && ks[q] >= mk) {
+        hyb_units += nruns;
+        hyb_score += (ks[q] - 8.8) * nruns;
+      }
     const bool few = !merge_env && !ctx->sparse && mfma_mink == 0 && nruns <= 8 && hyb_units > 0;  // (8 restarts: 177-179 vs 186 ms)
     if ((merge > 0 && !merge_env) || few) {  // few restarts per rank: merged sweep, the ranks >= 6 as one group beside the small ones
       hyb_on = 1;
       if (hyb_units > 0) merge = 1;  // the few small ranks left: one packed-VALU group (126 vs 130 ms per 400 iterations)
-    } else if (merge == 0 && !merge_env && nruns >= 16 && hyb_units >= 64) {
+    } else if (merge == 0 && !merge_env && nruns >= 16 && hyb_units >= 64 && hyb_score >= 300) {
+      // (score 947 / 416: the bench sweep at 32 / 16 restarts, -14 % / -11 %; 218: k = 2:12 x 32, +2 %; 45: k = 2:10 x 32, +7 %)
       hyb_on = 1;
       hyb_phases = true;
     } else {

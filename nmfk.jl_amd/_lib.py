@@ -84,6 +84,7 @@ def lib():
                                     ip, C.POINTER(C.c_double), ip, ip, ip, C.c_void_p, C.c_void_p]
     L.nmfk_frobenius.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_double)]
     L.nmfk_set_profiling.argtypes = [vp, C.c_int]
+    L.nmfk_last_sweep_info.argtypes = [vp, C.POINTER(C.c_int32)]
     L.nmfk_get_profile.argtypes = [vp, C.c_int, C.c_void_p, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double),
                                    C.POINTER(C.c_int)]
     _lib = L
@@ -315,6 +316,13 @@ class Context:
         out = C.c_double()
         _check(lib().nmfk_frobenius(self._h, W.shape[1], W.ctypes.data, H.ctypes.data, C.byref(out)))
         return out.value
+
+    def last_sweep_info(self):
+        """nmfk_last_sweep_info: the launch schedule the last mu_sweep on this context took."""
+        info = (C.c_int32 * 8)()
+        _check(lib().nmfk_last_sweep_info(self._h, info))
+        return dict(phases=info[0], mfma_group_units=info[1], merged_valu_groups=info[2], launch_groups=info[3],
+                    wide_mfma_units=info[4], shared_x_units=info[5], shared_x_width=info[6])
 
     def set_profiling(self, on=True):
         _check(lib().nmfk_set_profiling(self._h, int(on)))

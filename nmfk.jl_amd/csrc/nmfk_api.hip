@@ -99,6 +99,7 @@ struct nmfk_ctx {
     int64_t launches = 0;
   };
   std::map<std::string, ProfEntry> prof;
+  int32_t sweep_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // nmfk_last_sweep_info
 };
 
 namespace {
@@ -489,6 +490,12 @@ NMFK_EXPORT int nmfk_set_profiling(nmfk_ctx *ctx, int enabled) {
   if (!ctx) return fail(NMFK_ERR_BAD_ARG, "ctx is null");
   ctx->profiling = enabled != 0;
   ctx->prof.clear();
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_last_sweep_info(nmfk_ctx *ctx, int32_t info[8]) {
+  if (!ctx || !info) return fail(NMFK_ERR_BAD_ARG, "bad argument");
+  memcpy(info, ctx->sweep_info, sizeof(ctx->sweep_info));
   return NMFK_OK;
 }
 
@@ -985,6 +992,17 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   const auto loop_w0 = std::chrono::steady_clock::now();
   int nphases = 1;
   for (const Group &G : groups) nphases = std::max(nphases, G.phase + 1);
+  {
+    int32_t *si = ctx->sweep_info;
+    memset(si, 0, sizeof(ctx->sweep_info));
+    si[0] = nphases;
+    si[3] = ngroups;
+    for (const Group &G : groups) si[2] += (G.kp == 0 && !G.hyb) ? 1 : 0;
+    for (int u = 0; u < nunits; ++u) {
+      si[1] += runs[u].hyb ? 1 : 0;
+      si[4] += use_wide_k(runs[u].k) ? 1 : 0;
+    }
+  }
   std::vector<char> in_phase(nunits);
   for (int phase = 0; phase < nphases; ++phase) {
   // (units still active when a phase's loop ends ran all `maxiter` iterations, so one total_iters serves every phase)

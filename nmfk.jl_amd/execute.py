@@ -259,9 +259,11 @@ def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1
             Wa, Ha, Wv, Hv = ctx.cluster_stats(Ws, Hs, labels)  # Fin:64-77
             extra.update(Wvar=Wv, Hvar=Hv)
     elif not best:
-        # Exec:648 -> Fin:114-118: mean(Wa[1]; dims=2), mean(Ha[1]; dims=1) of the first solution
-        Wa = WBig[sel[0]].mean(axis=1, keepdims=True)
-        Ha = HBig[sel[0]].mean(axis=0, keepdims=True)
+        # Exec:648 -> Fin:114-118: finalize(WBig[idxsol], HBig[idxsol]) masks the UNSORTED vectors with idxsol and takes
+        # mean(Wa[1]; dims=2), mean(Ha[1]; dims=1) of the first survivor in restart order (not the lowest objective)
+        first = int(np.flatnonzero(idxsol)[0])
+        Wa = WBig[first].mean(axis=1, keepdims=True)
+        Ha = HBig[first].mean(axis=0, keepdims=True)
     if best:
         Wa, Ha = Wbest, Hbest  # Exec:655-658
     phi_final = ctx.frobenius(Wa, Ha)  # Exec:664-667 (E[isnan] = 0 then norm == normnan)

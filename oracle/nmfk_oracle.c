@@ -249,9 +249,10 @@ EXPORT int nmfk_or_multiplicative_ex(double *X, int64_t n, int64_t m, int64_t k,
         baditers = 0;
       }
       const double eps = 2.220446049250313e-16; /* eps() is Float64 eps regardless of T, Mult:99-100 */
-      for (int64_t i = 0; i < k * m; i++) H[i] = H[i] > eps ? H[i] : eps;
+      /* Julia's max propagates NaN: max(NaN, eps()) = NaN, so a NaN factor entry stays NaN */
+      for (int64_t i = 0; i < k * m; i++) H[i] = H[i] < eps ? eps : H[i];
       for (int64_t i = 0; i < n * k; i++) {
-        W[i] = W[i] > eps ? W[i] : eps;
+        W[i] = W[i] < eps ? eps : W[i];
       }
       for (int64_t i = 0; i < n; i++)
         for (int64_t a = 0; a < k; a++) Wt[a + i * k] = W[i + a * n];
@@ -259,9 +260,11 @@ EXPORT int nmfk_or_multiplicative_ex(double *X, int64_t n, int64_t m, int64_t k,
        * Canonical form: label every column by the first column of its class. */
       for (int64_t a = 0; a < k; a++) first[a] = -1;
       for (int64_t q = 0; q < m; q++) {
-        int64_t am = 0; /* argmin: first minimum (Julia) */
-        for (int64_t a = 1; a < k; a++)
-          if (H[a + q * k] < H[am + q * k]) am = a;
+        int64_t am = 0; /* argmin: first minimum; the first NaN wins (Julia's argmin) */
+        for (int64_t a = 1; a < k; a++) {
+          if (isnan(H[am + q * k])) break;
+          if (isnan(H[a + q * k]) || H[a + q * k] < H[am + q * k]) am = a;
+        }
         index[q] = am;
         if (first[am] < 0) first[am] = q;
         canon[q] = first[am];

@@ -369,8 +369,14 @@ def execute_run(X, nk, nNMF, inits, acceptratio=1, acceptfactor=math.inf, best=T
         if not best:
             Wm, Hm, Wv, Hv = cluster_stats(Ws, Hs, labels)
             out.update(Wmean=Wm.astype(npT), Hmean=Hm.astype(npT), Wvar=Wv.astype(npT), Hvar=Hv.astype(npT))
-    if best or nk == 1:
+    if best:
         Wa, Ha = Wbest, Hbest  # Exec:655-658
+    elif nk == 1:
+        # Exec:648 -> Fin:114-118: finalize(WBig[idxsol], HBig[idxsol]) -- the mask built for the SORTED list is
+        # applied to the unsorted vectors; the first survivor's W (n x 1) and H (1 x m), means over the unit dimension
+        first = int(np.flatnonzero(idxsol)[0])
+        Wa = WBig[first].mean(axis=1, keepdims=True)
+        Ha = HBig[first].mean(axis=0, keepdims=True)
     else:
         Wa, Ha = out["Wmean"], out["Hmean"]
     E = np.asarray(X, dtype=np.float64) - np.asarray(Wa, dtype=npT) @ np.asarray(Ha, dtype=npT)  # Exec:664-667

@@ -26,10 +26,7 @@ struct NmfkRun {
   int32_t nsW, nsH;  // slots of the sum tables this unit's kernels write (<= PW, PH); the others stay zero
   // split-operand MFMA half-step (nmfk_step_hyb.hip): hyb = split width KS (8 or 16; 0 = unit does not use it)
   int32_t hyb;
-  int32_t ldWf, ldHf;  // row lengths of the transposed copies (multiple of 16, >= length + 16, zero padded)
   int32_t pad0;
-  int64_t oWbf, oHbf;  // bf16[(len + 16)][3][KS] split rows (x = h + m + l), padding rows zero
-  int64_t oWft, oHft;  // float[KS][ld] transposed copies
 };
 
 // Stop-rule state machine of NMFmultiplicative (Mult:57-63), one per unit, device resident.
@@ -250,11 +247,12 @@ void nmfk_launch_step_mfma_wide_f32(const NmfkStepArgs &a, const NmfkStepArgs *d
 int nmfk_mfma_wide_lane_tile(int wsplit);
 int nmfk_hyb_lane_tile(int wsplit);
 void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int ks, int u0, int cnt, hipStream_t s);
-void nmfk_launch_hyb_sse(char *arena, const float *Xtile_w, const NmfkRun *runs, const NmfkState *state, int n, int m,
-                         double weight, int ks, int u0, int cnt, hipStream_t s);
+void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double weight, int hsel, int ks, int u0, int cnt,
+                         hipStream_t s);
 void nmfk_launch_hyb_tile(const float *src, int L, int D, float *out, hipStream_t s);
-void nmfk_launch_hyb_forms(char *arena, const NmfkRun *runs, int n, int m, int hpar, int mask, int u0, int cnt,
-                           hipStream_t s);
+// nmfk_step_shx.hip: packed-VALU half-step with X shared by several restarts of one rank per workgroup
+int nmfk_shx_width(int k);
+void nmfk_launch_step_shx_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s);
 void nmfk_launch_sse_mfma_wide_f32(const NmfkSseArgs &a, int kp, int u0, int cnt, hipStream_t s);
 void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f64)

@@ -11,9 +11,11 @@
 //     term blocks at once -> 3 or 2 MFMAs of 16 cycles per 16 x 16 tile of P;
 //   * Q = X ./ P on the VALU (v_rcp_f32 + mul), it comes out of the MFMA in B-operand layout;
 //   * N += B' Q on the matrix pipe in plain fp32 (v_mfma_f32_16x16x4_f32, 4 per tile), no rounding of Q.
-// A factor is therefore kept in three forms: fp32 rows [L][k] (results, finish, objective), bf16 split rows
-// [L+16][3][KS] (first product, as lane factor and as loop factor) and fp32 transposed [KS][ld] (second product, as
-// loop factor: a lane's four loop steps are one 16-byte load).  The fused finish writes all three.
+// A factor lives in HBM in ONE form, its fp32 rows [L][k].  The operand forms of the two products -- bf16 split rows for
+// the first, a transposed fp32 block for the second -- exist only in LDS: the waves of a workgroup read 64 loop rows
+// of the loop factor once, split them on the fly and lay them out for the matrix pipe (HybStage); the lane factor's
+// split blocks are built in registers before the loop.  (Round 1 kept three forms of every factor in HBM and the
+// fused finish wrote all of them: 470 MB per launch of 256 factorizations, more than the half-step's X traffic.)
 #include "nmfk_common.h"
 #include "../../include/nmfk_hip.h"
 #include <algorithm>
@@ -61,37 +63,6 @@ __device__ __forceinline__ void split3(float v, uint32_t &h, uint32_t &m, uint32
 }
 
 // ------------------------------------------------------------------------------------------------------
-// bf16 split rows and transposed fp32 copy of a factor from its fp32 rows (after init and reduce; the fused half-step
-// writes them itself and clamp_kernel patches the entries it lifts to eps).  Grid (slices, units); mask bit 0: W, bit 1: H (buffer parity hpar).
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NMFK_TILE) void hyb_forms_kernel(char *arena, const NmfkRun *__restrict__ runs, int n, int m,
-                                                             int hpar, int mask, int u0) {
-  const NmfkRun *__restrict__ rdp = runs + u0 + blockIdx.y;
-  const int KS = rdp->hyb, k = rdp->k, kp = rdp->kp;
-  if (KS == 0) return;
-  for (int f = 0; f < 2; ++f) {
-    if (!((mask >> f) & 1)) continue;
-    const int L = f == 0 ? n : m, ld = f == 0 ? rdp->ldWf : rdp->ldHf;
-    const float *__restrict__ F = (const float *)(arena + (f == 0 ? rdp->oWt : NMFK_HOFF(*rdp, hpar)));
-    unsigned short *__restrict__ bf = (unsigned short *)(arena + (f == 0 ? rdp->oWbf : rdp->oHbf));
-    float *__restrict__ ft = (float *)(arena + (f == 0 ? rdp->oWft : rdp->oHft));
-    for (int l = blockIdx.x * NMFK_TILE + threadIdx.x; l < ld; l += gridDim.x * NMFK_TILE) {
-      for (int c = 0; c < KS; ++c) {
-        const float v = (l < L && c < k) ? F[c + (int64_t)l * kp] : 0.0f;
-        ft[(int64_t)c * ld + l] = v;
-        if (l < L + 16) {
-          uint32_t h, mm, lo;
-          split3(v, h, mm, lo);
-          bf[((int64_t)l * 3 + 0) * KS + c] = (unsigned short)h;
-          bf[((int64_t)l * 3 + 1) * KS + c] = (unsigned short)mm;
-          bf[((int64_t)l * 3 + 2) * KS + c] = (unsigned short)lo;
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------
 // tiled copy of X for one half-step: src element (l, d) at src[d + l*D]; out block (l / 16, d / 16) = 256 floats in
 // the order the MFMA layout consumes them: float index ((g*16 + c16)*4 + r) <-> l = 16 tl + c16, d = 16 td + 4g + r.
 // ------------------------------------------------------------------------------------------------------
@@ -109,38 +80,143 @@ __global__ __launch_bounds__(NMFK_TILE) void hyb_tile_kernel(const float *__rest
 }
 
 // ------------------------------------------------------------------------------------------------------
-// the half-step.  A wave owns NT tiles of 16 lane elements; workgroup = 4 waves with their own tiles (wsplit = 1) or
-// wsplit waves sharing NT tiles and splitting the loop range.  Lane (c16 = lane & 15, g = lane >> 4).
+// Staging of the loop factor.  A block = CPB chunks of 16 loop rows.  The GT threads of a staging group (the whole
+// workgroup when its waves walk the same loop range, a single wave otherwise) read the block's fp32 rows from
+// memory -- item = (row, pair of adjacent signals), NI items per thread, coalesced because the rows of a factor are
+// contiguous -- split every value into its three bf16 terms and write the two operand forms into an LDS buffer:
+//   [0, BFB)      split rows   row r at r*RS: term t at t*KS*2, signal c at 2c       (A operand of the first product)
+//   [BFB, STB)    transposed   chunk ch, signal c at (ch*16 + c)*FRS: 16 loop steps   (A operand of the second product)
+// RS / FRS: the b128 reads of 16 lanes hit 16 different groups of 4 banks (64 banks).
+// Rows at or beyond the factor's last row are staged as zeros; the caller masks the ratios of the loop steps beyond
+// its own range.
 // ------------------------------------------------------------------------------------------------------
-template <int KS, int NT, int NW>  // NW: waves per workgroup when wsplit = 1 (4 or 8)
+template <int KS, int CPB, int GT, bool WITH_T>
+struct HybStage {
+  static constexpr int RS = KS == 16 ? 112 : 48, FRS = 80;
+  static constexpr int BFB = 16 * CPB * RS, STB = BFB + (WITH_T ? CPB * 16 * FRS : 0);
+  static constexpr int PPR = KS / 2;                   // signal pairs per row
+  static constexpr int NITEM = 16 * CPB * PPR, NI = (NITEM + GT - 1) / GT;
+  uint32_t voff[NI], lsp[NI], ltr[NI];
+  int rr[NI];
+  bool pv[NI], c0[NI], c1[NI];
+  __amdgpu_buffer_rsrc_t rs;
+  int rowbytes, dlim;
+
+  // F: fp32 rows of the loop factor (row stride k floats), D rows; gt: thread index inside the staging group
+  __device__ __forceinline__ void init(const float *F, int k, int D, int gt) {
+    rs = __builtin_amdgcn_make_buffer_rsrc((void *)F, 0, -1, 0x00020000);
+    rowbytes = k * 4;
+    dlim = D;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int q = gt + GT * i;
+      pv[i] = q < NITEM;
+      const int qq = pv[i] ? q : 0, r = qq / PPR, cp = qq - r * PPR;
+      rr[i] = r;
+      voff[i] = (uint32_t)((r * k + 2 * cp) * 4);
+      c0[i] = 2 * cp < k;
+      c1[i] = 2 * cp + 1 < k;
+      lsp[i] = (uint32_t)(r * RS + cp * 4);
+      ltr[i] = (uint32_t)(BFB + ((r >> 4) * 16 + 2 * cp) * FRS + (r & 15) * 4);
+    }
+  }
+  // fetch the block that starts at loop row `row0`; rows past the factor's end and padding signals become zeros (a
+  // block reads at most 64 rows = 4 KB past the end of the array, inside the arena)
+  __device__ __forceinline__ void load(int row0, float (&v)[NI][2]) const {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (!pv[i]) continue;
+      const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[i], row0 * rowbytes, 0));
+      const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[i] + 4, row0 * rowbytes, 0));
+      const bool ok = row0 + rr[i] < dlim;
+      v[i][0] = (ok && c0[i]) ? a : 0.0f;
+      v[i][1] = (ok && c1[i]) ? b : 0.0f;
+    }
+  }
+  __device__ __forceinline__ void write(char *dst, const float (&v)[NI][2]) const {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (!pv[i]) continue;
+      uint32_t h0, m0, l0, h1, m1, l1;
+      split3(v[i][0], h0, m0, l0);
+      split3(v[i][1], h1, m1, l1);
+      *(uint32_t *)(dst + lsp[i]) = h0 | (h1 << 16);
+      *(uint32_t *)(dst + lsp[i] + KS * 2) = m0 | (m1 << 16);
+      *(uint32_t *)(dst + lsp[i] + KS * 4) = l0 | (l1 << 16);
+      if (WITH_T) {
+        *(float *)(dst + ltr[i]) = v[i][0];
+        *(float *)(dst + ltr[i] + FRS) = v[i][1];
+      }
+    }
+  }
+};
+
+// split blocks of the lane factor (B operand of the first product): 8 signals [8 * (g & SUBMASK), +8) of row `l` of
+// the fp32 rows A (row stride k), term hyb_sb(j, g) for MFMA j; rows that do not exist give zero blocks
+template <int KS, int NM>
+__device__ __forceinline__ void hyb_lane_blocks(const float *__restrict__ A, int k, int l, bool valid, int g,
+                                                bf16x8_t (&bop)[NM]) {
+  constexpr int SUBMASK = KS == 16 ? 1 : 0;
+  const int s0 = 8 * (g & SUBMASK);
+  uint32_t hh[4], mm[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t h[2], m[2], lo[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = s0 + 2 * i + e;
+      const float v = (valid && c < k) ? A[c + (int64_t)l * k] : 0.0f;
+      split3(v, h[e], m[e], lo[e]);
+    }
+    hh[i] = h[0] | (h[1] << 16);
+    mm[i] = m[0] | (m[1] << 16);
+    ll[i] = lo[0] | (lo[1] << 16);
+  }
+#pragma unroll
+  for (int j = 0; j < NM; ++j) {
+    const int sb = hyb_sb<KS>(j, g);
+    u32x4_t w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = sb == 0 ? hh[i] : sb == 1 ? mm[i] : sb == 2 ? ll[i] : 0u;
+    bop[j] = __builtin_bit_cast(bf16x8_t, w);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// the half-step.  A wave owns NT tiles of 16 lane elements; workgroup = NW waves with their own tiles (wsplit = 1) that
+// walk the same loop range and share the staged blocks, or wsplit waves sharing NT tiles and splitting the loop range
+// (each wave stages its own chunks).  Lane (c16 = lane & 15, g = lane >> 4).
+// ------------------------------------------------------------------------------------------------------
+// OBJ: the same walk computes the monitored objective (Mult:74) instead of a half-step: sum(((X - W*H) * weight)^2) with
+// W*H from the same three-term bf16 products (fp32-accurate), residuals squared and accumulated in fp64; W orientation
+// (gp = the W half-step's arguments, lanes = rows of X), whole loop range per workgroup, H of iteration parity `it`;
+// one partial per workgroup in ossepart[] like sse_kernel (256 rows per workgroup = its tile).
+template <int KS, int NT, int NW, bool OBJ>  // NW: waves per workgroup when wsplit = 1 (4 or 8)
 __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float *__restrict__ Xa,
                                                        const float *__restrict__ Xt,
                                                        const NmfkRun *__restrict__ runs,
                                                        const NmfkState *__restrict__ state,
-                                                       const NmfkStepArgs *__restrict__ gp, int it, int u0) {
-  extern __shared__ double lds[];  // den[16], red[8*16], cross-wave scratch
+                                                       const NmfkStepArgs *__restrict__ gp, int it, int u0, double weight) {
+  extern __shared__ double lds[];  // den[16], red[8*16], staging buffers / cross-wave scratch
   constexpr int NM = KS == 16 ? 3 : 2;       // bf16 MFMAs of the first product
   constexpr int SUBMASK = KS == 16 ? 1 : 0;  // signal sub-block of a k-lane group: 8 * (g & SUBMASK)
-  constexpr int ROWB = 3 * KS * 2;           // bytes of one bf16 split row
   const int u = u0 + blockIdx.y, bx = blockIdx.x;
-  if (!gp->force && !state[u].active) return;
+  if (!(gp->force && !OBJ) && !state[u].active) return;
   const NmfkRun *__restrict__ rdp = runs + u;
   const int k = rdp->k;  // = kp: row stride of the fp32 rows and of the sum tables
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const int which = gp->which, ws = gp->wsplit, S = gp->S, L = gp->L, D = gp->D;
+  const int which = gp->which, ws = OBJ ? 1 : gp->wsplit, S = OBJ ? 1 : gp->S, L = gp->L, D = gp->D;
   const int nwaves = blockDim.x >> 6;
   const int lpw = 16 * NT * (ws > 1 ? 1 : nwaves);
   const int tile = bx / S, s = bx - tile * S;
   const int l0 = tile * lpw + (ws > 1 ? 0 : wave * 16 * NT);
 
   const float *__restrict__ A = (const float *)(arena + (which == 0 ? NMFK_HOFF(*rdp, it) : rdp->oWt));  // lane factor
-  const char *__restrict__ Abf = arena + (which == 0 ? rdp->oHbf : rdp->oWbf);
-  const char *__restrict__ Bbf = arena + (which == 0 ? rdp->oWbf : rdp->oHbf);  // loop factor
-  const float *__restrict__ Bft = (const float *)(arena + (which == 0 ? rdp->oWft : rdp->oHft));
-  const int ldA = which == 0 ? rdp->ldHf : rdp->ldWf, ldB = which == 0 ? rdp->ldWf : rdp->ldHf;
+  const float *__restrict__ B =
+      (const float *)(arena + (which == 0 ? rdp->oWt : NMFK_HOFF(*rdp, OBJ ? it : it + 1)));  // loop factor
 
-  int d0 = s * gp->dchunk;
-  int d1 = min(D, d0 + gp->dchunk);
+  int d0 = OBJ ? 0 : s * gp->dchunk;
+  int d1 = OBJ ? D : min(D, d0 + gp->dchunk);
   if (ws > 1) {
     const int q = (((d1 - d0 + ws - 1) / ws) + 15) & ~15;  // equal shares of the range per wave, in whole chunks
     d0 = min(d0 + wave * q, d1);
@@ -149,7 +225,7 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
   d0 = __builtin_amdgcn_readfirstlane(d0);
   d1 = __builtin_amdgcn_readfirstlane(d1);
 
-  // lane-factor operand blocks of the first product (loop invariant)
+  // lane-factor operand blocks of the first product (loop invariant), built from the fp32 rows
   bf16x8_t bop[NT][NM];
   int lt[NT];
   bool lv[NT];
@@ -158,90 +234,69 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
     const int l = l0 + 16 * t + c16;
     lv[t] = l < L;
     lt[t] = lv[t] ? l : 0;
-#pragma unroll
-    for (int j = 0; j < NM; ++j) {
-      const int sb = hyb_sb<KS>(j, g);
-      u32x4_t w = {0u, 0u, 0u, 0u};
-      if (lv[t] && sb >= 0) w = *(const u32x4_t *)(Abf + ((int64_t)lt[t] * 3 + sb) * (KS * 2) + 16 * (g & SUBMASK));
-      bop[t][j] = __builtin_bit_cast(bf16x8_t, w);
-    }
+    hyb_lane_blocks<KS, NM>(A, k, lt[t], lv[t], g, bop[t]);
   }
   f32x4_t acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  // Xa = the copy of X with the loop dimension contiguous: element (l, d) at d + l*D
+  double ssum = 0.0;
 
   // X comes from the tiled copy Xt (hyb_tile_kernel): the 16 x 16 block (lane tile, chunk) is 1 KB in lane order, so
-  // a wave's load is one contiguous KB (from the plain copy each lane's 16 bytes sit in a different row: 64 separate
-  // L1 accesses per load, which bounded the kernel).  Byte offset of this lane's piece of chunk 0 of its tiles:
+  // a wave's load is one contiguous KB.  Byte offset of this lane's piece of chunk 0 of its tiles:
   const int nD16 = (D + 15) >> 4, nL16 = (L + 15) >> 4;
   uint32_t xoff[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) xoff[t] = (uint32_t)(((int64_t)min((l0 >> 4) + t, nL16 - 1) * nD16 * 256 + lane * 4) * 4);
-  uint32_t aoff[NM];  // byte offsets into a chunk of bf16 split rows: row c16, block (split, sub-block)
-#pragma unroll
-  for (int j = 0; j < NM; ++j) aoff[j] = (uint32_t)(c16 * ROWB + hyb_sa<KS>(j, g) * (KS * 2) + 16 * (g & SUBMASK));
-  // rows KS..15 of the second product's A operand do not exist: those lanes re-read row KS-1 and their numerator rows
-  // (signals >= KS) are never used
-  const uint32_t noff = (uint32_t)(((int64_t)min(c16, KS - 1) * ldB + 4 * g) * 4);
-
-  // full chunks: loads run one chunk ahead in two register sets.  Buffer loads: resource base = the array, per-lane
-  // part = a loop-invariant 32-bit VGPR offset, chunk position = the scalar offset -> no vector address arithmetic.
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)Xt, 0, -1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void *)Bbf, 0, -1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void *)Bft, 0, -1, 0x00020000);
-  auto load = [&](int dch, f32x4_t (&xv)[NT], u32x4_t (&av)[NM], f32x4_t &bn) __attribute__((always_inline)) {
+  auto xload = [&](int dch, f32x4_t (&xv)[NT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
+#ifdef HYB_DBG_NOX
+      xv[t] = (f32x4_t){1.f, 2.f, 3.f, 4.f};
+#else
       xv[t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, xoff[t], dch * 64, 0));
-#pragma unroll
-    for (int j = 0; j < NM; ++j) av[j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsa, aoff[j], dch * ROWB, 0));
-    bn = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsn, noff, dch * 4, 0));
+#endif
   };
-  auto chunk = [&](int dch, const f32x4_t (&xcur)[NT], const u32x4_t (&av)[NM], const f32x4_t &bn, auto full_tag)
+  // one chunk of 16 loop steps from the staged operands (av: split rows of the chunk, bn: its transposed block);
+  // MASK: the chunk crosses the end of the loop range, ratios of the steps >= d1 are dropped
+  auto chunk = [&](int dch, const f32x4_t (&xcur)[NT], const u32x4_t (&av)[NM], const f32x4_t &bn, bool mask)
                    __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(full_tag)::value;
     f32x4_t p[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NM; ++j)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-#ifdef HYB_DBG_NOM1
-        p[t] += __builtin_bit_cast(f32x4_t, av[j]);
-#else
+      for (int t = 0; t < NT; ++t)
         p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[j]), bop[t][j], p[t], 0, 0, 0);
-#endif
-      }
     // p[t][r] = <a_l, b_d> at d = dch + 4g + r, l = l0 + 16t + c16
+    if (OBJ) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = xcur[t][r] - p[t][r];
+          const double e2 = (double)e * (double)e;
+          ssum += (lv[t] && (!mask || dch + 4 * g + r < d1)) ? e2 : 0.0;
+        }
+      return;
+    }
     f32x4_t q[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-#ifdef HYB_DBG_NORCP
-        q[t][r] = xcur[t][r] * p[t][r];
-#else
         q[t][r] = hyb_div(xcur[t][r], p[t][r]);
-#endif
-        if (!FULL) q[t][r] = (dch + 4 * g + r < d1) ? q[t][r] : 0.0f;
+        if (mask) q[t][r] = (dch + 4 * g + r < d1) ? q[t][r] : 0.0f;
       }
-#ifdef HYB_DBG_NOM2
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[0] + bn[1] + bn[2] + bn[3], (q[t][0] + q[t][1]) + (q[t][2] + q[t][3]), acc[t], 0, 0, 0);
-#else
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[r], q[t][r], acc[t], 0, 0, 0);
-#endif
   };
   // inputs of the fused finish, fetched before the loop so that the finish does not wait for memory: the other
   // factor's sums (denominators of Mult:67 / Mult:70) and this lane's old factor values
-  const bool fused = gp->fused != 0;
+  const bool fused = !OBJ && gp->fused != 0;
   double *den = lds;
   const bool vec4 = (k & 3) == 0;  // fp32 rows are 16-byte aligned: one load / store per lane instead of four
   f32x4_t aold[NT];
@@ -265,147 +320,85 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
       }
     }
   }
-#ifdef HYB_DBG_NOLOOP
-  const int nfull = 0;
-#else
-  const int nfull = (d1 - d0) >> 4;
-#endif
-  char *sbase = (char *)(lds + 9 * 16);  // staging buffers (wsplit = 1) / cross-wave scratch (wsplit > 1)
-  if (ws == 1) {
-    // The waves of the workgroup walk the same loop range: the loop factor's chunks are fetched ONCE per workgroup
-    // into LDS (two chunks = 32 loop steps per barrier, double-buffered) and every wave reads its operand blocks
-    // from there -- the vector L1 (64 B/clk/CU) only carries X and one copy of the loop factor instead of one per
-    // wave, which is what bounded the first version of this kernel.
-    constexpr int CPB = 4;                   // chunks per staged block (one barrier per block)
-    constexpr int RS = KS == 16 ? 112 : 48;  // LDS row stride of the split rows, FRS of the transposed rows: the b128
-    constexpr int FRS = 80;                  // reads of 16 lanes hit 16 different groups of 4 banks (64 banks)
-    constexpr int BFB = 16 * CPB * RS, STB = BFB + CPB * 16 * FRS;  // bytes of a staged block: split rows, then [chunk][c][16 d]
-    constexpr int PR = ROWB / 16, PBF = 16 * CPB * PR, NP = PBF + KS * 4 * CPB;  // 16-byte pieces of a block
-    constexpr int NPT = (NP + 64 * NW - 1) / (64 * NW);
-    const int64_t obf = which == 0 ? rdp->oWbf : rdp->oHbf, oft = which == 0 ? rdp->oWft : rdp->oHft;
-    const int64_t ob = obf < oft ? obf : oft;
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void *)(arena + ob), 0, -1, 0x00020000);
-    uint32_t goff[NPT], gstep[NPT], lofs[NPT];
-    bool pv[NPT];
+  char *sbase = (char *)(lds + 9 * 16);  // staging buffers, later the cross-wave scratch (wsplit > 1)
+  const int nchunks = (d1 - d0 + 15) >> 4;
+
+  // The loop.  TRIP chunks per trip of the (unrolled) body so that the LDS buffer of a block and the register set of
+  // a chunk's X entries are compile-time constants; X runs two chunks ahead in four register sets, the next block of
+  // the loop factor is fetched while a block is computed and written to the free LDS buffer at the block's end.
+  auto run = [&](auto stage, char *sb, auto barrier) __attribute__((always_inline)) {
+    typedef decltype(stage) ST;
+    constexpr int CPB = (ST::NITEM / (16 * ST::PPR));
+    constexpr int TRIP = 2 * CPB > 4 ? 2 * CPB : 4;
+    const int fofs = c16 * ST::RS + 16 * (g & SUBMASK), nofs = ST::BFB + min(c16, KS - 1) * ST::FRS + g * 16;
+    if (nchunks <= 0) return;
+    float sv[ST::NI][2];
+    f32x4_t xr[4][NT];
+    const int dlast = d0 + 16 * (nchunks - 1);
+    stage.load(d0, sv);
+    xload(d0, xr[0]);
+    xload(min(d0 + 16, dlast), xr[1]);
+    stage.write(sb, sv);
+    barrier();
+    for (int c0 = 0; c0 < nchunks; c0 += TRIP) {
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-      const int pc = tid + 64 * NW * i;
-      pv[i] = pc < NP;
-      if (pc < PBF) {
-        const int row = pc / PR, part = pc - row * PR;
-        goff[i] = (uint32_t)(obf - ob) + row * ROWB + part * 16;
-        gstep[i] = ROWB;
-        lofs[i] = row * RS + part * 16;
-      } else {
-        const int q = min(pc, NP - 1) - PBF, c = q / (4 * CPB), part = q - c * (4 * CPB);
-        goff[i] = (uint32_t)(oft - ob) + (uint32_t)(((int64_t)c * ldB + part * 4) * 4);
-        gstep[i] = 4;
-        lofs[i] = BFB + ((part >> 2) * 16 + c) * FRS + (part & 3) * 16;
-      }
-    }
-    auto stage_load = [&](int dch, u32x4_t (&sv)[NPT]) __attribute__((always_inline)) {
+      for (int ci = 0; ci < TRIP; ++ci) {
+        const int c = c0 + ci;
+        if (c >= nchunks) break;
+        const int dch = d0 + 16 * c;
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int buf = (ci / CPB) & 1, ch = ci % CPB;
+        const bool more = c - ch + CPB < nchunks;  // a block follows the one this chunk belongs to
+        if (ch == 0 && more) stage.load(dch + 16 * CPB, sv);
+        xload(min(dch + 32, dlast), xr[(ci + 2) & 3]);
+        __builtin_amdgcn_sched_barrier(0);  // loads stay in front of the arithmetic they overlap with
+        {
+          const char *b = sb + buf * ST::STB;
+          u32x4_t av[NM];
 #pragma unroll
-      for (int i = 0; i < NPT; ++i)
-        if (pv[i]) sv[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsb, goff[i] + dch * gstep[i], 0, 0));
-    };
-    auto stage_write = [&](int buf, const u32x4_t (&sv)[NPT]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < NPT; ++i)
-        if (pv[i]) *(u32x4_t *)(sbase + buf * STB + lofs[i]) = sv[i];
-    };
-    auto xload = [&](int dch, f32x4_t (&xv)[NT]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#ifdef HYB_DBG_NOX
-        xv[t] = (f32x4_t){1.f, 2.f, 3.f, 4.f};
-#else
-        xv[t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, xoff[t], dch * 64, 0));
-#endif
-    };
-    const int fofs = c16 * RS + 16 * (g & SUBMASK), nofs = BFB + min(c16, KS - 1) * FRS + g * 16;
-    auto lds_chunk = [&](int buf, int ch, int dch, const f32x4_t (&xv)[NT]) __attribute__((always_inline)) {
-      const char *b = sbase + buf * STB;
-      u32x4_t av[NM];
-#pragma unroll
-      for (int j = 0; j < NM; ++j) av[j] = *(const u32x4_t *)(b + ch * 16 * RS + fofs + hyb_sa<KS>(j, g) * (KS * 2));
-      const f32x4_t bn = *(const f32x4_t *)(b + nofs + ch * 16 * FRS);
-      chunk(dch, xv, av, bn, std::true_type());
-    };
-    int dch = d0;
-    for (int i = 0; i < (nfull & (2 * CPB - 1)); ++i, dch += 16) {  // chunks ahead of the pipeline: straight from memory
-      f32x4_t xv[NT], bn;
-      u32x4_t av[NM];
-      load(dch, xv, av, bn);
-      chunk(dch, xv, av, bn, std::true_type());
-    }
-    const int dend = d0 + 16 * nfull;
-    if (dch < dend) {
-      // pipeline over pairs of blocks (2 * CPB chunks per trip): X runs two chunks ahead in four register sets, the
-      // block after next is fetched while a block is computed and written to the free LDS buffer at the block's end
-      f32x4_t xr[4][NT];
-      u32x4_t sv[NPT];
-      const int dlast = dend - 16;
-      stage_load(dch, sv);
-      xload(dch, xr[0]);
-      xload(dch + 16, xr[1]);
-      stage_write(0, sv);
-      __syncthreads();
-      for (; dch < dend; dch += 32 * CPB) {
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-          const int db = dch + 16 * CPB * hb;
-          stage_load(min(db + 16 * CPB, dend - 16 * CPB), sv);  // (past the end: the last block again, unused)
-#pragma unroll
-          for (int ch = 0; ch < CPB; ++ch) {
-            const int ci = hb * CPB + ch;
-            xload(min(db + 16 * (ch + 2), dlast), xr[(ci + 2) & 3]);
-            __builtin_amdgcn_sched_barrier(0);  // loads stay in front of the arithmetic they overlap with
-            lds_chunk(hb, ch, db + 16 * ch, xr[ci & 3]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          stage_write(hb ^ 1, sv);
-          HYB_BARRIER();
+          for (int j = 0; j < NM; ++j) av[j] = *(const u32x4_t *)(b + ch * 16 * ST::RS + fofs + hyb_sa<KS>(j, g) * (KS * 2));
+          f32x4_t bn = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          if (!OBJ) bn = *(const f32x4_t *)(b + nofs + ch * 16 * ST::FRS);
+          chunk(dch, xr[ci & 3], av, bn, dch + 16 > d1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch == CPB - 1 || c == nchunks - 1) {  // end of a block
+          if (more) stage.write(sb + (buf ^ 1) * ST::STB, sv);
+          barrier();
         }
       }
     }
+  };
+#ifndef HYB_DBG_NOLOOP
+  if (OBJ) {
+    HybStage<KS, 4, 64 * NW, false> stage;
+    stage.init(B, k, D, tid);
+    run(stage, sbase, [] { HYB_BARRIER(); });
+    // workgroup sum in wave order (fixed order => reproducible), one partial per workgroup
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ssum += __shfl_down(ssum, o, 64);
+    double *sh = lds;
+    if (lane == 0) sh[wave] = ssum;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0;
+      for (int w = 0; w < nwaves; ++w) t += sh[w];
+      ((double *)(arena + rdp->ossepart))[tile] = t * weight * weight;
+    }
+    return;
+  }
+  if (ws == 1) {
+    HybStage<KS, 4, 64 * NW, true> stage;
+    stage.init(B, k, D, tid);
+    run(stage, sbase, [] { HYB_BARRIER(); });
   } else {
-    f32x4_t x0[NT], x1[NT], b0, b1;
-    u32x4_t a0[NM], a1[NM];
-    int dch = d0;
-    if (nfull & 1) {  // odd count: one chunk ahead of the two-chunk pipeline
-      load(dch, x0, a0, b0);
-      chunk(dch, x0, a0, b0, std::true_type());
-      dch += 16;
-    }
-    const int dend = d0 + 16 * nfull;
-    if (dch < dend) {
-      load(dch, x0, a0, b0);
-      for (; dch < dend; dch += 32) {
-        load(dch + 16, x1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);  // the loads of the next chunk stay in front of this chunk's arithmetic
-        chunk(dch, x0, a0, b0, std::true_type());
-        __builtin_amdgcn_sched_barrier(0);
-        load(min(dch + 32, dend - 16), x0, a0, b0);  // (past the end: the last chunk again, unused)
-        __builtin_amdgcn_sched_barrier(0);
-        chunk(dch + 16, x1, a1, b1, std::true_type());
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
+    HybStage<KS, 1, 64, true> stage;
+    stage.init(B, k, D, lane);
+    run(stage, sbase + wave * 2 * HybStage<KS, 1, 64, true>::STB, [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); });
+    __syncthreads();  // the cross-wave scratch below overlays the staging buffers
   }
-  if ((d1 - d0) & 15) {  // ragged end of the loop range: element-wise X loads inside the row, loop steps >= d1 masked
-    const int dch = d0 + 16 * nfull;
-    f32x4_t xv[NT], bn;
-    u32x4_t av[NM];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xv[t][r] = Xa[(int64_t)lt[t] * D + min(dch + 4 * g + r, D - 1)];
-    const char *ab = Bbf + (int64_t)dch * ROWB;
-#pragma unroll
-    for (int j = 0; j < NM; ++j) av[j] = *(const u32x4_t *)(ab + aoff[j]);
-    bn = *(const f32x4_u *)((const char *)(Bft + dch) + noff);
-    chunk(dch, xv, av, bn, std::false_type());
-  }
+#endif
   // acc[t][r] = numerator of signal c = 4g + r at lane element l0 + 16t + c16
 
   float *scratch = (float *)sbase;
@@ -446,8 +439,6 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
 
   __syncthreads();  // den[] is visible
   float *__restrict__ Anew = which == 0 ? (float *)(arena + NMFK_HOFF(*rdp, it + 1)) : (float *)(arena + rdp->oWt);
-  char *__restrict__ Abfw = arena + (which == 0 ? rdp->oHbf : rdp->oWbf);
-  float *__restrict__ Aftw = (float *)(arena + (which == 0 ? rdp->oHft : rdp->oWft));
   double *sumA = (double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)) + (int64_t)tile * k;
   double *red = den + 16;  // [8][16]
   float vs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -460,7 +451,6 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
     for (int t = 0; t < NT; ++t)
       if (lv[t]) {
         float v[4];
-        uint32_t h[4], mm[4], lo[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int c = 4 * g + r;
@@ -469,17 +459,9 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
             v[r] = aold[t][r] * acc[t][r] / (float)den[c];  // Mult:67 / Mult:70 order
             if (!vec4) Anew[c + (int64_t)lt[t] * k] = v[r];
           }
-          if (c < KS) Aftw[(int64_t)c * ldA + lt[t]] = v[r];
           vs[r] += v[r];
-          split3(v[r], h[r], mm[r], lo[r]);
         }
         if (vec4 && 4 * g < k) *(f32x4_t *)(Anew + 4 * g + (int64_t)lt[t] * k) = (f32x4_t){v[0], v[1], v[2], v[3]};
-        if (4 * g < KS) {
-          char *row = Abfw + (int64_t)lt[t] * ROWB + 8 * g;
-          *(u32x2_t *)(row + 0 * KS * 2) = (u32x2_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-          *(u32x2_t *)(row + 1 * KS * 2) = (u32x2_t){mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16)};
-          *(u32x2_t *)(row + 2 * KS * 2) = (u32x2_t){lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16)};
-        }
       }
   }
 #pragma unroll
@@ -497,84 +479,6 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
       for (int w = 1; w < nwaves; ++w) t += red[w * 16 + tid];
     sumA[tid] = t;
   }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Monitored objective (Mult:74) of the units of the split-operand MFMA group: sum(((X - W*H) * weight)^2) with W*H from
-// the same three-term bf16 products as the half-step (fp32-accurate), residuals squared and accumulated in fp64.
-// Dense X without missing entries, scalar weight.  Lanes = rows of X (W orientation: tiled copy Xt of the W half-step,
-// loop over the columns = rows of H's split form).  Grid ((n + 255) / 256, units), 256 threads: a wave owns 4 tiles of
-// 16 rows; one partial per workgroup in ossepart[] like sse_kernel.
-// ------------------------------------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(NMFK_TILE) void hyb_sse_kernel(char *arena, const float *__restrict__ Xt,
-                                                            const NmfkRun *__restrict__ runs,
-                                                            const NmfkState *__restrict__ state, int n, int m, double weight,
-                                                            int u0) {
-  __shared__ double sh[8];
-  constexpr int NT = 4, NM = KS == 16 ? 3 : 2, SUBMASK = KS == 16 ? 1 : 0, ROWB = 3 * KS * 2;
-  const int u = u0 + blockIdx.y;
-  if (!state[u].active) return;
-  const NmfkRun *__restrict__ rdp = runs + u;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const int L = n, D = m, nD16 = (D + 15) >> 4, nL16 = (L + 15) >> 4;
-  const int l0 = blockIdx.x * NMFK_TILE + wave * 64;
-  const char *__restrict__ Abf = arena + rdp->oWbf;  // lane factor W
-  const char *__restrict__ Bbf = arena + rdp->oHbf;  // loop factor H
-  bf16x8_t bop[NT][NM];
-  bool lv[NT];
-  uint32_t xoff[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int l = l0 + 16 * t + c16;
-    lv[t] = l < L;
-    const int lt = lv[t] ? l : 0;
-#pragma unroll
-    for (int j = 0; j < NM; ++j) {
-      const int sb = hyb_sb<KS>(j, g);
-      u32x4_t w = {0u, 0u, 0u, 0u};
-      if (lv[t] && sb >= 0) w = *(const u32x4_t *)(Abf + ((int64_t)lt * 3 + sb) * (KS * 2) + 16 * (g & SUBMASK));
-      bop[t][j] = __builtin_bit_cast(bf16x8_t, w);
-    }
-    xoff[t] = (uint32_t)(((int64_t)min((l0 >> 4) + t, nL16 - 1) * nD16 * 256 + lane * 4) * 4);
-  }
-  uint32_t aoff[NM];
-#pragma unroll
-  for (int j = 0; j < NM; ++j) aoff[j] = (uint32_t)(c16 * ROWB + hyb_sa<KS>(j, g) * (KS * 2) + 16 * (g & SUBMASK));
-  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)Xt, 0, -1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void *)Bbf, 0, -1, 0x00020000);
-  double ssum = 0.0;
-  for (int dch = 0; dch < D; dch += 16) {  // (the split rows are zero-padded by 16, the tiled X by whole blocks)
-    f32x4_t xv[NT], p[NT];
-    u32x4_t av[NM];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-      xv[t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, xoff[t], dch * 64, 0));
-#pragma unroll
-    for (int j = 0; j < NM; ++j)
-      av[j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsa, aoff[j], dch * ROWB, 0));
-#pragma unroll
-    for (int t = 0; t < NT; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < NM; ++j)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[j]), bop[t][j], p[t], 0, 0, 0);
-    const bool full = dch + 16 <= D;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = xv[t][r] - p[t][r];
-        const double e2 = (double)e * (double)e;
-        ssum += (lv[t] && (full || dch + 4 * g + r < D)) ? e2 : 0.0;
-      }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ssum += __shfl_down(ssum, o, 64);
-  if (lane == 0) sh[wave] = ssum;
-  __syncthreads();
-  if (tid == 0) ((double *)(arena + rdp->ossepart))[blockIdx.x] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) * weight * weight;
 }
 
 }  // namespace
@@ -596,18 +500,14 @@ void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, 
   const int ntile = (a.L + lpw - 1) / lpw;
   const dim3 grid(ntile * a.S, cnt), blk(64 * nwaves);
   const size_t cross = ws > 1 ? (size_t)(ws - 1) * NT * 4 * 64 * sizeof(float) : 0;
-  const size_t stage = 2 * (64 * (ks == 16 ? 112 : 48) + 4 * 16 * 80);  // two staged blocks of 4 chunks (wsplit = 1)
+  const size_t rs = ks == 16 ? 112 : 48;
+  // two staged blocks of 4 chunks per workgroup (wsplit = 1) / of one chunk per wave (wsplit > 1)
+  const size_t stage = ws > 1 ? (size_t)ws * 2 * (16 * rs + 16 * 80) : 2 * (64 * rs + 4 * 16 * 80);
   const size_t ldsb = sizeof(double) * 9 * 16 + std::max(cross, stage);
   if (ks == 8)
-    hipLaunchKernelGGL((hyb_step_kernel<8, NT, NW>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0);
+    hipLaunchKernelGGL((hyb_step_kernel<8, NT, NW, false>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
   else
-    hipLaunchKernelGGL((hyb_step_kernel<16, NT, NW>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0);
-}
-
-void nmfk_launch_hyb_forms(char *arena, const NmfkRun *runs, int n, int m, int hpar, int mask, int u0, int cnt,
-                           hipStream_t s) {
-  const int nb = std::max(1, std::min(32, (std::max(n, m) + 16 + NMFK_TILE - 1) / NMFK_TILE));
-  hipLaunchKernelGGL(hyb_forms_kernel, dim3(nb, cnt), dim3(NMFK_TILE), 0, s, arena, runs, n, m, hpar, mask, u0);
+    hipLaunchKernelGGL((hyb_step_kernel<16, NT, NW, false>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
 }
 
 // tiled copy of X (element (l, d) at src[d + l*D]) for nmfk_launch_step_hyb_f32; out: roundup16(L) * roundup16(D) floats
@@ -617,12 +517,17 @@ void nmfk_launch_hyb_tile(const float *src, int L, int D, float *out, hipStream_
   hipLaunchKernelGGL(hyb_tile_kernel, dim3(nb), dim3(NMFK_TILE), 0, s, src, L, D, out);
 }
 
-// monitored objective of the units [u0, u0 + cnt) of a group on the split-operand MFMA kernel (active units only)
-void nmfk_launch_hyb_sse(char *arena, const float *Xtile_w, const NmfkRun *runs, const NmfkState *state, int n, int m,
-                         double weight, int ks, int u0, int cnt, hipStream_t s) {
-  const dim3 grid((n + NMFK_TILE - 1) / NMFK_TILE, cnt), blk(NMFK_TILE);
+// monitored objective of the units [u0, u0 + cnt) of a group on the split-operand MFMA kernel (active units only):
+// the half-step kernel in its objective mode.  w: the W half-step's arguments (dw: their device copy); hsel: parity
+// of the H buffer that holds the current H
+void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double weight, int hsel, int ks, int u0, int cnt,
+                         hipStream_t s) {
+  constexpr int NT = NMFK_HYB_NT, NW = NMFK_HYB_NW;
+  const int lpw = 16 * NT * NW;  // = NMFK_TILE: the partials line up with sse_kernel's
+  const dim3 grid((w.L + lpw - 1) / lpw, cnt), blk(64 * NW);
+  const size_t ldsb = sizeof(double) * 9 * 16 + 2 * 64 * (ks == 16 ? 112 : 48);
   if (ks == 8)
-    hipLaunchKernelGGL((hyb_sse_kernel<8>), grid, blk, 0, s, arena, Xtile_w, runs, state, n, m, weight, u0);
+    hipLaunchKernelGGL((hyb_step_kernel<8, NT, NW, true>), grid, blk, ldsb, s, w.arena, w.Xalt, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
   else
-    hipLaunchKernelGGL((hyb_sse_kernel<16>), grid, blk, 0, s, arena, Xtile_w, runs, state, n, m, weight, u0);
+    hipLaunchKernelGGL((hyb_step_kernel<16, NT, NW, true>), grid, blk, ldsb, s, w.arena, w.Xalt, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
 }

@@ -1643,17 +1643,7 @@ __global__ __launch_bounds__(NMFK_TILE) void clamp_kernel(NmfkCheckArgs g, int u
     slot_range(len, P, b, l0, l1);
     for (int64_t e = (int64_t)l0 * kp + tid; e < (int64_t)l1 * kp; e += NMFK_TILE) {
       const T v = F[e];
-      if ((int)(e % kp) < k && v < eps) {
-        F[e] = eps;
-        if (rd.hyb) {  // unit of the split-operand MFMA kernel: patch its operand forms (eps = 2^-52 is a bf16 number)
-          const int l = (int)(e / kp), c = (int)(e % kp), KS = rd.hyb;
-          unsigned short *bf = (unsigned short *)(g.arena + (f == 0 ? rd.oWbf : rd.oHbf)) + (int64_t)l * 3 * KS + c;
-          bf[0] = 0x2580;  // 2^-52
-          bf[KS] = 0;
-          bf[2 * KS] = 0;
-          ((float *)(g.arena + (f == 0 ? rd.oWft : rd.oHft)))[(int64_t)c * (f == 0 ? rd.ldWf : rd.ldHf) + l] = (float)eps;
-        }
-      }
+      if ((int)(e % kp) < k && v < eps) F[e] = eps;
     }
     __syncthreads();
     range_signal_sums(F, kp, k, l0, l1, tab + (int64_t)b * kp, sh);

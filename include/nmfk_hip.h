@@ -185,9 +185,7 @@ int nmfk_set_profiling(nmfk_ctx *ctx, int enabled);
 /* Launch schedule the LAST nmfk_mu_sweep on this context chose (tests assert that the schedule they mean to cover was
  * the one taken; bench.py reports it).  info[0] = phases of the sweep (2 = the split-operand MFMA group first, the
  * packed-VALU ranks afterwards), info[1] = units on the split-operand MFMA half-step, info[2] = mixed-rank packed-VALU
- * launch groups, info[3] = launch groups in all, info[4] = units on the all-MFMA half-step (k > 16), info[5] = units on
- * the shared-X packed-VALU half-step (several restarts of one rank per workgroup), info[6] = restarts per workgroup of
- * the widest such group, info[7] = reserved. */
+ * launch groups, info[3] = launch groups in all, info[4] = units on the all-MFMA half-step (k > 16), info[5..7] reserved. */
 int nmfk_last_sweep_info(nmfk_ctx *ctx, int32_t info[8]);
 int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *total_ms, int64_t *launches,
                      double *flops, int *count);

@@ -322,7 +322,7 @@ class Context:
         info = (C.c_int32 * 8)()
         _check(lib().nmfk_last_sweep_info(self._h, info))
         return dict(phases=info[0], mfma_group_units=info[1], merged_valu_groups=info[2], launch_groups=info[3],
-                    wide_mfma_units=info[4], shared_x_units=info[5], shared_x_width=info[6])
+                    wide_mfma_units=info[4])
 
     def set_profiling(self, on=True):
         _check(lib().nmfk_set_profiling(self._h, int(on)))

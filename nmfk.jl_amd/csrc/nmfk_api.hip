@@ -624,17 +624,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     return hyb_on && wide_ok_nowide && mfma_mink == 0 && k <= 16 && k >= hyb_mink &&
            (int64_t)n * m * 4 < ((int64_t)1 << 32) - 4096;
   };
-  // Small ranks (2..8), dense fp32 X without missing data, per-rank launches: the shared-X packed-VALU half-step
-  // (nmfk_step_shx.hip) gives a workgroup UN restarts of the rank, so that an X entry is loaded once for all of them
-  // (the per-restart kernel re-reads X from L2 for every restart: 1/3 of the fp32 peak at k <= 8).  NMFK_SHX=0 disables.
-  int shx_on = 0;
-  if (const char *e = getenv("NMFK_SHX")) shx_on = atoi(e);
-  auto shx_width_k = [&](int k) {
-    if (!shx_on || f64 || ctx->sparse || ctx->nan_count != 0 || mfma_mink > 0 || merge > 0) return 0;
-    if (use_hyb_k(k)) return 0;
-    const int w = nmfk_shx_width(k);
-    return (w > 0 && nruns >= w) ? w : 0;
-  };
   // lane elements per workgroup (= per sum-table slot) of the half-step kernel a rank runs
   auto lane_tile = [&](int k, int ws) {
     if (ctx->sparse) return NMFK_TILE;
@@ -654,10 +643,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     auto wgs = [&](int ws) {  // workgroups of one half-step over all units of the phase
       int64_t t = 0;
       for (int q = 0; q < nk; ++q)
-        if (phase_of_k(ks[q]) == phase) {
-          const int w = shx_width_k(ks[q]);  // shared-X kernel: one workgroup per lane tile and group of w restarts
-          t += (int64_t)((L + lane_tile(ks[q], ws) - 1) / lane_tile(ks[q], ws)) * (w ? (nruns + w - 1) / w : nruns);
-        }
+        if (phase_of_k(ks[q]) == phase) t += (int64_t)((L + lane_tile(ks[q], ws) - 1) / lane_tile(ks[q], ws)) * nruns;
       return std::max<int64_t>(t, 1);
     };
     g.wsplit = 1;
@@ -702,7 +688,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     int k, kp, begin, count;
     int hyb;    // split width of the split-operand MFMA kernel (8 / 16) when the group runs on it, else 0
     int phase;  // groups of phase 0 run to the end before those of phase 1 start
-    int shx;    // restarts per workgroup of the shared-X packed-VALU kernel when the group runs on it, else 0
   };
   // Launch groups = contiguous unit ranges.  Default: one group per rank (units sorted by k descending), each with its
   // own kernel instantiation and stream.  With few restarts per rank the per-rank launches are tiny and the loop is
@@ -715,15 +700,14 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     const int q = order[oi], k = ks[q];
     if (merge > 0 && k <= NMFK_MULTI_MAXK) continue;
     if (hyb_phases && use_hyb_k(k)) continue;
-    groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns, use_hyb_k(k) ? (k <= 8 ? 8 : 16) : 0, hyb_phases ? 1 : 0,
-                      shx_width_k(k)});
+    groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns, use_hyb_k(k) ? (k <= 8 ? 8 : 16) : 0, hyb_phases ? 1 : 0});
     for (int r = 0; r < nruns; ++r) ulist.push_back({q, r});
   }
   // merged sweeps: the ranks of the split-operand MFMA kernel (its cost does not depend on the rank, one instantiation
   // serves them all at split width 16) form mixed-rank groups of their own, the other ranks <= 16 the VALU ones
   const int hg = (merge > 0 || hyb_phases) ? std::min(hyb_groups, nruns) : 0;
   for (int g = 0; g < hg; ++g) {
-    Group G{0, 0, (int)ulist.size(), 0, 16, 0, 0};
+    Group G{0, 0, (int)ulist.size(), 0, 16, 0};
     for (int oi = 0; oi < nk; ++oi) {
       const int q = order[oi];
       if (ks[q] > NMFK_MULTI_MAXK || !use_hyb_k(ks[q])) continue;
@@ -732,7 +716,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if (G.count > 0) groups.push_back(G);
   }
   for (int g = 0; g < merge; ++g) {
-    Group G{0, 0, (int)ulist.size(), 0, 0, 0, 0};
+    Group G{0, 0, (int)ulist.size(), 0, 0, 0};
     for (int oi = 0; oi < nk; ++oi) {
       const int q = order[oi];
       if (ks[q] > NMFK_MULTI_MAXK || use_hyb_k(ks[q])) continue;
@@ -1002,13 +986,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     memset(si, 0, sizeof(ctx->sweep_info));
     si[0] = nphases;
     si[3] = ngroups;
-    for (const Group &G : groups) {
-      si[2] += (G.kp == 0 && !G.hyb) ? 1 : 0;
-      if (G.shx) {
-        si[5] += G.count;
-        si[6] = std::max(si[6], G.shx);
-      }
-    }
+    for (const Group &G : groups) si[2] += (G.kp == 0 && !G.hyb) ? 1 : 0;
     for (int u = 0; u < nunits; ++u) {
       si[1] += runs[u].hyb ? 1 : 0;
       si[4] += use_wide_k(runs[u].k) ? 1 : 0;
@@ -1044,8 +1022,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_sp_step_f32(&sph, G.kp, G.begin, G.count, gs);
         else if (use_hyb(G))
           nmfk_launch_step_hyb_f32(hs, d_hs, G.hyb, G.begin, G.count, gs);
-        else if (G.shx)
-          nmfk_launch_step_shx_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         else if (G.kp == 0 && f64)
           nmfk_launch_step_multi_f64(hs, d_hs, G.begin, G.count, gs);
         else if (G.kp == 0)
@@ -1075,8 +1051,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_sp_step_f32(&spw, G.kp, G.begin, G.count, gs);
         else if (use_hyb(G))
           nmfk_launch_step_hyb_f32(ws, d_ws, G.hyb, G.begin, G.count, gs);
-        else if (G.shx)
-          nmfk_launch_step_shx_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         else if (G.kp == 0 && f64)
           nmfk_launch_step_multi_f64(ws, d_ws, G.begin, G.count, gs);
         else if (G.kp == 0)

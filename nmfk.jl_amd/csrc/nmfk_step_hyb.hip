@@ -62,6 +62,26 @@ __device__ __forceinline__ void split3(float v, uint32_t &h, uint32_t &m, uint32
   l = bf16_bits(r2);
 }
 
+// the same split for a PAIR of values with packed conversions: words of two bf16 terms each (first value in the low
+// half), 9 vector instructions instead of 20 (v_cvt_pk_bf16_f32 rounds and packs both, the residuals are one v_pk_add)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_pack2(f32x2_t v) {
+  const bf16x2_t r = {(__bf16)v.x, (__bf16)v.y};
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ f32x2_t bf16_unpack2(uint32_t w) {
+  return (f32x2_t){__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+}
+__device__ __forceinline__ void split3_pair(float v0, float v1, uint32_t &h, uint32_t &m, uint32_t &l) {
+  const f32x2_t v = {v0, v1};
+  h = bf16_pack2(v);
+  const f32x2_t r1 = v - bf16_unpack2(h);
+  m = bf16_pack2(r1);
+  const f32x2_t r2 = r1 - bf16_unpack2(m);
+  l = bf16_pack2(r2);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // tiled copy of X for one half-step: src element (l, d) at src[d + l*D]; out block (l / 16, d / 16) = 256 floats in
 // the order the MFMA layout consumes them: float index ((g*16 + c16)*4 + r) <-> l = 16 tl + c16, d = 16 td + 4g + r.
@@ -120,32 +140,32 @@ struct HybStage {
       ltr[i] = (uint32_t)(BFB + ((r >> 4) * 16 + 2 * cp) * FRS + (r & 15) * 4);
     }
   }
-  // fetch the block that starts at loop row `row0`; rows past the factor's end and padding signals become zeros (a
-  // block reads at most 64 rows = 4 KB past the end of the array, inside the arena)
-  __device__ __forceinline__ void load(int row0, float (&v)[NI][2]) const {
+  // fetch the block that starts at loop row `row0` (a block reads at most 64 rows = 4 KB past the end of the array,
+  // inside the arena).  Nothing here may USE the loaded values: the loads stay in flight until write() (a select
+  // right behind the load made the compiler wait for vmcnt(0) on the spot, X prefetches included).
+  __device__ __forceinline__ void load(int row0, float (&v)[NI][2], int &vrow0) const {
+    vrow0 = row0;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      if (!pv[i]) continue;
-      const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[i], row0 * rowbytes, 0));
-      const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[i] + 4, row0 * rowbytes, 0));
-      const bool ok = row0 + rr[i] < dlim;
-      v[i][0] = (ok && c0[i]) ? a : 0.0f;
-      v[i][1] = (ok && c1[i]) ? b : 0.0f;
+    for (int i = 0; i < NI; ++i) {  // (threads without an item load item 0 again and drop it)
+      v[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[i], row0 * rowbytes, 0));
+      v[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[i] + 4, row0 * rowbytes, 0));
     }
   }
-  __device__ __forceinline__ void write(char *dst, const float (&v)[NI][2]) const {
+  // rows past the factor's end and padding signals become zeros
+  __device__ __forceinline__ void write(char *dst, const float (&vin)[NI][2], int vrow0) const {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      if (!pv[i]) continue;
-      uint32_t h0, m0, l0, h1, m1, l1;
-      split3(v[i][0], h0, m0, l0);
-      split3(v[i][1], h1, m1, l1);
-      *(uint32_t *)(dst + lsp[i]) = h0 | (h1 << 16);
-      *(uint32_t *)(dst + lsp[i] + KS * 2) = m0 | (m1 << 16);
-      *(uint32_t *)(dst + lsp[i] + KS * 4) = l0 | (l1 << 16);
+      if (NITEM % GT != 0 && !pv[i]) continue;
+      const bool ok = vrow0 + rr[i] < dlim;
+      const float v[1][2] = {{(ok && c0[i]) ? vin[i][0] : 0.0f, (ok && c1[i]) ? vin[i][1] : 0.0f}};
+      uint32_t h, m, l;
+      split3_pair(v[0][0], v[0][1], h, m, l);
+      *(uint32_t *)(dst + lsp[i]) = h;
+      *(uint32_t *)(dst + lsp[i] + KS * 2) = m;
+      *(uint32_t *)(dst + lsp[i] + KS * 4) = l;
       if (WITH_T) {
-        *(float *)(dst + ltr[i]) = v[i][0];
-        *(float *)(dst + ltr[i] + FRS) = v[i][1];
+        *(float *)(dst + ltr[i]) = v[0][0];
+        *(float *)(dst + ltr[i] + FRS) = v[0][1];
       }
     }
   }
@@ -161,16 +181,13 @@ __device__ __forceinline__ void hyb_lane_blocks(const float *__restrict__ A, int
   uint32_t hh[4], mm[4], ll[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    uint32_t h[2], m[2], lo[2];
+    float v[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int c = s0 + 2 * i + e;
-      const float v = (valid && c < k) ? A[c + (int64_t)l * k] : 0.0f;
-      split3(v, h[e], m[e], lo[e]);
+      v[e] = (valid && c < k) ? A[c + (int64_t)l * k] : 0.0f;
     }
-    hh[i] = h[0] | (h[1] << 16);
-    mm[i] = m[0] | (m[1] << 16);
-    ll[i] = lo[0] | (lo[1] << 16);
+    split3_pair(v[0], v[1], hh[i], mm[i], ll[i]);
   }
 #pragma unroll
   for (int j = 0; j < NM; ++j) {
@@ -333,42 +350,63 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
     const int fofs = c16 * ST::RS + 16 * (g & SUBMASK), nofs = ST::BFB + min(c16, KS - 1) * ST::FRS + g * 16;
     if (nchunks <= 0) return;
     float sv[ST::NI][2];
+    int svrow;
     f32x4_t xr[4][NT];
     const int dlast = d0 + 16 * (nchunks - 1);
-    stage.load(d0, sv);
+    stage.load(d0, sv, svrow);
     xload(d0, xr[0]);
     xload(min(d0 + 16, dlast), xr[1]);
-    stage.write(sb, sv);
+    stage.write(sb, sv, svrow);
     barrier();
-    for (int c0 = 0; c0 < nchunks; c0 += TRIP) {
+    // one trip; FULLT: every chunk of the trip exists, every block of it has a successor and no chunk touches the end
+    // of the loop range -> no guards in the unrolled body
+    auto trip = [&](int c0, auto full_tag) __attribute__((always_inline)) {
+      constexpr bool FULLT = decltype(full_tag)::value;
 #pragma unroll
       for (int ci = 0; ci < TRIP; ++ci) {
         const int c = c0 + ci;
-        if (c >= nchunks) break;
+        if (!FULLT && c >= nchunks) break;
         const int dch = d0 + 16 * c;
-        constexpr int dummy = 0;
-        (void)dummy;
         const int buf = (ci / CPB) & 1, ch = ci % CPB;
-        const bool more = c - ch + CPB < nchunks;  // a block follows the one this chunk belongs to
-        if (ch == 0 && more) stage.load(dch + 16 * CPB, sv);
-        xload(min(dch + 32, dlast), xr[(ci + 2) & 3]);
+        const bool more = FULLT || (c - ch + CPB < nchunks);  // a block follows the one this chunk belongs to
+        xload(FULLT ? dch + 32 : min(dch + 32, dlast), xr[(ci + 2) & 3]);
+        // (vmcnt retires in order: issued AFTER this chunk's X prefetch, the rows of the next block -- they come from
+        // beyond L2 -- are not covered by the wait for X two chunks on, only by the one three chunks on)
+#if !defined(HYB_DBG_NOSTAGE) && !defined(HYB_DBG_NOSTAGE_L)
+        if (ch == 0 && more) stage.load(dch + 16 * CPB, sv, svrow);
+#endif
+        // the next block goes to the free LDS buffer BEFORE the block's last chunk, so that the conversion and the
+        // LDS writes overlap with that chunk's matrix work instead of sitting in front of the barrier
+#if !defined(HYB_DBG_NOSTAGE) && !defined(HYB_DBG_NOSTAGE_W)
+        if (CPB > 1 && ch == CPB - 1 && more) stage.write(sb + (buf ^ 1) * ST::STB, sv, svrow);
+#endif
         __builtin_amdgcn_sched_barrier(0);  // loads stay in front of the arithmetic they overlap with
         {
           const char *b = sb + buf * ST::STB;
           u32x4_t av[NM];
 #pragma unroll
+#ifdef HYB_DBG_NOLDSR
+          for (int j = 0; j < NM; ++j) av[j] = (u32x4_t){0x3f803f80u + (uint32_t)(ch + j), 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+          f32x4_t bn = (f32x4_t){1.f, 2.f, 3.f, 4.f};
+          (void)b; (void)fofs; (void)nofs;
+#else
           for (int j = 0; j < NM; ++j) av[j] = *(const u32x4_t *)(b + ch * 16 * ST::RS + fofs + hyb_sa<KS>(j, g) * (KS * 2));
           f32x4_t bn = (f32x4_t){0.f, 0.f, 0.f, 0.f};
           if (!OBJ) bn = *(const f32x4_t *)(b + nofs + ch * 16 * ST::FRS);
-          chunk(dch, xr[ci & 3], av, bn, dch + 16 > d1);
+#endif
+          chunk(dch, xr[ci & 3], av, bn, !FULLT && dch + 16 > d1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ch == CPB - 1 || c == nchunks - 1) {  // end of a block
-          if (more) stage.write(sb + (buf ^ 1) * ST::STB, sv);
+        if (ch == CPB - 1 || (!FULLT && c == nchunks - 1)) {  // end of a block
+          if (CPB == 1 && more) stage.write(sb + (buf ^ 1) * ST::STB, sv, svrow);
           barrier();
         }
       }
-    }
+    };
+    constexpr int AHEAD = CPB > 2 ? CPB : 2;
+    int c0 = 0;
+    for (; c0 + TRIP + AHEAD <= nchunks; c0 += TRIP) trip(c0, std::true_type());
+    for (; c0 < nchunks; c0 += TRIP) trip(c0, std::false_type());
   };
 #ifndef HYB_DBG_NOLOOP
   if (OBJ) {

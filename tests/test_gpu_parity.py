@@ -884,83 +884,6 @@ def test_robustkmeans_rows_of_W_at_bench_size(NMFk, ctx, oracle):
     assert one["totalcost"] == r["totalcost"]
 
 
-# ---------------------------------------------------------------------------------------------------------------
-# shared-X packed-VALU half-step for the ranks 2..8 (nmfk_step_shx.hip)
-# ---------------------------------------------------------------------------------------------------------------
-class _env:
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update({k: str(v) for k, v in self.kv.items()})
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
-@pytest.mark.parametrize("shape,R", [((600, 260), 9), ((1030, 520), 16), ((130, 70), 8)])
-def test_shared_x_kernel_bitwise_equal_and_oracle(NMFk, ctx, oracle, shape, R):
-    """Ranks 2..8 with >= UN restarts run the shared-X half-step (one X load feeds UN restarts of a rank).  A restart's
-    operation order is that of the per-restart kernel, so under the same launch geometry the results are BITWISE
-    equal (ragged lane tiles, short last groups: R = 9 leaves groups of 1); under the default geometry both sit
-    within the fp32 tolerance of the Float64 oracle."""
-    n, m = shape
-    X = (0.05 + oracle.uniform_fill(21, 0, n * m)).reshape(n, m).astype(np.float32)
-    ctx.set_X(X)
-    ks = list(range(2, 9))
-    seeds = _seeds(NMFk, 8, ks, R)
-    for geo in (dict(NMFK_TARGET_WGS=1), dict()):  # one workgroup per lane tile, no splits / the default geometry
-        with _env(NMFK_SHX=1, **geo):
-            a = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=30, **NOSTOP)
-            info = ctx.last_sweep_info()
-        if info["merged_valu_groups"] == 0 and info["mfma_group_units"] == 0:  # (few-restart sweeps keep their merged launches)
-            assert info["shared_x_units"] == sum(R for k in ks if R >= {2: 8, 3: 4, 4: 4, 5: 3}.get(k, 2)), info
-        with _env(NMFK_SHX=0, **geo):
-            b = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=30, **NOSTOP)
-            assert ctx.last_sweep_info()["shared_x_units"] == 0
-        for k in ks:
-            if geo:
-                assert (a[k]["W"] == b[k]["W"]).all() and (a[k]["H"] == b[k]["H"]).all(), k
-                assert (a[k]["objvalue"] == b[k]["objvalue"]).all()
-            else:
-                for r in range(R):
-                    assert _rel(a[k]["W"][r] @ a[k]["H"][r], b[k]["W"][r] @ b[k]["H"][r], X) <= 5e-6
-    for k, r in [(2, 0), (2, R - 1), (3, 5), (5, R - 1), (8, 3)]:
-        W0, H0 = oracle.init_factors(int(seeds[k - 2, r]), n, m, k)
-        ref = oracle.singlerun(X, k, W0, H0, maxiter=30, **NOSTOP)
-        assert _rel(a[k]["W"][r] @ a[k]["H"][r], ref["W"] @ ref["H"], X) <= 1e-4
-        assert abs(a[k]["objvalue"][r] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
-
-
-def test_shared_x_kernel_restarts_stop_independently(NMFk, ctx, oracle):
-    """Default stop rule on a planted matrix: the restarts of a shared-X group leave the loop at different checks; a
-    stopped restart must stay frozen while its group mates go on.  Same iteration counts, stop reasons and (bitwise)
-    factors as the per-restart kernels under the same geometry."""
-    n, m, k0 = 200, 48, 3
-    W0 = oracle.uniform_fill(31, 0, n * k0).reshape(n, k0)
-    H0 = oracle.uniform_fill(32, 0, k0 * m).reshape(k0, m)
-    X = (W0 @ H0 + 0.01 * oracle.uniform_fill(33, 0, n * m).reshape(n, m)).astype(np.float32)
-    ctx.set_X(X)
-    ks, R = [2, 3, 4, 6], 8
-    seeds = _seeds(NMFk, 13, ks, R)
-    with _env(NMFK_SHX=1, NMFK_TARGET_WGS=1):
-        a = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=3000, tolOF=1e-2)
-        assert ctx.last_sweep_info()["shared_x_units"] == len(ks) * R
-    with _env(NMFK_SHX=0, NMFK_TARGET_WGS=1):
-        b = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=3000, tolOF=1e-2)
-    spread = 0
-    for k in ks:
-        assert (a[k]["iters"] == b[k]["iters"]).all() and (a[k]["reason"] == b[k]["reason"]).all()
-        assert (a[k]["W"] == b[k]["W"]).all() and (a[k]["H"] == b[k]["H"]).all()
-        spread = max(spread, int(a[k]["iters"].max() - a[k]["iters"].min()))
-    assert spread >= 10  # the case does exercise restarts of one group stopping at different checks
-
-
 def test_valu_kernels_unperturbed_by_concurrent_mfma_sweep(NMFk, oracle):
     """Two contexts on one GPU (separate arenas and streams): the packed-VALU sweep of one must give bit-identical
     results whether or not the other runs the split-operand MFMA group (half-steps + its monitored objective) at the

@@ -171,9 +171,48 @@ struct Sampler {
   }
 };
 
+// Schedule overrides for A/B measurements and tests (the defaults are the product): environment variables, read in this
+// ONE place at the start of every sweep (a sweep runs seconds; tests flip them between sweeps).
+//   NMFK_TARGET_WGS   workgroups a half-step launch should have before loop ranges are split (default 2 x CUs)
+//   NMFK_MFMA_WIDE    0: ranks > 16 on the packed-VALU kernel instead of the all-MFMA one
+//   NMFK_HYB          0 / 1: split-operand MFMA half-step off / on for the ranks >= NMFK_HYB_MINK (default: automatic)
+//   NMFK_HYB_GROUPS   mixed-rank launch groups of that kernel in merged sweeps (1)
+//   NMFK_MERGE        g: the ranks <= 16 share g mixed-rank packed-VALU launch groups (default: by restarts per rank)
+//   NMFK_HYB_PHASES   0 / 1: force the one-phase / two-phase sweep
+//   NMFK_MAX_WSPLIT   4 / 8: waves of a workgroup that may split a loop range
+//   NMFK_MFMA_SSE, NMFK_HYB_SSE   0: monitored objective of the MFMA groups on the packed-VALU objective kernel
+//   NMFK_STREAMS      concurrent rank-group streams (8);  NMFK_HOST_TIMING=1 prints the host's share of the loop
+struct Tuning {
+  int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, hyb_groups = 1, merge = -1, phases = -1, max_wsplit = 8;
+  int wide_sse = 1, hyb_sse = 1, streams = 8, host_timing = 0;
+};
+Tuning read_tuning() {
+  Tuning t;
+  auto geti = [](const char *name, int &dst) {
+    if (const char *e = getenv(name)) dst = atoi(e);
+  };
+  geti("NMFK_TARGET_WGS", t.target_wgs);
+  geti("NMFK_MFMA_WIDE", t.wide);
+  geti("NMFK_HYB", t.hyb);
+  if (t.hyb > 1) t.hyb = 1;
+  geti("NMFK_HYB_MINK", t.hyb_mink);
+  geti("NMFK_HYB_GROUPS", t.hyb_groups);
+  t.hyb_groups = std::max(1, t.hyb_groups);
+  geti("NMFK_MERGE", t.merge);
+  geti("NMFK_HYB_PHASES", t.phases);
+  geti("NMFK_MAX_WSPLIT", t.max_wsplit);
+  t.max_wsplit = t.max_wsplit >= 8 ? 8 : 4;
+  geti("NMFK_MFMA_SSE", t.wide_sse);
+  geti("NMFK_HYB_SSE", t.hyb_sse);
+  geti("NMFK_STREAMS", t.streams);
+  t.streams = std::max(1, std::min(64, t.streams));
+  geti("NMFK_HOST_TIMING", t.host_timing);
+  return t;
+}
+
 }  // namespace
 
-NMFK_EXPORT int nmfk_version(void) { return 100; }
+NMFK_EXPORT int nmfk_version(void) { return 200; }
 
 NMFK_EXPORT const char *nmfk_last_error(void) { return g_last_error.c_str(); }
 
@@ -550,66 +589,61 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // Launch geometry of the two half-steps (see step_body): wsplit = 1 when the lane dimension alone fills the
   // chip, else the four waves of a workgroup share 64*LB lane elements and split the loop range; grid-level
   // splits S > 1 (finished by the reduce kernel) only when there are too few units to fill the chip otherwise.
+  const Tuning T = read_tuning();
   const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-  int target = 2 * cus;
-  if (const char *e = getenv("NMFK_TARGET_WGS")) target = std::max(1, atoi(e));
+  const int target = T.target_wgs > 0 ? T.target_wgs : 2 * cus;
   struct Geo {
     int wsplit, S, dchunk, fused, slots;
   };
-  // ranks above 16 use the all-MFMA half-step (fp32 compute, no missing data, dense X); NMFK_MFMA_WIDE=0 disables
-  int wide_on = 1;
-  if (const char *e = getenv("NMFK_MFMA_WIDE")) wide_on = atoi(e);
-  const bool wide_ok_nowide = !f64 && !ctx->sparse && ctx->nan_count == 0 && n >= 16 && m >= 16;
-  const bool wide_ok = wide_on && wide_ok_nowide;
-  bool any_wide = false;
-  for (int q = 0; q < nk; ++q) any_wide = any_wide || (wide_ok && ks[q] > 16);
-  // ranks in [mfma_mink, 16] can use an MFMA variant of the half-step too: experimental, off by default (see
-  // no gain over the packed-VALU kernel at k <= 16); enable with NMFK_MFMA_MINK=<k>
-  int mfma_mink = 0;
-  if (const char *e = getenv("NMFK_MFMA_MINK")) mfma_mink = atoi(e);
+  // ranks above 16 use the all-MFMA half-step (fp32 compute, no missing data, dense X)
+  const bool mfma_ok = !f64 && !ctx->sparse && ctx->nan_count == 0 && n >= 16 && m >= 16;
+  const bool wide_ok = T.wide && mfma_ok;
   auto use_wide_k = [&](int k) { return wide_ok && k > 16; };
-  auto use_mfma_k = [&](int k) { return wide_ok_nowide && k <= 16 && mfma_mink > 0 && k >= mfma_mink; };
-  // ranks in [hyb_mink, 16]: split-operand MFMA half-step (nmfk_step_hyb.hip).  Its cost does not depend on the rank
-  // and ONE instantiation serves all ranks, so it pays where the sweep has few restarts per rank (8-GPU strong scaling):
-  // there the ranks >= 6 run as one mixed-rank launch group on it (MU loop of one rank's share at 8 GPUs 3.98 -> 3.16 s)
-  // and only the small ranks stay on the merged packed-VALU kernel.  With many restarts per rank it is 1.3x faster than
-  // the packed-VALU kernel at k = 16 on a GPU filled with one rank but slower inside the mixed sweep, so
-  // it stays off there.  NMFK_HYB=0 / 1 forces it off / on (on: per-rank launches for ranks >= NMFK_HYB_MINK = 5).
-  int hyb_on = -1, hyb_mink = -1;
-  if (const char *e = getenv("NMFK_HYB")) hyb_on = atoi(e) != 0;
-  if (const char *e = getenv("NMFK_HYB_MINK")) hyb_mink = std::max(1, atoi(e));
-  int hyb_groups = 1;  // merged sweeps: number of mixed-rank launch groups of the split-operand MFMA kernel
-  if (const char *e = getenv("NMFK_HYB_GROUPS")) hyb_groups = std::max(1, atoi(e));
-  int merge = -1;
-  const bool merge_env = getenv("NMFK_MERGE") != nullptr;
-  if (merge_env) merge = atoi(getenv("NMFK_MERGE"));
+  // Ranks in [hyb_mink, 16]: split-operand MFMA half-step (nmfk_step_hyb.hip).  Its cost does not depend on the rank
+  // and ONE instantiation serves all ranks, so its units share one launch group.  Two schedules use it:
+  //  * few restarts per rank (<= 8; a rank's share at 4-8 GPUs): a merged sweep, the ranks >= 6 as one group on it
+  //    beside one merged packed-VALU group of the small ranks (per-rank launches would be launch-bound);
+  //  * many restarts per rank: a TWO-PHASE sweep -- the ranks >= k0 run FIRST, as one group with the GPU to themselves
+  //    (its fp32 MFMAs and the packed FMAs of the other ranks' kernels share the multipliers, so the two kinds must not
+  //    run side by side), then the other ranks on their per-rank packed-VALU launches.
+  // The two-phase rule is a cost model in (n, m, ranks, restarts), constants measured on MI355X (profiles/r02/
+  // schedule_shapes.txt): per factorization and iteration a packed-VALU unit costs E' * (1406 + 324 k) ns and a unit
+  // of the group E' * 3670 ns + 8.5 ns per workgroup of its W half-step, E' = n*m / (8192*512); inside the mixed
+  // sweep the packed-VALU ranks overlap better than one at a time, which moves the break-even from k = 7 to 8.8 at the
+  // reference shape.  The phases are taken when (a) the group's launches are long enough not to be launch-bound,
+  // (b) its workgroups in the short dimension cover at least half the CUs, and (c) the model promises >= 300
+  // rank-restarts of saving (k = 2:12 x 32 would lose 3 %, k = 2:16 x 32 gains 15 %, x 16 gains 5 %).
+  int hyb_on = T.hyb, hyb_mink = T.hyb_mink;
+  const int hyb_groups = T.hyb_groups;  // merged sweeps: number of mixed-rank launch groups of the split-operand MFMA kernel
+  int merge = T.merge;
+  const bool merge_env = T.merge >= 0;
   if (merge < 0) merge = nruns <= NMFK_MERGE_MAX_RUNS ? std::min(nruns, NMFK_MERGE_GROUPS) : 0;
-  if (ctx->sparse || mfma_mink > 0) merge = 0;
+  if (ctx->sparse) merge = 0;
   merge = std::min(merge, nruns);
-  // Two-phase sweep (many restarts per rank): the ranks >= 9 run FIRST, as one mixed-rank group on the split-operand
-  // MFMA kernel with the GPU to themselves (enough units to fill it: its fp32 MFMAs and the packed FMAs of the other
-  // ranks' kernels share the multipliers, so the two kinds must not run side by side), then the other ranks on their
-  // per-rank packed-VALU launches.  Bench sweep, 200 iterations: 401.8 -> 245.3 + 126.6 ms.  NMFK_HYB_PHASES=0 / 1.
   bool hyb_phases = false;
-  const bool hyb_fits = wide_ok_nowide && mfma_mink == 0 && (int64_t)n * m * 4 < ((int64_t)1 << 32) - 4096;
+  // (the kernel's buffer loads address X with 32-bit byte offsets from the array base)
+  const bool hyb_fits = mfma_ok && (int64_t)n * m * 4 < ((int64_t)1 << 32) - 4096;
   if (hyb_on < 0) {  // automatic (an explicit NMFK_MERGE keeps the packed-VALU groups)
-    // first rank of the group: 9 with 32 restarts per rank (381 vs 406 ms per 200 iterations), 12 with 16 (313 vs 331 ms
-    // per 300; 9: 221 vs 216 per 200), none with 8 (151 vs 120)
-    // (24 restarts: 9 -> 331, 12 -> 303 vs 320 ms one phase; 20: 281 / 259 vs 274; 12 restarts: no difference)
-    const int mk = hyb_mink >= 0 ? hyb_mink : (nruns <= 8 ? 6 : (nruns >= 32 ? 9 : 12));
+    const double Erel = (double)n * m / (8192.0 * 512.0);
+    const double wg_ns = 8.5 * ((double)n + m) / 256.0;              // per-workgroup overhead of a unit of the group
+    const double k0 = 8.8 + (wg_ns / Erel - 8.5 * 34.0) / 324.0;     // break-even rank (8.8 at 8192 x 512)
+    // first rank of the group: the break-even (9 at the reference shape, also with 16 restarts per rank: 206 vs 216 ms
+    // per 200 iterations; 2048 x 2048: 180 vs 294), 6 in merged sweeps
+    const int mk = hyb_mink >= 0 ? hyb_mink : (nruns <= 8 ? 6 : std::min(16, (int)ceil(k0)));
     int hyb_units = 0;
-    double hyb_score = 0;  // ~ what the group saves: the packed-VALU cost of a unit grows with k, the group's does not
+    double hyb_score = 0;  // what the group saves, in rank-restarts (a packed-VALU unit costs ~k, a unit of the group ~k0)
     for (int q = 0; q < nk; ++q)
       if (hyb_fits && ks[q] <= 16 && ks[q] >= mk) {
         hyb_units += nruns;
-        hyb_score += (ks[q] - 8.8) * nruns;
+        hyb_score += (ks[q] - k0) * nruns;
       }
-    const bool few = !merge_env && !ctx->sparse && mfma_mink == 0 && nruns <= 8 && hyb_units > 0;  // (8 restarts: 177-179 vs 186 ms)
-    if ((merge > 0 && !merge_env) || few) {  // few restarts per rank: merged sweep, the ranks >= 6 as one group beside the small ones
+    const bool few = !merge_env && !ctx->sparse && nruns <= 8 && hyb_units > 0;  // (8 restarts: 177-179 vs 186 ms)
+    const double launch_ns = hyb_units * Erel * 1835.0;                         // one half-step launch of the group
+    const int64_t h_wgs = (int64_t)hyb_units * ((std::min(n, m) + 255) / 256);  // its workgroups in the short dimension
+    if ((merge > 0 && !merge_env) || few) {  // few restarts per rank: merged sweep
       hyb_on = 1;
       if (hyb_units > 0) merge = 1;  // the few small ranks left: one packed-VALU group (126 vs 130 ms per 400 iterations)
-    } else if (merge == 0 && !merge_env && nruns >= 16 && hyb_units >= 64 && hyb_score >= 300) {
-      // (score 947 / 416: the bench sweep at 32 / 16 restarts, -14 % / -11 %; 218: k = 2:12 x 32, +2 %; 45: k = 2:10 x 32, +7 %)
+    } else if (merge == 0 && !merge_env && nruns >= 16 && launch_ns >= 50e3 && 2 * h_wgs >= cus && hyb_score >= 300) {
       hyb_on = 1;
       hyb_phases = true;
     } else {
@@ -617,25 +651,18 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     }
     hyb_mink = mk;
   }
-  if (const char *e = getenv("NMFK_HYB_PHASES")) hyb_phases = hyb_on && merge == 0 && atoi(e) != 0;
+  if (T.phases >= 0) hyb_phases = hyb_on && merge == 0 && T.phases != 0;
   if (hyb_mink < 0) hyb_mink = 5;
-  auto use_hyb_k = [&](int k) {
-    // (its buffer loads address X with 32-bit byte offsets from the array base)
-    return hyb_on && wide_ok_nowide && mfma_mink == 0 && k <= 16 && k >= hyb_mink &&
-           (int64_t)n * m * 4 < ((int64_t)1 << 32) - 4096;
-  };
+  auto use_hyb_k = [&](int k) { return hyb_on && hyb_fits && k <= 16 && k >= hyb_mink; };
   // lane elements per workgroup (= per sum-table slot) of the half-step kernel a rank runs
   auto lane_tile = [&](int k, int ws) {
     if (ctx->sparse) return NMFK_TILE;
     if (use_wide_k(k)) return nmfk_mfma_wide_lane_tile(ws);
-    if (use_mfma_k(k)) return ws == 4 ? 64 : NMFK_TILE;
     if (use_hyb_k(k)) return nmfk_hyb_lane_tile(ws);
     if (merge > 0 && k <= NMFK_MULTI_MAXK && !use_hyb_k(k)) return (ws > 1 ? 64 : NMFK_TILE) * NMFK_MULTI_LB;
     return (ws > 1 ? 64 : NMFK_TILE) * NMFK_LB_OF(nmfk_padded_k(k));
   };
-  int max_ws = 8;  // the experimental MFMA variant is written for 4-wave workgroups
-  if (const char *e = getenv("NMFK_MFMA_MINK")) max_ws = atoi(e) > 0 ? 4 : 8;
-  if (const char *e = getenv("NMFK_MAX_WSPLIT")) max_ws = atoi(e) >= 8 ? 8 : 4;
+  const int max_ws = T.max_wsplit;
   // phases of a two-phase sweep run one after the other, so each gets the geometry that fills the chip with ITS units
   auto phase_of_k = [&](int k) { return hyb_phases && !use_hyb_k(k) ? 1 : 0; };
   auto geometry = [&](int L, int D, int phase) {
@@ -943,12 +970,10 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // exchange data before the clustering step, so no cross-stream synchronisation is needed inside the loop.
   const int ngroups = (int)groups.size();
   auto use_wide = [&](const Group &G) { return use_wide_k(G.k); };
-  const bool wide_sse = !(getenv("NMFK_MFMA_SSE") && atoi(getenv("NMFK_MFMA_SSE")) == 0);
-  auto use_mfma = [&](const Group &G) { return use_mfma_k(G.k); };
+  const bool wide_sse = T.wide_sse != 0;
   auto use_hyb = [&](const Group &G) { return G.hyb != 0; };
-  const bool hyb_sse = !(getenv("NMFK_HYB_SSE") && atoi(getenv("NMFK_HYB_SSE")) == 0);  // objective of those groups on the matrix pipe
-  int max_streams = 8;
-  if (const char *e = getenv("NMFK_STREAMS")) max_streams = std::max(1, std::min(64, atoi(e)));
+  const bool hyb_sse = T.hyb_sse != 0;  // objective of those groups on the matrix pipe
+  const int max_streams = T.streams;
   const int NS = std::min(ngroups, max_streams);
   while ((int)ctx->gstreams.size() < NS) {
     hipStream_t gs;
@@ -1030,8 +1055,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_step_f64(hs, d_hs, G.kp, G.begin, G.count, gs);
         else if (use_wide(G))
           nmfk_launch_step_mfma_wide_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
-        else if (use_mfma(G))
-          nmfk_launch_step_mfma_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         else
           nmfk_launch_step_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         if (timed) prof.end(e0, PK_HSTEP, j, it, gs);
@@ -1059,8 +1082,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_step_f64(ws, d_ws, G.kp, G.begin, G.count, gs);
         else if (use_wide(G))
           nmfk_launch_step_mfma_wide_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
-        else if (use_mfma(G))
-          nmfk_launch_step_mfma_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         else
           nmfk_launch_step_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         if (timed) prof.end(e0, PK_WSTEP, j, it, gs);
@@ -1118,7 +1139,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     HIPCHECK(hipStreamSynchronize(poll));
   }
   }  // phases
-  if (getenv("NMFK_HOST_TIMING"))
+  if (T.host_timing)
     fprintf(stderr, "[nmfk] loop: %d iterations, %d groups, host %.3f s of which waiting for the GPU %.3f s\n", total_iters,
             ngroups, std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_w0).count(), host_wait_s);
   HIPCHECK(hipGetLastError());

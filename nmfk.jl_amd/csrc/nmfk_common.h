@@ -178,12 +178,6 @@ static inline int nmfk_padded_k(int k) {
 #ifndef NMFK_UNIT_FAST
 #define NMFK_UNIT_FAST 0     // half-step grids: 1 = unit is the fast dimension (see the launchers: measured worse for L2)
 #endif
-#ifndef NMFK_PCHAINS
-#define NMFK_PCHAINS 1       // independent partial sums of <a, b> in the element-packed half-step (2, 4: no gain measured)
-#endif
-#ifndef NMFK_ADJ
-#define NMFK_ADJ 0           // 1: the two lane elements of a thread are adjacent, one 8-byte X load per step (measured 5-10 % slower)
-#endif
 #ifndef NMFK_EPACK
 #define NMFK_EPACK 1         // packed VALU lanes = the two lane elements of a thread (1) or adjacent signals (0)
 #endif
@@ -201,18 +195,6 @@ static inline int nmfk_padded_k(int k) {
 #endif
 #ifndef NMFK_WIDE_NT
 #define NMFK_WIDE_NT 2   // 16-wide lane tiles per wave of the all-MFMA kernel for k > 16
-#endif
-#ifndef NMFK_LDSB
-#define NMFK_LDSB 0      // 1: loop-factor rows through LDS for kp >= NMFK_LDSB_MINK (no missing data)
-#endif
-#ifndef NMFK_LDSB_MINK
-#define NMFK_LDSB_MINK 9
-#endif
-#ifndef NMFK_MFMA_EXP
-#define NMFK_MFMA_EXP 0
-#endif
-#ifndef NMFK_UPOL
-#define NMFK_UPOL 2
 #endif
 #ifndef NMFK_FASTDIV
 #define NMFK_FASTDIV 2  // 2: v_rcp_f32 (1 ulp) * x; 1: + one Newton step; 0: IEEE divide.  fp32 ratio X/(W*H) by v_rcp_f32 + one Newton step instead of the IEEE divide sequence
@@ -251,7 +233,6 @@ void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double w
                          hipStream_t s);
 void nmfk_launch_hyb_tile(const float *src, int L, int D, float *out, hipStream_t s);
 void nmfk_launch_sse_mfma_wide_f32(const NmfkSseArgs &a, int kp, int u0, int cnt, hipStream_t s);
-void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f64)
 
 // nmfk_cluster.hip

@@ -29,11 +29,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
-#ifdef HYB_DBG_NOBAR
-#define HYB_BARRIER() __builtin_amdgcn_wave_barrier()
-#else
 #define HYB_BARRIER() __syncthreads()
-#endif
 __device__ __forceinline__ float hyb_div(float x, float p) { return x * __builtin_amdgcn_rcpf(p); }
 
 // term blocks of the first product: MFMA j, k-lane group g -> split index (0 = h, 1 = m, 2 = l) of the loop factor
@@ -268,11 +264,7 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
   auto xload = [&](int dch, f32x4_t (&xv)[NT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
-#ifdef HYB_DBG_NOX
-      xv[t] = (f32x4_t){1.f, 2.f, 3.f, 4.f};
-#else
       xv[t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, xoff[t], dch * 64, 0));
-#endif
   };
   // one chunk of 16 loop steps from the staged operands (av: split rows of the chunk, bn: its transposed block);
   // MASK: the chunk crosses the end of the loop range, ratios of the steps >= d1 are dropped
@@ -372,28 +364,18 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
         xload(FULLT ? dch + 32 : min(dch + 32, dlast), xr[(ci + 2) & 3]);
         // (vmcnt retires in order: issued AFTER this chunk's X prefetch, the rows of the next block -- they come from
         // beyond L2 -- are not covered by the wait for X two chunks on, only by the one three chunks on)
-#if !defined(HYB_DBG_NOSTAGE) && !defined(HYB_DBG_NOSTAGE_L)
         if (ch == 0 && more) stage.load(dch + 16 * CPB, sv, svrow);
-#endif
         // the next block goes to the free LDS buffer BEFORE the block's last chunk, so that the conversion and the
         // LDS writes overlap with that chunk's matrix work instead of sitting in front of the barrier
-#if !defined(HYB_DBG_NOSTAGE) && !defined(HYB_DBG_NOSTAGE_W)
         if (CPB > 1 && ch == CPB - 1 && more) stage.write(sb + (buf ^ 1) * ST::STB, sv, svrow);
-#endif
         __builtin_amdgcn_sched_barrier(0);  // loads stay in front of the arithmetic they overlap with
         {
           const char *b = sb + buf * ST::STB;
           u32x4_t av[NM];
 #pragma unroll
-#ifdef HYB_DBG_NOLDSR
-          for (int j = 0; j < NM; ++j) av[j] = (u32x4_t){0x3f803f80u + (uint32_t)(ch + j), 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-          f32x4_t bn = (f32x4_t){1.f, 2.f, 3.f, 4.f};
-          (void)b; (void)fofs; (void)nofs;
-#else
           for (int j = 0; j < NM; ++j) av[j] = *(const u32x4_t *)(b + ch * 16 * ST::RS + fofs + hyb_sa<KS>(j, g) * (KS * 2));
           f32x4_t bn = (f32x4_t){0.f, 0.f, 0.f, 0.f};
           if (!OBJ) bn = *(const f32x4_t *)(b + nofs + ch * 16 * ST::FRS);
-#endif
           chunk(dch, xr[ci & 3], av, bn, !FULLT && dch + 16 > d1);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -408,7 +390,6 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
     for (; c0 + TRIP + AHEAD <= nchunks; c0 += TRIP) trip(c0, std::true_type());
     for (; c0 < nchunks; c0 += TRIP) trip(c0, std::false_type());
   };
-#ifndef HYB_DBG_NOLOOP
   if (OBJ) {
     HybStage<KS, 4, 64 * NW, false> stage;
     stage.init(B, k, D, tid);
@@ -436,7 +417,6 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
     run(stage, sbase + wave * 2 * HybStage<KS, 1, 64, true>::STB, [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); });
     __syncthreads();  // the cross-wave scratch below overlays the staging buffers
   }
-#endif
   // acc[t][r] = numerator of signal c = 4g + r at lane element l0 + 16t + c16
 
   float *scratch = (float *)sbase;
@@ -480,11 +460,7 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
   double *sumA = (double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)) + (int64_t)tile * k;
   double *red = den + 16;  // [8][16]
   float vs[4] = {0.f, 0.f, 0.f, 0.f};
-#ifdef HYB_DBG_NOFIN
-  if (owner && acc[0][0] == 12345.f) {
-#else
   if (owner) {
-#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       if (lv[t]) {

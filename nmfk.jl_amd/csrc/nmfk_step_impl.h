@@ -199,13 +199,7 @@ template <int KP, int LB, bool NANS>
 __device__ __forceinline__ void step_body(char *arena, const float *__restrict__ X, const NmfkStepArgs *__restrict__ gp,
                                           const NmfkRun *__restrict__ rdp, const int it, double *lds, const int bx) {
   // loop steps per group: the loop-factor rows of TWO groups live in SGPRs (about 100 available)
-#if NMFK_UPOL == 1
-  constexpr int U = (KP <= 4) ? 4 : (KP <= 12) ? 2 : 1;
-#elif NMFK_UPOL == 2
   constexpr int U = (KP <= 6) ? 4 : (KP <= 12) ? 2 : 1;
-#else
-  constexpr int U = (KP <= 4) ? 4 : (KP <= 8) ? 2 : 1;
-#endif
   constexpr bool PIPE = KP <= 24;  // wider factors: single buffer, no run-ahead loads
   // Only the pointers are by-value kernel arguments (the compiler must know they are global memory to use
   // scalar loads); the rest of the argument block and the unit descriptor live in device memory and are read
@@ -232,9 +226,8 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   const int tile = bx / g.S;  // bx: index of the (lane tile, loop split) pair, see NMFK_GRID
   const int s = bx - tile * g.S;
   if (tile * lpw * LB >= g.L) return;  // the grid is sized for the smallest LB of the launch
-  // lane elements of a thread: NMFK_ADJ: LB adjacent ones (one wide X load per loop step), else lpw apart
-  constexpr bool ADJ = (NMFK_ADJ != 0) && (NMFK_XBUF != 0) && LB == 2;
-  const int lbase = ADJ ? tile * lpw * LB + LB * ((ws > 1) ? lane : tid) : tile * lpw * LB + ((ws > 1) ? lane : tid);
+  // lane elements of a thread: lpw apart (adjacent ones with one 8-byte X load measured 5-10 % slower)
+  const int lbase = tile * lpw * LB + ((ws > 1) ? lane : tid);
 
   const T *__restrict__ Hcur = NMFK_PTR(const T, g, NMFK_HOFF(*rdp, g.it));
   const T *__restrict__ Hnew = NMFK_PTR(const T, g, NMFK_HOFF(*rdp, g.it + 1));
@@ -260,7 +253,7 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
 #define ACC_(e, c) (EP ? acce[EP ? (c) : 0][(e)] : (TAIL && (c) == KP - 1) ? acct[(e)] : acc2[(e)][(c) / 2][(c) & 1])
 #pragma unroll
   for (int e = 0; e < LB; ++e) {
-    const int l = ADJ ? lbase + e : lbase + e * lpw;
+    const int l = lbase + e * lpw;
     valid[e] = l < g.L;
     lc[e] = valid[e] ? l : 0;
     at[e] = (T)0;
@@ -315,20 +308,9 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
     for (int uu = 0; uu < U; ++uu) {
 #pragma unroll
       for (int c = 0; c < KP; ++c) bufv[uu][c] = bnext[uu * KP + c];
-      if (ADJ) {  // the pair (l, l + 1) in one 8-byte load (dword alignment suffices); l + 1 may be a dummy
-        typedef float xpair_t __attribute__((ext_vector_type(2)));
-        const xpair_t xx = __builtin_bit_cast(xpair_t, __builtin_amdgcn_raw_buffer_load_b64(rs, lbyte[0], uu * ldb, 0));
-        bufx[uu][0] = xx.x;
-        bufx[uu][LB - 1] = xx.y;
-        continue;
-      }
 #pragma unroll
       for (int e = 0; e < LB; ++e)
-#ifdef NMFK_DBG_NOLOAD
-        bufx[uu][e] = __builtin_bit_cast(float, lbyte[e] + uu);
-#else
         bufx[uu][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lbyte[e], uu * ldb, 0));
-#endif
     }
     xnext += U * ld;
 #else
@@ -358,18 +340,10 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   };
   auto row = [&](int d, const T *bv, const float *xf) __attribute__((always_inline)) {
     if (EP) {
-      // NMFK_PCHAINS independent partial sums: a single chain of KP dependent FMAs leaves a wave waiting on its own
-      // previous result at every step
-      constexpr int NCH = KP >= 2 * NMFK_PCHAINS ? NMFK_PCHAINS : 1;
-      T2 pp[NCH];
+      // (2 or 4 independent partial sums instead of one chain of KP dependent FMAs: no gain measured)
+      T2 pp[1] = {splat2((T)0)};
 #pragma unroll
-      for (int h = 0; h < NCH; ++h) pp[h] = splat2((T)0);
-#pragma unroll
-      for (int c = 0; c < KP; ++c) pp[c % NCH] = fma2(ae[EP ? c : 0], splat2(bv[c]), pp[c % NCH]);
-#pragma unroll
-      for (int h = NCH / 2; h > 0; h >>= 1)
-#pragma unroll
-        for (int i = 0; i < h; ++i) pp[i] = pp[i] + pp[i + h];
+      for (int c = 0; c < KP; ++c) pp[0] = fma2(ae[EP ? c : 0], splat2(bv[c]), pp[0]);
       T2 p2 = pp[0];
       T2 x2 = {(T)xf[0], (T)xf[LB - 1]};
       if (NANS) {
@@ -382,11 +356,7 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
           }
         }
       }
-#ifdef NMFK_DBG_NORCP
-      const T2 q2 = x2 * p2;
-#else
       const T2 q2 = div2(x2, p2);
-#endif
 #pragma unroll
       for (int c = 0; c < KP; ++c) acce[EP ? c : 0] = fma2(splat2(bv[c]), q2, acce[EP ? c : 0]);
       return;
@@ -429,68 +399,6 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   };
 
   int d = d0;
-#if NMFK_LDSB
-  // Variant: loop-factor rows staged through LDS.  Scalar loads can only be waited for with lgkmcnt(0), which caps
-  // their run-ahead at one loop step; here a wave copies 16 rows at a time into its own LDS buffer one whole chunk
-  // (16 loop steps) ahead with ordinary vector loads, reads each row back as a broadcast, and keeps X loads three
-  // rows ahead (vmcnt is counted, in order).
-  if (!NANS && KP >= NMFK_LDSB_MINK) {
-    constexpr int CH = 16, CHF = CH * KP, NPL = (CHF + 63) / 64;
-    T *stg = (T *)(lds + 9 * NMFK_MAX_K) + wave * 2 * CHF;
-    const int64_t bend = (int64_t)g.D * KP - 1;
-    T sreg[NPL];
-    auto gload = [&](int dch) __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < NPL; ++q) {
-        const int64_t o = (int64_t)dch * KP + lane + 64 * q;
-        sreg[q] = B[o < bend ? o : bend];
-      }
-    };
-    auto swrite = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < NPL; ++q)
-        if (lane + 64 * q < CHF) stg[buf * CHF + lane + 64 * q] = sreg[q];
-    };
-    float xq[4][LB];
-    auto xload = [&](int rr, float (&xs)[LB]) __attribute__((always_inline)) {
-      const float *__restrict__ xr = g.X + (int64_t)min(rr, d1 - 1) * ld;
-#pragma unroll
-      for (int e = 0; e < LB; ++e) xs[e] = xr[lofs[e]];
-    };
-    if (d1 > d0) {
-      gload(d0);
-      xload(d0, xq[0]);
-      xload(d0 + 1, xq[1]);
-      xload(d0 + 2, xq[2]);
-    }
-    int cur = 0;
-    for (int dch = d0; dch < d1; dch += CH) {
-      swrite(cur);
-      if (dch + CH < d1) gload(dch + CH);
-      __builtin_amdgcn_wave_barrier();
-      const T *cb = stg + cur * CHF;
-      const int rend = min(CH, d1 - dch);
-#pragma unroll 1
-      for (int r0 = 0; r0 < rend; r0 += 4) {
-#pragma unroll
-        for (int uu = 0; uu < 4; ++uu) {
-          const int r = r0 + uu;
-          xload(dch + r + 3, xq[(uu + 3) & 3]);
-          if (r < rend) {
-            T bv[KP];
-#pragma unroll
-            for (int c = 0; c < KP; ++c) bv[c] = cb[r * KP + c];
-            row(dch + r, bv, xq[uu]);
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      cur ^= 1;
-    }
-    d = d1;
-    if (ws > 1) __syncthreads();  // the cross-wave scratch below overlays the staging buffers
-  }
-#endif
   const int nfull = (d1 - d) / U;
   if (nfull > 0) {
     T v0[U][KP], v1[U][KP];  // the two register buffers: loop-factor rows (SGPRs) ...
@@ -675,276 +583,9 @@ __global__ __launch_bounds__(2 * NMFK_TILE, NMFK_MULTI_MINWAVES) void step_kerne
   }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// MFMA variant of the half-step (fp32, no missing data, k <= 16), v_mfma_f32_16x16x4_f32.
-//
-// On gfx950 the fp32 MFMA rate equals the fp32 vector rate, so this kernel is not faster per se -- but it runs on
-// the MATRIX pipe while the VALU kernels of the small ranks run on the vector pipe of the same CUs (different
-// streams), and it needs ~1/3 of the VALU instructions per element (only the ratio).  Both products of a
-// 16 (loop) x 16 (lane) tile are MFMAs:
-//     P[d][l]  = sum_c B[c][d] * A[c][l]            ceil(k/4) MFMAs   (A-operand rows = loop steps d)
-//     N[c][l] += sum_d B[c][d] * Q[d][l]            4 MFMAs           (Q = X ./ P is already in B-operand layout:
-//                                                                      C/D register r of lane (g, j) = row 4g+r, col j)
-// A wave owns 64 lane elements = 4 tiles (numerators: 4 x 4 VGPRs) and walks its loop range in chunks of 16.
-// ------------------------------------------------------------------------------------------------------
 #ifdef NMFK_IS_F32
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-byte global access
-
-template <int KQ, bool FULLK>  // KQ = ceil(k / 4): MFMAs of the first product; FULLK: k == 4*KQ (no signal masks)
-__global__ __launch_bounds__(NMFK_TILE) void mfma_step_kernel(char *arena, const float *__restrict__ X,
-                                                              const NmfkRun *__restrict__ runs,
-                                                              const NmfkState *__restrict__ state,
-                                                              const NmfkStepArgs *__restrict__ gp, int it, int u0) {
-  __shared__ double lds[5 * NMFK_MAX_K + 3 * 16 * 32];  // den[64], red[4*64], cross-wave scratch 3 x 16 x 64 floats
-  const int u = u0 + blockIdx.y;
-  if (!gp->force && !state[u].active) return;
-  const NmfkRun *__restrict__ rdp = runs + u;
-  const int kp = rdp->kp, k = rdp->k;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const int which = gp->which, ws = gp->wsplit, S = gp->S, L = gp->L, D = gp->D;
-  const int lpw = (ws == 4) ? 64 : NMFK_TILE;
-  const int tile = blockIdx.x / S, s = blockIdx.x - tile * S;
-  const int l0 = tile * lpw + ((ws == 4) ? 0 : wave * 64);
-
-  const float *__restrict__ Hcur = (const float *)(arena + NMFK_HOFF(*rdp, it));
-  const float *__restrict__ Hnew = (const float *)(arena + NMFK_HOFF(*rdp, it + 1));
-  const float *__restrict__ Wt = (const float *)(arena + rdp->oWt);
-  const float *__restrict__ A = which == 0 ? Hcur : Wt;  // lane factor
-  const float *__restrict__ B = which == 0 ? Wt : Hnew;  // loop factor
-
-  int d0 = s * gp->dchunk;
-  int d1 = min(D, d0 + gp->dchunk);
-  if (ws == 4) {
-    const int q = (((d1 - d0 + 3) >> 2) + 15) & ~15;  // quarter of the range per wave, in whole chunks
-    d0 = min(d0 + wave * q, d1);
-    d1 = min(d0 + q, d1);
-  }
-  d0 = __builtin_amdgcn_readfirstlane(d0);  // wave-uniform: keeps the chunk loop and its fast-path test scalar
-  d1 = __builtin_amdgcn_readfirstlane(d1);
-
-  // Signal index of the first product's contraction: MFMA step sq, k-lane g  <->  c = KQ*g + sq, so that the KQ
-  // values a lane needs from one loop-factor row are contiguous and KQ = ceil(k/4) steps cover all signals.
-  // B-operand fragments of the first product, persistent: A[c = KQ*g + sq][l = l0 + 16t + c16]
-  float afrag[4][KQ];
-  int lt[4];
-  bool lv[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int l = l0 + 16 * t + c16;
-    lv[t] = l < L;
-    lt[t] = lv[t] ? l : 0;
-#pragma unroll
-    for (int sq = 0; sq < KQ; ++sq) {
-      const int c = KQ * g + sq;
-      afrag[t][sq] = (lv[t] && c < k) ? A[c + (int64_t)lt[t] * kp] : 0.0f;
-    }
-  }
-  f32x4_t acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  // X is read from the copy in which the LOOP dimension is contiguous (Xalt: element (l, d) at d + l*D), so the
-  // four rows 4g..4g+3 of a lane are one 16-byte load; the 16 x kp chunk of the loop factor is staged through a
-  // per-wave LDS buffer (one 16-byte load per lane, row stride 17 floats against bank conflicts) and read back
-  // as fragments.  Loads run one chunk ahead in two register sets (no copies).
-  // (the host only selects this kernel when D >= 16; the arena leaves > 1 KB of readable slack behind every factor)
-  const float *__restrict__ Xa = gp->Xalt;
-  float *stage = (float *)(lds + 5 * NMFK_MAX_K) + wave * (16 * 17 + 4);
-  const int nload = 4 * kp;  // 16-byte pieces of a chunk (16 rows x kp floats), one per lane
-  const int nch = (d1 - d0 + 15) >> 4;
-  const float *xbase[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) xbase[t] = Xa + (int64_t)lt[t] * D + 4 * g;
-  const float *bbase = B + 4 * lane;
-  int wofs[4];  // LDS slots of this lane's four staged floats
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int f = 4 * lane + e;
-    wofs[e] = (f / kp) * 17 + (f % kp);
-  }
-  const int pofs = c16 * 17 + KQ * g;  // first product: row c16, signals KQ*g ..
-  const int nofs = 4 * g * 17 + c16;   // second product: rows 4g + r, signal c16
-
-  auto load = [&](int dch, f32x4_t (&xv)[4], f32x4_t &bv) __attribute__((always_inline)) {
-    if (dch + 16 <= D) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) xv[t] = *(const f32x4_u *)(xbase[t] + dch);
-    } else {  // rows past D are masked in the tail path; keep the address in range
-      const int dx = min(dch + 4 * g, D - 4) - 4 * g;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) xv[t] = *(const f32x4_u *)(xbase[t] + dx);
-    }
-    bv = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if (lane < nload) bv = *(const f32x4_u *)(bbase + (int64_t)dch * kp);
-  };
-
-  // one chunk of 16 loop steps.  FULL: all 16 rows are inside [d0, d1) and the 16-byte X loads were not clamped
-  // (every chunk but possibly the last): no row masks, no realignment of the X registers.
-  auto chunk = [&](int dch, const f32x4_t (&xcur)[4], auto full_tag) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(full_tag)::value;
-    float bP[KQ];
-    {
-      const float *pr = stage + (FULL ? pofs : min(c16, d1 - 1 - dch) * 17 + KQ * g);
-#pragma unroll
-#if NMFK_MFMA_EXP == 3
-      for (int sq = 0; sq < KQ; ++sq) bP[sq] = 0.25f + 0.01f * sq + 0.001f * (dch & 255);
-      (void)pr;
-#else
-      for (int sq = 0; sq < KQ; ++sq) bP[sq] = (FULLK || KQ * g + sq < k) ? pr[sq] : 0.0f;
-#endif
-    }
-    float bN[4];
-    bool rv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      rv[r] = FULL || (dch + 4 * g + r < d1);
-#if NMFK_MFMA_EXP == 3
-      bN[r] = 0.5f + 0.01f * r + 0.001f * (dch & 255);
-#else
-      bN[r] = (rv[r] && (FULLK || c16 < k)) ? stage[nofs + 17 * r] : 0.0f;
-#endif
-    }
-    f32x4_t p[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int sq = 0; sq < KQ; ++sq)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bP[sq], afrag[t][sq], p[t], 0, 0, 0);
-    f32x4_t q[4];
-    if (FULL) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) q[t][r] = div_t(xcur[t][r], p[t][r]);
-    } else {
-      // the 16-byte X load started at min(dch + 4g, D - 4): shift the registers when it was clamped
-      const int shift = (dch + 4 * g) - min(dch + 4 * g, D - 4);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rr = r + shift;
-          const float xx = rr <= 0 ? xcur[t][0] : rr == 1 ? xcur[t][1] : rr == 2 ? xcur[t][2] : xcur[t][3];
-          q[t][r] = rv[r] ? div_t(xx, p[t][r]) : 0.0f;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bN[r], q[t][r], acc[t], 0, 0, 0);
-  };
-  // stage the chunk held in (xc, bc), start the loads of the next one into (xn, bn), compute
-  auto step = [&](int ci, const f32x4_t (&xc)[4], const f32x4_t &bc, f32x4_t (&xn)[4], f32x4_t &bn)
-                  __attribute__((always_inline)) {
-    const int dch = d0 + 16 * ci;
-#if NMFK_MFMA_EXP != 3
-    if (lane < nload) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) stage[wofs[e]] = bc[e];
-    }
-#endif
-    if (ci + 1 < nch) load(dch + 16, xn, bn);
-    __builtin_amdgcn_wave_barrier();
-    if (dch + 16 <= d1 && dch + 16 <= D)
-      chunk(dch, xc, std::true_type());
-    else
-      chunk(dch, xc, std::false_type());
-    __builtin_amdgcn_wave_barrier();
-  };
-  {
-    f32x4_t x0[4], x1[4], b0, b1;
-    if (nch > 0) load(d0, x0, b0);
-    for (int ci = 0; ci < nch; ci += 2) {
-      step(ci, x0, b0, x1, b1);
-      if (ci + 1 < nch) step(ci + 1, x1, b1, x0, b0);
-    }
-  }
-  // acc[t][r] = numerator of signal c = 4g + r at lane element l0 + 16t + c16
-
-  float *ldsF = (float *)(lds + 5 * NMFK_MAX_K);
-  if (ws == 4) {  // add the four waves' numerators in wave order
-    __syncthreads();  // the scratch overlays the waves' staging buffers: everybody must have left the loop
-    if (wave > 0) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ldsF[(((wave - 1) * 4 + t) * 4 + r) * 64 + lane] = acc[t][r];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll 1
-      for (int w = 0; w < 3; ++w)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[t][r] += ldsF[((w * 4 + t) * 4 + r) * 64 + lane];
-    }
-    __syncthreads();
-  }
-  const bool owner = (ws == 1) || (wave == 0);
-
-  if (!gp->fused) {
-    if (owner) {
-      float *__restrict__ part = (float *)(arena + rdp->opart);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (lv[t]) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int c = 4 * g + r;
-            if (c < kp) part[((int64_t)s * L + lt[t]) * kp + c] = acc[t][r];
-          }
-        }
-    }
-    return;
-  }
-
-  const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
-  const int PB = which == 0 ? gp->PW : gp->PH;
-  double *den = lds;
-  if (tid < kp) {
-    double sd = 0;
-    for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * kp + tid];
-    den[tid] = sd;
-  }
-  __syncthreads();
-  float *__restrict__ Anew = which == 0 ? (float *)(arena + NMFK_HOFF(*rdp, it + 1)) : (float *)(arena + rdp->oWt);
-  float vs[4] = {0.f, 0.f, 0.f, 0.f};  // per signal c = 4g + r: sum over this lane's elements
-  if (owner) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = 4 * g + r;
-        float v = 0.f;
-        if (lv[t] && c < k) {
-          v = A[c + (int64_t)lt[t] * kp] * acc[t][r] / (float)den[c];  // Mult:67 / Mult:70 operation order
-          Anew[c + (int64_t)lt[t] * kp] = v;
-        } else if (lv[t] && c < kp) {
-          Anew[c + (int64_t)lt[t] * kp] = 0.f;
-        }
-        vs[r] += v;
-      }
-  }
-  // partial sums of A_new: over the 16 lanes of a group, then over waves -> slot `tile`
-  double *sumA = (double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)) + (int64_t)tile * kp;
-  double *red = den + NMFK_MAX_K;  // [4][16]
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    double v = (double)vs[r];
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (c16 == 0) red[wave * 16 + 4 * g + r] = v;
-  }
-  __syncthreads();
-  if (tid < kp) {
-    const double t = (ws == 4) ? red[tid] : ((red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]));
-    sumA[tid] = (tid < k) ? t : 0.0;
-  }
-}
-
 #endif
 
 #ifdef NMFK_IS_F32
@@ -1803,9 +1444,6 @@ static void launch_step_kp(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int
   const int uf = nmfk_unit_fast(ntile * a.S);
   const dim3 grid = NMFK_GRID(uf, ntile * a.S, cnt), blk(ws > 1 ? 64 * ws : NMFK_TILE);
   size_t scratch = ws > 1 ? (size_t)(ws - 1) * LB * KP * 64 * sizeof(T) : 0;
-#if NMFK_LDSB
-  scratch = std::max(scratch, (size_t)(ws > 1 ? ws : 4) * 2 * 16 * KP * sizeof(T));
-#endif
   const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + scratch;
   if (a.has_nan)
     hipLaunchKernelGGL((step_kernel<true, KP>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0, uf);
@@ -1827,34 +1465,12 @@ void NMFK_NAME(nmfk_launch_step_multi)(const NmfkStepArgs &a, const NmfkStepArgs
   const int uf = nmfk_unit_fast(ntile * a.S);
   const dim3 grid = NMFK_GRID(uf, ntile * a.S, cnt), blk(ws > 1 ? 64 * ws : NMFK_TILE);
   size_t scratch = ws > 1 ? (size_t)(ws - 1) * LB * 16 * 64 * sizeof(T) : 0;
-#if NMFK_LDSB
-  scratch = std::max(scratch, (size_t)(ws > 1 ? ws : 4) * 2 * 16 * 16 * sizeof(T));
-#endif
   const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + scratch;
   if (a.has_nan)
     hipLaunchKernelGGL((step_kernel_multi<true>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0, uf);
   else
     hipLaunchKernelGGL((step_kernel_multi<false>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0, uf);
 }
-
-#ifdef NMFK_IS_F32
-void nmfk_launch_step_mfma_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s) {
-  const int lpw = a.wsplit == 4 ? 64 : NMFK_TILE;
-  const int ntile = (a.L + lpw - 1) / lpw;
-  const dim3 grid(ntile * a.S, cnt), blk(NMFK_TILE);
-  // kp == k for k <= 16
-#define NMFK_MFMA_LAUNCH(KQ, FK) \
-  hipLaunchKernelGGL((mfma_step_kernel<KQ, FK>), grid, blk, 0, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0)
-  const bool fullk = (kp % 4) == 0;
-  switch ((kp + 3) / 4) {
-    case 1: if (fullk) NMFK_MFMA_LAUNCH(1, true); else NMFK_MFMA_LAUNCH(1, false); break;
-    case 2: if (fullk) NMFK_MFMA_LAUNCH(2, true); else NMFK_MFMA_LAUNCH(2, false); break;
-    case 3: if (fullk) NMFK_MFMA_LAUNCH(3, true); else NMFK_MFMA_LAUNCH(3, false); break;
-    case 4: if (fullk) NMFK_MFMA_LAUNCH(4, true); else NMFK_MFMA_LAUNCH(4, false); break;
-    default: break;
-  }
-}
-#endif
 
 #ifdef NMFK_IS_F32
 // all-MFMA half-step for 16 < kp <= 64 (fp32, no missing data, D >= 16)

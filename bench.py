@@ -110,13 +110,24 @@ def main():
 
     ks = list(range(args.kmin, args.kmax + 1))
     ctx = NMFk.Context(local)
-    # synthetic X: U(0,1), generated on rank 0's GPU with the library's portable generator, broadcast over RCCL
-    if rank == 0:
-        X = ctx.fill_uniform(1, 0, args.n * args.m).reshape(args.m, args.n).T
+    # synthetic X: U(0,1) from the library's portable generator (identical on every rank: the host copy only gives
+    # execute() its shape); the DEVICE copy every rank computes on comes from rank 0 over RCCL
+    X = np.asfortranarray(ctx.fill_uniform(1, 0, args.n * args.m).reshape(args.m, args.n).T)
+    comm = None
+    if world > 1 and backend == "nccl":
+        # the N > 1 data path is the C ABI's: nmfk_comm_create (unique id through torch.distributed), ncclBroadcast of X,
+        # restarts sharded inside libnmfk_hip, ONE ncclAllGather of the device result buffers per sweep
+        try:
+            comm = NMFk.parallel.attach(ctx)
+            comm.bcast_X(X if rank == 0 else None, root=0)
+        except Exception as e:  # fail loudly with the rank: a silent hang in the next collective helps nobody
+            print(f"[bench rank {rank}/{world}] joining the RCCL communicator failed: {e!r}", file=sys.stderr, flush=True)
+            raise
+    elif world > 1:  # CPU-side rehearsal of the sharding logic (gloo): torch.distributed carries the data
+        X = np.asfortranarray(NMFk.parallel.broadcast_X(X if rank == 0 else None))
+        ctx.set_X(X)
     else:
-        X = None
-    X = np.asfortranarray(NMFk.parallel.broadcast_X(X))
-    ctx.set_X(X)  # X resident in HBM (column-major + row-major copies) before the timed region
+        ctx.set_X(X)  # X resident in HBM (column-major + row-major copies) before the timed region
 
     def sync():
         if world > 1:
@@ -124,8 +135,12 @@ def main():
         torch.cuda.synchronize()
 
     def step(seed):
-        return NMFk.execute(X, ks, args.nruns, load=False, save=False, quiet=True, seed=seed, ctx=ctx,
-                            maxiter=args.maxiter, compute=args.compute, return_details=True)
+        try:
+            return NMFk.execute(X, ks, args.nruns, load=False, save=False, quiet=True, seed=seed, ctx=ctx,
+                                maxiter=args.maxiter, compute=args.compute, return_details=True)
+        except Exception as e:
+            print(f"[bench rank {rank}/{world}] sweep failed: {e!r}", file=sys.stderr, flush=True)
+            raise
 
     for w in range(args.warmup):
         step(1000 + w)
@@ -158,7 +173,8 @@ def main():
             "config": {"workload": f"dense U(0,1) fp32 X {args.n}x{args.m}, k={args.kmin}:{args.kmax}, nruns={args.nruns} "
                                    f"(BASELINE.json configs[2] / north-star 1-GPU target; {nfact} factorizations per step)",
                        "stop_rule": f"reference defaults: maxiter={args.maxiter}, tol=1e-19, tolOF=1e-3, maxbaditers=10, maxreattempts=2",
-                       "parallelism": f"restarts sharded over {world} rank(s)", "kopt": kopt,
+                       "parallelism": f"restarts sharded over {world} rank(s)" + (" (C ABI: nmfk_comm_* / RCCL)" if comm else ""),
+                       "kopt": kopt,
                        "mean_iterations_per_factorization": total_iters / nfact},
         }
         if prof and "mu_loop" in prof and prof["mu_loop"]["ms"] > 0:
@@ -218,6 +234,8 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
+        if comm is not None:
+            NMFk.parallel.detach(ctx)
         dist.destroy_process_group()
 
 

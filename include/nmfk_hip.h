@@ -13,8 +13,10 @@
  *    hipMemcpyDefault into/out of its own HBM workspace and never retains a caller pointer after return.
  *  - Every function returns an nmfk_status (0 = ok).  No C++ exception crosses the boundary;
  *    nmfk_last_error() gives the message of the last failure on the calling thread.
- *  - A context is bound to one GPU and is not re-entrant.  Multi-GPU = one process (and one context) per
- *    GPU; the (k, restart) work list is sharded by the host layer.
+ *    (Exception: nmfk_set_X_csc builds its CSR twin on the host and takes HOST pointers.)
+ *  - A context is bound to one GPU and is not re-entrant.  Multi-GPU = one context per GPU, as one process per GPU
+ *    (nmfk_comm_*: the host layer passes the RCCL unique id around) or as threads of one process (nmfk_multi_*, what a
+ *    Julia caller uses); the (k, restart) work list is sharded by restart inside the library ("multi-GPU" below).
  */
 #ifndef NMFK_HIP_H
 #define NMFK_HIP_H
@@ -35,7 +37,8 @@ typedef enum {
   NMFK_ERR_NO_X = 4,         /* nmfk_set_X has not been called                                                */
   NMFK_ERR_HIP = 5,          /* a HIP runtime call failed                                                      */
   NMFK_ERR_UNSUPPORTED = 6,  /* k > NMFK_MAX_K                                                                 */
-  NMFK_ERR_NO_DEVICE = 7     /* no usable gfx950 device: the library has NO CPU fallback                      */
+  NMFK_ERR_NO_DEVICE = 7,    /* no usable gfx950 device: the library has NO CPU fallback                      */
+  NMFK_ERR_RCCL = 8          /* librccl missing, or an RCCL call failed (the message names the call and the rank) */
 } nmfk_status;
 
 enum { NMFK_MAX_K = 64 };
@@ -173,6 +176,50 @@ int nmfk_robustkmeans(nmfk_ctx *ctx, int d, int64_t n, const float *X, int k, in
                       uint64_t seed, int32_t *assignments, float *centers, float *costs, int32_t *counts,
                       double *totalcost, int32_t *best_repeat, int32_t *iterations, int32_t *nclusters,
                       double *all_costs, float *silhouettes);
+
+/* multi-GPU -------------------------------------------------------------------------------------------------- */
+/* Replaces the reference's only parallelism on this path, Distributed.pmap over the restarts of one rank
+ * (src/NMFkExecute.jl:511-526, X shipped to a worker with every task): rank g of N owns the restarts {g, g+N, ...} of
+ * EVERY rank k of the sweep; X is broadcast once (ncclBroadcast, device to device over xGMI), nothing is exchanged
+ * inside the MU loop, and the results of all restarts are exchanged in ONE ncclAllGather of equally sized device
+ * buffers, so that every rank can run the robustness step.  librccl is loaded at run time (dlopen).            */
+typedef struct nmfk_comm nmfk_comm;
+enum { NMFK_UNIQUE_ID_BYTES = 128 };
+/* restarts of one rank k that shard `rank` of `nranks` runs: *count real ones, padded to *padded = ceil(nruns/nranks)
+ * (short lists repeat their last restart; the padding results are dropped).  Pure host arithmetic. */
+int nmfk_shard_plan(int nruns, int nranks, int rank, int32_t *count, int32_t *padded);
+/* ncclGetUniqueId: called by ONE rank, the host layer hands the 128 bytes to the others (Julia: Distributed / a file;
+ * bench.py: torch.distributed).  nmfk_comm_create is collective over the nranks contexts (ncclCommInitRank). */
+int nmfk_comm_unique_id(void *id128);
+int nmfk_comm_create(nmfk_ctx *ctx, int nranks, int rank, const void *id128, nmfk_comm **out);
+int nmfk_comm_destroy(nmfk_comm *comm);
+int nmfk_comm_info(nmfk_comm *comm, int *rank, int *nranks);
+/* Collective.  X (n x m, leading dimension ldx; host or device) is read on `root` only -- the other ranks pass NULL and
+ * learn n, m from the broadcast; every rank then runs NMFpreprocessing! (nmfk_set_X) on its device copy. */
+int nmfk_comm_bcast_X(nmfk_comm *comm, int root, const float *X, int64_t n, int64_t m, int64_t ldx, double lambda,
+                      int64_t *n_out, int64_t *m_out, int64_t *nan_count, int64_t *zero_count);
+/* Collective nmfk_mu_sweep: identical arguments on every rank, describing ALL nruns restarts (seeds, optional inits,
+ * outputs).  Each rank runs its shard and receives the results of every restart; pass H_out = NULL on a rank that
+ * does not need them.  need_W = 0: the W matrices are not exchanged (W_out then receives this rank's own restarts
+ * only; the best=true, clusterWmatrix=false path of execute_run needs the W of one restart per rank k). */
+int nmfk_mu_sweep_sharded(nmfk_ctx *ctx, nmfk_comm *comm, int nk, const int32_t *ks, int nruns,
+                          const float *const *Winit, const float *const *Hinit, const uint64_t *seeds,
+                          const nmfk_mu_params *params, int need_W, float *const *W_out, float *const *H_out,
+                          float *const *frob_out, double *const *sse_out, int32_t *const *iters_out,
+                          int32_t *const *reason_out);
+/* One process, several GPUs (what `NMFkHIP.execute(...; ngpus = 8)` calls): GPUs 0..ngpus-1, one context, communicator
+ * and host thread each; the results are delivered through GPU 0.  nmfk_multi_context gives GPU g's context (GPU 0:
+ * clustering, silhouettes and fit re-checks after the sweep). */
+typedef struct nmfk_multi nmfk_multi;
+int nmfk_multi_create(int ngpus, nmfk_multi **out);
+int nmfk_multi_destroy(nmfk_multi *mh);
+int nmfk_multi_context(nmfk_multi *mh, int gpu, nmfk_ctx **ctx);
+int nmfk_multi_set_X(nmfk_multi *mh, const float *X, int64_t n, int64_t m, int64_t ldx, double lambda, int64_t *nan_count,
+                     int64_t *zero_count);
+int nmfk_multi_sweep(nmfk_multi *mh, int nk, const int32_t *ks, int nruns, const float *const *Winit,
+                     const float *const *Hinit, const uint64_t *seeds, const nmfk_mu_params *params, float *const *W_out,
+                     float *const *H_out, float *const *frob_out, double *const *sse_out, int32_t *const *iters_out,
+                     int32_t *const *reason_out);
 
 /* measurement ----------------------------------------------------------------------------------------------- */
 /* HIP-event timing of the MU kernels on the streams they are launched on (bench.py's roofline leg).

@@ -7,9 +7,9 @@ The directory name contains a dot, so it is imported through the `nmfk_jl_amd` s
 """
 from ._lib import (COMPUTE_F32, COMPUTE_F64, STOP_CONSISTENCY, STOP_MAXITER, STOP_STAGNATION, STOP_TOL, Context,
                    NMFkError, build, default_params, device_count, lib)
-from .execute import execute, execute_run, getk, input_checks, run_seed, signalorder
+from .execute import ExecuteOptions, execute, execute_run, getk, input_checks, run_seed, signalorder
 from . import parallel
 from .cluster import robustkmeans, sortclustering
 
-__all__ = ["robustkmeans", "sortclustering", "execute", "execute_run", "getk", "signalorder", "input_checks", "run_seed", "Context", "NMFkError",
+__all__ = ["ExecuteOptions", "robustkmeans", "sortclustering", "execute", "execute_run", "getk", "signalorder", "input_checks", "run_seed", "Context", "NMFkError",
            "build", "lib", "device_count", "default_params", "parallel"]

@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("NMFK_HIP_LIB", os.path.join(_HERE, "libnmfk_hip.so"))
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nmfk_hip.h")
 
 NMFK_OK = 0
-ERR_BAD_ARG, ERR_NEGATIVE, ERR_NAN_INIT, ERR_NO_X, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = 1, 2, 3, 4, 5, 6, 7
+ERR_BAD_ARG, ERR_NEGATIVE, ERR_NAN_INIT, ERR_NO_X, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_RCCL = 1, 2, 3, 4, 5, 6, 7, 8
+UNIQUE_ID_BYTES = 128
 STOP_MAXITER, STOP_STAGNATION, STOP_TOL, STOP_CONSISTENCY = 1, 2, 3, 4
 COMPUTE_F32, COMPUTE_F64 = 0, 1
 MAX_K = 64
@@ -85,6 +86,21 @@ def lib():
     L.nmfk_frobenius.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_double)]
     L.nmfk_set_profiling.argtypes = [vp, C.c_int]
     L.nmfk_last_sweep_info.argtypes = [vp, C.POINTER(C.c_int32)]
+    i32p = C.POINTER(C.c_int32)
+    L.nmfk_shard_plan.argtypes = [C.c_int, C.c_int, C.c_int, i32p, i32p]
+    L.nmfk_comm_unique_id.argtypes = [C.c_void_p]
+    L.nmfk_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_void_p, C.POINTER(vp)]
+    L.nmfk_comm_destroy.argtypes = [vp]
+    L.nmfk_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.nmfk_comm_bcast_X.argtypes = [vp, C.c_int, fp, C.c_int64, C.c_int64, C.c_int64, C.c_double, i64p, i64p, i64p, i64p]
+    L.nmfk_mu_sweep_sharded.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int32), C.c_int, pp, pp, C.POINTER(C.c_uint64),
+                                        C.POINTER(MuParams), C.c_int, pp, pp, pp, pp, pp, pp]
+    L.nmfk_multi_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.nmfk_multi_destroy.argtypes = [vp]
+    L.nmfk_multi_context.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.nmfk_multi_set_X.argtypes = [vp, fp, C.c_int64, C.c_int64, C.c_int64, C.c_double, i64p, i64p]
+    L.nmfk_multi_sweep.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.c_int, pp, pp, C.POINTER(C.c_uint64),
+                                   C.POINTER(MuParams), pp, pp, pp, pp, pp, pp]
     L.nmfk_get_profile.argtypes = [vp, C.c_int, C.c_void_p, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double),
                                    C.POINTER(C.c_int)]
     _lib = L
@@ -118,6 +134,162 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def _sweep_call(call, n, m, ks, nruns, seeds, Winit, Hinit, params, kw, need_W=None):
+    """Marshals the arguments of nmfk_mu_sweep / nmfk_mu_sweep_sharded / nmfk_multi_sweep and unpacks the results."""
+    P = params if params is not None else default_params(**kw)
+    ks = [int(k) for k in ks]
+    nk = len(ks)
+    arr_k = (C.c_int32 * nk)(*ks)
+    PP = C.c_void_p * nk
+    keep = []
+
+    def table(d, shape_of):
+        t = PP()
+        any_ = False
+        for q, k in enumerate(ks):
+            a = None if d is None else d.get(k)
+            if a is None:
+                t[q] = None
+                continue
+            a = np.asarray(a, dtype=np.float32)
+            if a.shape != shape_of(k):
+                raise NMFkError(ERR_BAD_ARG, f"initial factor for k={k} has shape {a.shape}, expected {shape_of(k)}")
+            # natural (r, row, col) -> stacked column-major: (r, col, row) C-contiguous
+            a = np.ascontiguousarray(np.transpose(a, (0, 2, 1)))
+            keep.append(a)
+            t[q] = a.ctypes.data
+            any_ = True
+        return t if any_ else None
+
+    wi = table(Winit, lambda k: (nruns, n, k))
+    hi = table(Hinit, lambda k: (nruns, k, m))
+    sd = None
+    if seeds is not None:
+        sd_np = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64).reshape(nk, nruns))
+        keep.append(sd_np)
+        sd = sd_np.ctypes.data_as(C.POINTER(C.c_uint64))
+    out = {}
+    tw, th, tf, ts, ti, tr = PP(), PP(), PP(), PP(), PP(), PP()
+    for q, k in enumerate(ks):
+        o = dict(Wt=np.full((nruns, k, n), np.nan, dtype=np.float32), Ht=np.empty((nruns, m, k), dtype=np.float32),
+                 objvalue=np.empty(nruns, dtype=np.float32), sse=np.empty(nruns, dtype=np.float64),
+                 iters=np.empty(nruns, dtype=np.int32), reason=np.empty(nruns, dtype=np.int32))
+        out[k] = o
+        tw[q], th[q], tf[q] = o["Wt"].ctypes.data, o["Ht"].ctypes.data, o["objvalue"].ctypes.data
+        ts[q], ti[q], tr[q] = o["sse"].ctypes.data, o["iters"].ctypes.data, o["reason"].ctypes.data
+    args = [nk, arr_k, int(nruns), wi, hi, sd, C.byref(P)]
+    if need_W is not None:
+        args.append(int(need_W))
+    _check(call(*args, tw, th, tf, ts, ti, tr))
+    for k, o in out.items():
+        o["W"] = np.transpose(o.pop("Wt"), (0, 2, 1))  # views: (nruns, n, k), Fortran-ordered per restart
+        o["H"] = np.transpose(o.pop("Ht"), (0, 2, 1))  # (nruns, k, m)
+    return out
+
+
+def shard_plan(nruns, nranks, rank):
+    """nmfk_shard_plan -> (real restarts of the shard, padded count every shard runs)."""
+    cnt, pad = C.c_int32(), C.c_int32()
+    _check(lib().nmfk_shard_plan(int(nruns), int(nranks), int(rank), C.byref(cnt), C.byref(pad)))
+    return cnt.value, pad.value
+
+
+def _pin_rccl():
+    """One copy of RCCL per process: inside a PyTorch process libnmfk_hip must use the librccl PyTorch ships and has
+    loaded (two copies double-free at exit), so point the library's dlopen at it before its first RCCL call."""
+    import sys
+
+    if "NMFK_RCCL_LIB" in os.environ or "torch" not in sys.modules:
+        return
+    cand = os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib", "librccl.so")
+    if os.path.exists(cand):
+        os.environ["NMFK_RCCL_LIB"] = cand
+
+
+def comm_unique_id():
+    """nmfk_comm_unique_id: 128 opaque bytes, generated on ONE rank and handed to the others by the host layer."""
+    _pin_rccl()
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    _check(lib().nmfk_comm_unique_id(buf))
+    return bytes(buf.raw)
+
+
+class Comm:
+    """nmfk_comm: RCCL communicator of one rank (one Context = one GPU); collective calls, one process per GPU."""
+
+    def __init__(self, ctx, nranks, rank, unique_id):
+        self.ctx, self.nranks, self.rank = ctx, int(nranks), int(rank)
+        self._h = C.c_void_p()
+        _pin_rccl()
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise NMFkError(ERR_BAD_ARG, f"the RCCL unique id has {UNIQUE_ID_BYTES} bytes")
+        idbuf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        _check(lib().nmfk_comm_create(ctx._h, self.nranks, self.rank, idbuf, C.byref(self._h)))
+        ctx._comms = getattr(ctx, "_comms", []) + [self]  # the context closes its communicators before itself
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().nmfk_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def bcast_X(self, X=None, root=0, lambda_=1e-32):
+        """nmfk_comm_bcast_X: X is read on `root` only; every rank ends with X resident (NMFpreprocessing! done)."""
+        n = m = 0
+        ptr = None
+        if self.rank == root:
+            Xf = np.asfortranarray(X, dtype=np.float32)
+            n, m = Xf.shape
+            ptr = Xf.ctypes.data
+        no, mo, nan, zero = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        _check(lib().nmfk_comm_bcast_X(self._h, int(root), ptr, n, m, max(n, 1), float(lambda_), C.byref(no), C.byref(mo),
+                                       C.byref(nan), C.byref(zero)))
+        self.ctx.n, self.ctx.m = no.value, mo.value
+        self.ctx.nan_count, self.ctx.zero_count = nan.value, zero.value
+        return self.ctx
+
+    def mu_sweep(self, ks, nruns, seeds=None, Winit=None, Hinit=None, params=None, need_W=True, **kw):
+        """nmfk_mu_sweep_sharded: same arguments on every rank (ALL restarts); every rank gets all results.  need_W=False:
+        W comes back for this rank's own restarts only (NaN elsewhere)."""
+        return _sweep_call(lambda *a: lib().nmfk_mu_sweep_sharded(self.ctx._h, self._h, *a), self.ctx.n, self.ctx.m, ks, nruns,
+                           seeds, Winit, Hinit, params, kw, need_W=bool(need_W))
+
+
+class Multi:
+    """nmfk_multi: one process, GPUs 0..ngpus-1 (a context, a communicator and a host thread per GPU)."""
+
+    def __init__(self, ngpus):
+        _pin_rccl()
+        self._h = C.c_void_p()
+        _check(lib().nmfk_multi_create(int(ngpus), C.byref(self._h)))
+        self.ngpus = int(ngpus)
+        h0 = C.c_void_p()
+        _check(lib().nmfk_multi_context(self._h, 0, C.byref(h0)))
+        self.ctx0 = Context.__new__(Context)  # GPU 0's context (not owned): clustering, silhouettes, fit re-checks
+        self.ctx0._h, self.ctx0._owned = h0, False
+        self.ctx0.n = self.ctx0.m = self.ctx0.nan_count = self.ctx0.zero_count = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().nmfk_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_X(self, X, lambda_=1e-32):
+        Xf = np.asfortranarray(X, dtype=np.float32)
+        n, m = Xf.shape
+        nan, zero = C.c_int64(), C.c_int64()
+        _check(lib().nmfk_multi_set_X(self._h, Xf.ctypes.data, n, m, max(n, 1), float(lambda_), C.byref(nan), C.byref(zero)))
+        self.ctx0.n, self.ctx0.m, self.ctx0.nan_count, self.ctx0.zero_count = n, m, nan.value, zero.value
+        return self
+
+    def mu_sweep(self, ks, nruns, seeds=None, Winit=None, Hinit=None, params=None, **kw):
+        return _sweep_call(lambda *a: lib().nmfk_multi_sweep(self._h, *a), self.ctx0.n, self.ctx0.m, ks, nruns, seeds, Winit,
+                           Hinit, params, kw)
+
+
 class Context:
     """One GPU (nmfk_ctx).  Arrays cross the boundary as float32 numpy arrays in Julia (column-major) layout:
     a stack of R matrices n x k is passed as a C-contiguous array of shape (R, k, n)."""
@@ -129,9 +301,12 @@ class Context:
         self.nan_count = self.zero_count = 0
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
+        for c in getattr(self, "_comms", []):
+            c.close()
+        self._comms = []
+        if getattr(self, "_h", None) is not None and self._h.value and getattr(self, "_owned", True):
             lib().nmfk_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     __del__ = close
 
@@ -186,52 +361,8 @@ class Context:
         """nmfk_mu_sweep.  ks: list of ranks; seeds: (len(ks), nruns) uint64; Winit/Hinit: optional dicts
         k -> array (nruns, n, k) / (nruns, k, m) in natural (row, col) indexing.
         Returns dict k -> dict(W (nruns, n, k), H (nruns, k, m), objvalue (nruns,) float32, sse, iters, reason)."""
-        P = params if params is not None else default_params(**kw)
-        ks = [int(k) for k in ks]
-        nk, n, m = len(ks), self.n, self.m
-        arr_k = (C.c_int32 * nk)(*ks)
-        PP = C.c_void_p * nk
-        keep = []
-
-        def table(d, shape_of):
-            t = PP()
-            any_ = False
-            for q, k in enumerate(ks):
-                a = None if d is None else d.get(k)
-                if a is None:
-                    t[q] = None
-                    continue
-                a = np.asarray(a, dtype=np.float32)
-                if a.shape != shape_of(k):
-                    raise NMFkError(ERR_BAD_ARG, f"initial factor for k={k} has shape {a.shape}, expected {shape_of(k)}")
-                # natural (r, row, col) -> stacked column-major: (r, col, row) C-contiguous
-                a = np.ascontiguousarray(np.transpose(a, (0, 2, 1)))
-                keep.append(a)
-                t[q] = a.ctypes.data
-                any_ = True
-            return t if any_ else None
-
-        wi = table(Winit, lambda k: (nruns, n, k))
-        hi = table(Hinit, lambda k: (nruns, k, m))
-        sd = None
-        if seeds is not None:
-            sd_np = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64).reshape(nk, nruns))
-            keep.append(sd_np)
-            sd = sd_np.ctypes.data_as(C.POINTER(C.c_uint64))
-        out = {}
-        tw, th, tf, ts, ti, tr = PP(), PP(), PP(), PP(), PP(), PP()
-        for q, k in enumerate(ks):
-            o = dict(Wt=np.empty((nruns, k, n), dtype=np.float32), Ht=np.empty((nruns, m, k), dtype=np.float32),
-                     objvalue=np.empty(nruns, dtype=np.float32), sse=np.empty(nruns, dtype=np.float64),
-                     iters=np.empty(nruns, dtype=np.int32), reason=np.empty(nruns, dtype=np.int32))
-            out[k] = o
-            tw[q], th[q], tf[q] = o["Wt"].ctypes.data, o["Ht"].ctypes.data, o["objvalue"].ctypes.data
-            ts[q], ti[q], tr[q] = o["sse"].ctypes.data, o["iters"].ctypes.data, o["reason"].ctypes.data
-        _check(lib().nmfk_mu_sweep(self._h, nk, arr_k, int(nruns), wi, hi, sd, C.byref(P), tw, th, tf, ts, ti, tr))
-        for k, o in out.items():
-            o["W"] = np.transpose(o.pop("Wt"), (0, 2, 1))  # views: (nruns, n, k), Fortran-ordered per restart
-            o["H"] = np.transpose(o.pop("Ht"), (0, 2, 1))  # (nruns, k, m)
-        return out
+        return _sweep_call(lambda *a: lib().nmfk_mu_sweep(self._h, *a), self.n, self.m, ks, nruns, seeds, Winit, Hinit,
+                           params, kw)
 
     def cluster_silhouette(self, Hs):
         """nmfk_cluster_silhouette.  Hs: (nsol, k, m) sorted by objective.  Returns labels (k, nsol) int32 1-based,

@@ -1,0 +1,401 @@
+// libnmfk_hip: multi-GPU layer of the C ABI (include/nmfk_hip.h, "multi-GPU").
+//
+// The reference's only parallelism on this path is `Distributed.pmap` over the restarts of ONE rank
+// (src/NMFkExecute.jl:511-526), shipping X to a worker with every task.  Here the (k, restart) units of the WHOLE sweep
+// are sharded: rank g owns the restarts {g, g + N, ...} of every k (the cost of a unit grows with k, so every rank
+// gets the same mix of ranks), X is broadcast ONCE, nothing is exchanged inside the MU loop, and the results of all
+// restarts are exchanged in ONE all-gather of equally sized device buffers, so that every rank can run the (tiny)
+// robustness step.  RCCL (ncclBroadcast / ncclAllGather over xGMI) moves device buffers; no host staging.
+//
+// librccl is loaded at run time (dlopen): a single-GPU user needs no RCCL, and inside a PyTorch process the copy that
+// is already loaded is the one used.  One rank = one nmfk_ctx = one GPU; ranks may be processes (unique id passed by
+// the host layer) or threads of one process (nmfk_multi_*).
+#include <dlfcn.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "nmfk_ctx.h"
+
+namespace {
+
+// the few RCCL entry points used (signatures of rccl.h; the types are opaque here)
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+  char internal[NMFK_UNIQUE_ID_BYTES];
+} ncclUniqueId;
+enum { ncclSuccess = 0, ncclInt8 = 0, ncclChar = 0, ncclFloat32 = 7 };
+struct Rccl {
+  void *h = nullptr;
+  int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  std::string err;
+};
+Rccl &rccl() {
+  static Rccl R;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    // NMFK_RCCL_LIB names the copy to use (a process must hold ONE librccl: inside PyTorch, the one it ships)
+    const char *names[] = {getenv("NMFK_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names)
+      if (nm && *nm && (R.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!R.h) {
+      R.err = std::string("librccl could not be loaded (") + (dlerror() ? dlerror() : "?") + ")";
+      return;
+    }
+    auto sym = [&](const char *s) {
+      void *p = dlsym(R.h, s);
+      if (!p && R.err.empty()) R.err = std::string("librccl lacks ") + s;
+      return p;
+    };
+    R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
+    R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
+    R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+    R.Broadcast = (decltype(R.Broadcast))sym("ncclBroadcast");
+    R.AllGather = (decltype(R.AllGather))sym("ncclAllGather");
+    R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+  });
+  return R;
+}
+
+}  // namespace
+
+struct nmfk_comm {
+  nmfk_ctx *ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  DevBuf send, recv, xbuf;
+};
+
+namespace {
+
+int rccl_fail(const nmfk_comm *c, const char *what, int rc) {
+  char b[512];
+  snprintf(b, sizeof(b), "RCCL error %d (%s) in %s on rank %d of %d", rc,
+           rccl().GetErrorString ? rccl().GetErrorString(rc) : "?", what, c ? c->rank : -1, c ? c->nranks : -1);
+  return fail(NMFK_ERR_RCCL, b);
+}
+#define RCCLCHECK(c, what, expr)                   \
+  do {                                             \
+    const int _r = (expr);                         \
+    if (_r != ncclSuccess) return rccl_fail(c, what, _r); \
+  } while (0)
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+#define NMFK_EXPORT extern "C" __attribute__((visibility("default")))
+
+NMFK_EXPORT int nmfk_shard_plan(int nruns, int nranks, int rank, int32_t *count, int32_t *padded) {
+  if (nruns <= 0 || nranks <= 0 || rank < 0 || rank >= nranks) return fail(NMFK_ERR_BAD_ARG, "bad shard arguments");
+  if (count) *count = rank < nruns ? (nruns - rank + nranks - 1) / nranks : 0;  // restarts {rank, rank + N, ...}
+  if (padded) *padded = (nruns + nranks - 1) / nranks;                          // every rank runs this many (short lists repeat their last restart)
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_comm_unique_id(void *id128) {
+  if (!id128) return fail(NMFK_ERR_BAD_ARG, "id is null");
+  Rccl &R = rccl();
+  if (!R.err.empty()) return fail(NMFK_ERR_RCCL, R.err);
+  ncclUniqueId id;
+  const int rc = R.GetUniqueId(&id);
+  if (rc != ncclSuccess) return rccl_fail(nullptr, "ncclGetUniqueId", rc);
+  memcpy(id128, &id, NMFK_UNIQUE_ID_BYTES);
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_comm_create(nmfk_ctx *ctx, int nranks, int rank, const void *id128, nmfk_comm **out) {
+  if (!ctx || !id128 || !out) return fail(NMFK_ERR_BAD_ARG, "null argument");
+  *out = nullptr;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(NMFK_ERR_BAD_ARG, "bad rank / nranks");
+  Rccl &R = rccl();
+  if (!R.err.empty()) return fail(NMFK_ERR_RCCL, R.err);
+  HIPCHECK(hipSetDevice(ctx->device));
+  nmfk_comm *c = new nmfk_comm();
+  c->ctx = ctx;
+  c->nranks = nranks;
+  c->rank = rank;
+  ncclUniqueId id;
+  memcpy(&id, id128, NMFK_UNIQUE_ID_BYTES);
+  const int rc = R.CommInitRank(&c->comm, nranks, id, rank);
+  if (rc != ncclSuccess) {
+    const int e = rccl_fail(c, "ncclCommInitRank", rc);
+    delete c;
+    return e;
+  }
+  *out = c;
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_comm_destroy(nmfk_comm *c) {
+  if (!c) return NMFK_OK;
+  (void)hipSetDevice(c->ctx->device);
+  (void)hipStreamSynchronize(c->ctx->stream);
+  if (c->comm) (void)rccl().CommDestroy(c->comm);
+  c->send.release();
+  c->recv.release();
+  c->xbuf.release();
+  delete c;
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_comm_info(nmfk_comm *c, int *rank, int *nranks) {
+  if (!c) return fail(NMFK_ERR_BAD_ARG, "comm is null");
+  if (rank) *rank = c->rank;
+  if (nranks) *nranks = c->nranks;
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_comm_bcast_X(nmfk_comm *c, int root, const float *X, int64_t n, int64_t m, int64_t ldx, double lambda,
+                                  int64_t *n_out, int64_t *m_out, int64_t *nan_count, int64_t *zero_count) {
+  if (!c) return fail(NMFK_ERR_BAD_ARG, "comm is null");
+  if (root < 0 || root >= c->nranks) return fail(NMFK_ERR_BAD_ARG, "bad root");
+  nmfk_ctx *ctx = c->ctx;
+  HIPCHECK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  // header: the size of X, known on the root only
+  if (c->xbuf.ensure(256)) return fail(NMFK_ERR_HIP, "out of device memory");
+  int64_t hdr[2] = {0, 0};
+  if (c->rank == root) {
+    if (!X || n <= 0 || m <= 0 || ldx < n) return fail(NMFK_ERR_BAD_ARG, "root: bad X");
+    hdr[0] = n;
+    hdr[1] = m;
+  }
+  HIPCHECK(hipMemcpyAsync(c->xbuf.p, hdr, sizeof(hdr), hipMemcpyHostToDevice, st));
+  RCCLCHECK(c, "ncclBroadcast(size of X)", rccl().Broadcast(c->xbuf.p, c->xbuf.p, sizeof(hdr), ncclChar, root, c->comm, st));
+  HIPCHECK(hipMemcpyAsync(hdr, c->xbuf.p, sizeof(hdr), hipMemcpyDeviceToHost, st));
+  HIPCHECK(hipStreamSynchronize(st));
+  n = hdr[0];
+  m = hdr[1];
+  if (n <= 0 || m <= 0) return fail(NMFK_ERR_BAD_ARG, "Input array has a zero dimension!");
+  const size_t bytes = (size_t)n * (size_t)m * sizeof(float);
+  if (c->xbuf.ensure(bytes)) return fail(NMFK_ERR_HIP, "out of device memory (X broadcast buffer)");
+  if (c->rank == root)  // dense n x m image of the caller's (host or device) array
+    HIPCHECK(hipMemcpy2DAsync(c->xbuf.p, (size_t)n * 4, X, (size_t)ldx * 4, (size_t)n * 4, (size_t)m, hipMemcpyDefault, st));
+  RCCLCHECK(c, "ncclBroadcast(X)", rccl().Broadcast(c->xbuf.p, c->xbuf.p, (size_t)n * m, ncclFloat32, root, c->comm, st));
+  HIPCHECK(hipStreamSynchronize(st));
+  const int rc = nmfk_set_X(ctx, (const float *)c->xbuf.p, n, m, n, lambda, nan_count, zero_count);  // NMFpreprocessing! on every rank
+  if (n_out) *n_out = n;
+  if (m_out) *m_out = m;
+  return rc;
+}
+
+NMFK_EXPORT int nmfk_mu_sweep_sharded(nmfk_ctx *ctx, nmfk_comm *c, int nk, const int32_t *ks, int nruns,
+                                      const float *const *Winit, const float *const *Hinit, const uint64_t *seeds,
+                                      const nmfk_mu_params *params, int need_W, float *const *W_out, float *const *H_out,
+                                      float *const *frob_out, double *const *sse_out, int32_t *const *iters_out,
+                                      int32_t *const *reason_out) {
+  if (!ctx || !c || c->ctx != ctx || !ks || !params) return fail(NMFK_ERR_BAD_ARG, "null argument");
+  if (nk <= 0 || nruns <= 0) return fail(NMFK_ERR_BAD_ARG, "nk and nruns must be positive");
+  if (!ctx->Xc && !ctx->sparse) return fail(NMFK_ERR_NO_X, "nmfk_set_X / nmfk_comm_bcast_X has not been called");
+  HIPCHECK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int N = c->nranks, g = c->rank;
+  const int64_t n = ctx->n, m = ctx->m;
+  int32_t mine = 0, cpad = 0;
+  (void)nmfk_shard_plan(nruns, N, g, &mine, &cpad);
+  const bool withW = need_W != 0;
+  // layout of a rank's contribution: per rank k (in the caller's order) cpad restarts of W, H, frob, iters, reason, sse
+  std::vector<size_t> oW(nk), oH(nk), oF(nk), oI(nk), oR(nk), oS(nk);
+  size_t tot = 0;
+  for (int q = 0; q < nk; ++q) {
+    if (ks[q] < 1 || ks[q] > NMFK_MAX_K) return fail(NMFK_ERR_UNSUPPORTED, "k out of range");
+    const size_t k = (size_t)ks[q];
+    oW[q] = tot;
+    tot += align256(withW ? sizeof(float) * cpad * k * n : 0);
+    oH[q] = tot;
+    tot += align256(sizeof(float) * cpad * k * m);
+    oF[q] = tot;
+    tot += align256(sizeof(float) * cpad);
+    oI[q] = tot;
+    tot += align256(sizeof(int32_t) * cpad);
+    oR[q] = tot;
+    tot += align256(sizeof(int32_t) * cpad);
+    oS[q] = tot;
+    tot += align256(sizeof(double) * cpad);
+  }
+  // local scratch behind the contribution: W of the local restarts when it is not exchanged, local inits
+  std::vector<size_t> oWl(nk, 0), oWi(nk, 0), oHi(nk, 0);
+  size_t loc = tot;
+  for (int q = 0; q < nk; ++q) {
+    const size_t k = (size_t)ks[q];
+    if (!withW) {
+      oWl[q] = loc;
+      loc += align256(sizeof(float) * cpad * k * n);
+    }
+    if (Winit && Winit[q]) {
+      oWi[q] = loc;
+      loc += align256(sizeof(float) * cpad * k * n);
+    }
+    if (Hinit && Hinit[q]) {
+      oHi[q] = loc;
+      loc += align256(sizeof(float) * cpad * k * m);
+    }
+  }
+  if (c->send.ensure(loc)) return fail(NMFK_ERR_HIP, "out of device memory (shard buffers)");
+  if (c->recv.ensure(tot * (size_t)N)) return fail(NMFK_ERR_HIP, "out of device memory (gather buffer)");
+  char *S = c->send.p;
+
+  if (mine > 0) {
+    // this rank's restarts r = g + j*N (j < mine), padded to cpad by repeating the last one
+    std::vector<uint64_t> lseeds((size_t)nk * cpad, 0);
+    std::vector<const float *> wi(nk, nullptr), hi(nk, nullptr);
+    std::vector<float *> wo(nk), ho(nk), fo(nk);
+    std::vector<double *> so(nk);
+    std::vector<int32_t *> io(nk), ro(nk);
+    for (int q = 0; q < nk; ++q) {
+      const size_t k = (size_t)ks[q];
+      for (int j = 0; j < cpad; ++j) {
+        const int r = g + std::min(j, mine - 1) * N;
+        if (seeds) lseeds[(size_t)q * cpad + j] = seeds[(size_t)q * nruns + r];
+        if (Winit && Winit[q])
+          HIPCHECK(hipMemcpyAsync(S + oWi[q] + sizeof(float) * j * k * n, Winit[q] + (size_t)r * k * n, sizeof(float) * k * n,
+                                  hipMemcpyDefault, st));
+        if (Hinit && Hinit[q])
+          HIPCHECK(hipMemcpyAsync(S + oHi[q] + sizeof(float) * j * k * m, Hinit[q] + (size_t)r * k * m, sizeof(float) * k * m,
+                                  hipMemcpyDefault, st));
+      }
+      wi[q] = (Winit && Winit[q]) ? (const float *)(S + oWi[q]) : nullptr;
+      hi[q] = (Hinit && Hinit[q]) ? (const float *)(S + oHi[q]) : nullptr;
+      wo[q] = (float *)(S + (withW ? oW[q] : oWl[q]));
+      ho[q] = (float *)(S + oH[q]);
+      fo[q] = (float *)(S + oF[q]);
+      so[q] = (double *)(S + oS[q]);
+      io[q] = (int32_t *)(S + oI[q]);
+      ro[q] = (int32_t *)(S + oR[q]);
+    }
+    HIPCHECK(hipStreamSynchronize(st));
+    // the local sweep writes straight into the contribution (device pointers on the boundary)
+    const int rc = nmfk_mu_sweep(ctx, nk, ks, cpad, wi.data(), hi.data(), seeds ? lseeds.data() : nullptr, params, wo.data(),
+                                 ho.data(), fo.data(), so.data(), io.data(), ro.data());
+    if (rc != NMFK_OK) return rc;  // (the other ranks then fail in the collective: the host layer tears the job down)
+  }
+  RCCLCHECK(c, "ncclAllGather(results)", rccl().AllGather(S, c->recv.p, tot, ncclChar, c->comm, st));
+
+  // deliver: restart r = h + j*N of rank k comes from rank h, slot j
+  if (H_out) {
+    for (int h = 0; h < N; ++h) {
+      int32_t cnt = 0;
+      (void)nmfk_shard_plan(nruns, N, h, &cnt, nullptr);
+      if (cnt == 0) continue;
+      const char *Rb = c->recv.p + (size_t)h * tot;
+      for (int q = 0; q < nk; ++q) {
+        const size_t k = (size_t)ks[q];
+        auto scatter = [&](void *dst0, const char *src, size_t elem) -> hipError_t {  // cnt pieces, destination stride N pieces
+          if (!dst0) return hipSuccess;
+          return hipMemcpy2DAsync((char *)dst0 + elem * h, elem * N, src, elem, elem, (size_t)cnt, hipMemcpyDefault, st);
+        };
+        if (withW && W_out && W_out[q]) HIPCHECK(scatter(W_out[q], Rb + oW[q], sizeof(float) * k * n));
+        if (H_out[q]) HIPCHECK(scatter(H_out[q], Rb + oH[q], sizeof(float) * k * m));
+        if (frob_out && frob_out[q]) HIPCHECK(scatter(frob_out[q], Rb + oF[q], sizeof(float)));
+        if (iters_out && iters_out[q]) HIPCHECK(scatter(iters_out[q], Rb + oI[q], sizeof(int32_t)));
+        if (reason_out && reason_out[q]) HIPCHECK(scatter(reason_out[q], Rb + oR[q], sizeof(int32_t)));
+        if (sse_out && sse_out[q]) HIPCHECK(scatter(sse_out[q], Rb + oS[q], sizeof(double)));
+      }
+    }
+    // W of this rank's own restarts when W is not exchanged (the caller's stack then holds W for these restarts only)
+    if (!withW && W_out && mine > 0)
+      for (int q = 0; q < nk; ++q)
+        if (W_out[q]) {
+          const size_t e = sizeof(float) * (size_t)ks[q] * n;
+          HIPCHECK(hipMemcpy2DAsync((char *)W_out[q] + e * g, e * N, S + oWl[q], e, e, (size_t)mine, hipMemcpyDefault, st));
+        }
+  }
+  HIPCHECK(hipStreamSynchronize(st));
+  return NMFK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// one process, several GPUs: a context, a communicator and a host thread per GPU
+// ------------------------------------------------------------------------------------------------------
+struct nmfk_multi {
+  std::vector<nmfk_ctx *> ctx;
+  std::vector<nmfk_comm *> comm;
+};
+
+namespace {
+template <class F>
+int on_all(nmfk_multi *mh, F f) {
+  const int N = (int)mh->ctx.size();
+  std::vector<int> rc(N, NMFK_OK);
+  std::vector<std::string> msg(N);
+  std::vector<std::thread> th;
+  for (int g = 0; g < N; ++g)
+    th.emplace_back([&, g] {
+      rc[g] = f(g);
+      if (rc[g] != NMFK_OK) msg[g] = nmfk_last_error();
+    });
+  for (auto &t : th) t.join();
+  for (int g = 0; g < N; ++g)
+    if (rc[g] != NMFK_OK) return fail(rc[g], "GPU " + std::to_string(g) + ": " + msg[g]);
+  return NMFK_OK;
+}
+}  // namespace
+
+NMFK_EXPORT int nmfk_multi_destroy(nmfk_multi *mh) {
+  if (!mh) return NMFK_OK;
+  for (auto *c : mh->comm) (void)nmfk_comm_destroy(c);
+  for (auto *x : mh->ctx) (void)nmfk_destroy(x);
+  delete mh;
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_multi_create(int ngpus, nmfk_multi **out) {
+  if (!out || ngpus < 1) return fail(NMFK_ERR_BAD_ARG, "bad argument");
+  *out = nullptr;
+  int have = 0;
+  (void)nmfk_device_count(&have);
+  if (have < ngpus) return fail(NMFK_ERR_NO_DEVICE, "fewer GPUs visible than requested");
+  nmfk_multi *mh = new nmfk_multi();
+  mh->ctx.assign(ngpus, nullptr);
+  mh->comm.assign(ngpus, nullptr);
+  char id[NMFK_UNIQUE_ID_BYTES];
+  int rc = nmfk_comm_unique_id(id);
+  for (int g = 0; g < ngpus && rc == NMFK_OK; ++g) rc = nmfk_create(g, &mh->ctx[g]);
+  if (rc == NMFK_OK) rc = on_all(mh, [&](int g) { return nmfk_comm_create(mh->ctx[g], ngpus, g, id, &mh->comm[g]); });
+  if (rc != NMFK_OK) {
+    const std::string keep = nmfk_last_error();
+    (void)nmfk_multi_destroy(mh);
+    return fail(rc, keep);
+  }
+  *out = mh;
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_multi_set_X(nmfk_multi *mh, const float *X, int64_t n, int64_t m, int64_t ldx, double lambda,
+                                 int64_t *nan_count, int64_t *zero_count) {
+  if (!mh || !X) return fail(NMFK_ERR_BAD_ARG, "null argument");
+  return on_all(mh, [&](int g) {
+    return nmfk_comm_bcast_X(mh->comm[g], 0, g == 0 ? X : nullptr, n, m, ldx, lambda, nullptr, nullptr, g == 0 ? nan_count : nullptr,
+                             g == 0 ? zero_count : nullptr);
+  });
+}
+
+NMFK_EXPORT int nmfk_multi_context(nmfk_multi *mh, int gpu, nmfk_ctx **ctx) {
+  if (!mh || !ctx || gpu < 0 || gpu >= (int)mh->ctx.size()) return fail(NMFK_ERR_BAD_ARG, "bad argument");
+  *ctx = mh->ctx[gpu];
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_multi_sweep(nmfk_multi *mh, int nk, const int32_t *ks, int nruns, const float *const *Winit,
+                                 const float *const *Hinit, const uint64_t *seeds, const nmfk_mu_params *params,
+                                 float *const *W_out, float *const *H_out, float *const *frob_out, double *const *sse_out,
+                                 int32_t *const *iters_out, int32_t *const *reason_out) {
+  if (!mh) return fail(NMFK_ERR_BAD_ARG, "null argument");
+  return on_all(mh, [&](int g) {  // GPU 0 delivers the results; the others only contribute
+    const bool d = g == 0;
+    return nmfk_mu_sweep_sharded(mh->ctx[g], mh->comm[g], nk, ks, nruns, Winit, Hinit, seeds, params, 1, d ? W_out : nullptr,
+                                 d ? H_out : nullptr, d ? frob_out : nullptr, d ? sse_out : nullptr, d ? iters_out : nullptr,
+                                 d ? reason_out : nullptr);
+  });
+}

@@ -15,6 +15,7 @@ clustering, silhouettes, fit re-checks); this file is orchestration only (sortin
 the acceptance filters, k selection).  The reference's serial loops over k and over restarts become one
 flat (k, restart) work list; with torch.distributed initialised the list is sharded by restart over the
 ranks (parallel.py)."""
+import dataclasses
 import hashlib
 import math
 import os
@@ -22,7 +23,7 @@ import warnings
 
 import numpy as np
 
-from . import _lib
+from . import _lib, resultio
 from ._lib import Context, NMFkError
 
 _METHOD_ALIASES = {"multdiv", "multmse", "alspgrad"}  # Exec:138-147 -> method=:nmf (NMF.jl), not this path
@@ -42,13 +43,53 @@ def _is_sparse(X):
     return hasattr(X, "tocsc") and hasattr(X, "nnz")
 
 
+@dataclasses.dataclass
+class ExecuteOptions:
+    """NMFk.ExecuteOptions (Exec:15-30): the keyword bundle of the options-based `execute` overloads (Exec:33-65)."""
+    cutoff: float = 0.5
+    clusterWmatrix: bool = False
+    mixture: str = "null"
+    method: str = "simple"
+    algorithm: str = "multdiv"
+    resultdir: str = "."
+    load: bool = True
+    save: bool = True
+    casefilename: str = ""
+    dims: object = (1, 2)
+    loadonly: bool = False
+    quiet: bool = False
+    check_inputs: bool = True
+    ordersignals: bool = True
+
+
+_first_warning = True  # NMFk's module-level `first_warning` (Mult:8-15): the two warnings appear once per session
+
+
+def _zero_line_warnings(X):
+    """Mult:8-15: a row / column whose entries sum to 0 (NaN sums compare false, as in Julia)."""
+    global _first_warning
+    if not _first_warning:
+        return
+    _first_warning = False
+    if _is_sparse(X):
+        rs, cs = np.asarray(X.sum(axis=1)).ravel(), np.asarray(X.sum(axis=0)).ravel()
+    else:
+        Xa = np.asarray(X)
+        rs, cs = Xa.sum(axis=1), Xa.sum(axis=0)
+    if rs.size and np.nanmin(np.where(np.isnan(rs), np.inf, rs)) == 0:
+        warnings.warn("All matrix entries in a row should not be 0!")
+    if cs.size and np.nanmin(np.where(np.isnan(cs), np.inf, cs)) == 0:
+        warnings.warn("All matrix entries in a column should not be 0!")
+
+
 def _upload(ctx, X, lambda_=1e-32):
     """Dense arrays go through NMFpreprocessing! (zeros -> lambda); scipy.sparse matrices select the gather kernels
     (zeros stay zeros, the same arithmetic to < 1e-30; BASELINE configs[3])."""
     if _is_sparse(X):
         ctx.set_X_sparse(X)
     else:
-        ctx.set_X(X, lambda_)
+        ctx.set_X(X, lambda_)  # raises "All matrix entries must be nonnegative!" first (Mult:4-7)
+    _zero_line_warnings(X)
 
 
 def run_seed(seed, nk, run):
@@ -149,8 +190,9 @@ def _sweep(ctx, X, ks, nNMF, kw, need_all_W=True):
         raise TypeError(f"unknown keyword arguments: {sorted(kw)}")
     modifymatrices = not (mu.get("Wfixed") or mu.get("Hfixed"))  # Exec:486-489 (haskey; we use truthiness)
     mu["normalize"] = int(modifymatrices)
-    if seed is None:  # global-RNG path of the reference (Random.seed!(s) before execute): numpy's global RNG here
-        seed = int(np.random.randint(0, 2 ** 31 - 1))
+    if seed is None:  # global-RNG path of the reference (Random.seed!(s) before execute): numpy's global RNG here;
+        # drawn on rank 0 for everybody, so that a multi-rank sweep is one seed family
+        seed = parallel.bcast_object(int(np.random.randint(0, 2 ** 31 - 1)))
     n, m = X.shape
     wi = hi = None
     if Winit is not None or Hinit is not None:
@@ -181,8 +223,12 @@ def _sweep(ctx, X, ks, nNMF, kw, need_all_W=True):
             raise ValueError(f"Length of normalizing vector does not match: {v.size} vs {n}")
         ctx.set_X((np.asarray(X, dtype=np.float32) / v[:, None]).astype(np.float32), mu.get("lambda_", 1e-32))
     ctx.set_weight(weight_array)
-    res = parallel.sharded_sweep(ctx.mu_sweep, ks, nNMF, seeds, wi, hi, params, n, m,
-                                 need_all_W=need_all_W or normalizevector is not None)
+    comm = parallel.comm_of(ctx)
+    if comm is not None:  # ranks joined through the C ABI: shard, RCCL all-gather of the device buffers (all W included)
+        res = comm.mu_sweep(ks, nNMF, seeds=seeds, Winit=wi, Hinit=hi, params=params, need_W=True)
+    else:
+        res = parallel.sharded_sweep(ctx.mu_sweep, ks, nNMF, seeds, wi, hi, params, n, m,
+                                     need_all_W=need_all_W or normalizevector is not None)
     if normalizevector is not None:  # Mult:119-122: X .*= normalizevector; W .*= normalizevector, then Exec:791-792
         ctx.set_X(X, mu.get("lambda_", 1e-32))
         for k in ks:
@@ -193,7 +239,7 @@ def _sweep(ctx, X, ks, nNMF, kw, need_all_W=True):
 
 
 def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1, acceptfactor=math.inf, best=True,
-                      nanaction="zeroed", quiet=True):
+                      nanaction="zeroed", quiet=True, saveall=False, resultdir=".", casefilename=""):
     """Everything of execute_run after the restart loop (Exec:545-710)."""
     n, m = X.shape
     # Matrix{T} (Exec:529-531).  Multi-GPU with best=true: only this rank's restarts and the best one carry a W
@@ -231,6 +277,15 @@ def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1
             if (WBig[i] is not None and np.isnan(WBig[i]).any()) or np.isnan(HBig[i]).any():
                 idxnan[i] = False
     idxsol = idxrat & idxcut & idxnan  # Exec:596
+    if idxsol.sum() < nNMF and not quiet:  # Exec:597-600
+        print(f"NMF solutions removed based on various criteria: {idxsol.sum()} out of {nNMF} solutions remain")
+    # Exec:602-607: of = normnan((X - W*H) .* weight) against the stored objective (which is unweighted, Exec:791): the
+    # weighted residual norm of the final factors is the sqrt of the library's sse output (Mult:125)
+    if res.get("sse") is not None:
+        for i in range(nNMF):
+            of = math.sqrt(max(float(res["sse"][i]), 0.0))
+            if of > 0 and abs(of - float(objvalue[i])) / of > 1e-4:
+                warnings.warn(f"OF {i + 1} is very different: {of} vs {objvalue[i]}!")
     sel = idxsort[idxsol]  # WBig[idxsort][idxsol]
     minsilhouette = 1.0
     extra = dict(objvalue=objvalue, idxsort=idxsort, iters=np.asarray(res["iters"]), reason=np.asarray(res["reason"]))
@@ -254,7 +309,7 @@ def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1
             Hbest[i, :] = Hb0[c - 1, :]
         minsilhouette = float(np.min(csil))  # Exec:638
         extra.update(labels=labels, centroids=centroids, psil=psil, csil=csil)
-        if not best:
+        if not best or (saveall and casefilename != ""):
             Ws = np.stack([WBig[i] for i in sel])
             Wa, Ha, Wv, Hv = ctx.cluster_stats(Ws, Hs, labels)  # Fin:64-77
             extra.update(Wvar=Wv, Hvar=Hv)
@@ -264,6 +319,19 @@ def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1
         first = int(np.flatnonzero(idxsol)[0])
         Wa = WBig[first].mean(axis=1, keepdims=True)
         Ha = HBig[first].mean(axis=0, keepdims=True)
+    if saveall and casefilename != "":  # Exec:650-654: everything, before `best` replaces the cluster means
+        if nk == 1:  # (the reference stops here with an UndefVarError: clustersilhouettes only exists for nk > 1)
+            raise NameError("clustersilhouettes not defined (saveall needs nk > 1, src/NMFkExecute.jl:652)")
+        fn = _result_filename(resultdir, casefilename, n, m, nk, nNMF, "-all")
+        os.makedirs(resultdir, exist_ok=True)
+        f32 = resultio.as_julia
+        resultio.save(fn, **{"W": [f32(w) for w in WBig], "H": [f32(h) for h in HBig], "Wmean": f32(Wa), "Hmean": f32(Ha),
+                             "Wvar": f32(extra["Wvar"]), "Hvar": f32(extra["Hvar"]), "Wbest": f32(Wbest), "Hbest": f32(Hbest),
+                             "fit": f32(objvalue), "Cluster Silhouettes": f32(extra["csil"]),
+                             "Cluster assignments": np.asarray(extra["labels"], dtype=np.int64),
+                             "Cluster centroids": f32(extra["centroids"])})
+        if not quiet:
+            print(f"All results are saved in {fn}!")
     if best:
         Wa, Ha = Wbest, Hbest  # Exec:655-658
     phi_final = ctx.frobenius(Wa, Ha)  # Exec:664-667 (E[isnan] = 0 then norm == normnan)
@@ -275,6 +343,19 @@ def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1
     return Wa, Ha, phi_final, minsilhouette, aic, extra
 
 
+def _loadall(resultdir, casefilename, n, m, nk, nNMF):
+    """Exec:499-509: the restarts of an earlier run from `<case>_<n>_<m>_<nk>_<nNMF>-all.jld` ("W", "H", "fit"), or None."""
+    fn = _result_filename(resultdir, casefilename, n, m, nk, nNMF, "-all")
+    if not os.path.isfile(fn):
+        warnings.warn(f"File {fn} with ALL results is missing; runs will be executed!")
+        return None
+    z = resultio.load(fn, "W", "H", "fit")
+    print(f"All results are loaded from {fn}!")
+    R = len(z["W"])
+    return dict(W=np.stack([np.asarray(w, np.float32) for w in z["W"]]), H=np.stack([np.asarray(h, np.float32) for h in z["H"]]),
+                objvalue=np.asarray(z["fit"], np.float32), sse=None, iters=np.zeros(R, np.int32), reason=np.zeros(R, np.int32))
+
+
 def execute_run(X, nk, nNMF, device=None, return_details=False, **kw):
     """execute_run(X, nk, nNMF; ...) (Exec:483-711) -> (Wa, Ha, phi_final, minsilhouette, aic)."""
     if not _is_sparse(X):
@@ -283,12 +364,21 @@ def execute_run(X, nk, nNMF, device=None, return_details=False, **kw):
         raise ValueError(f"Input array has a zero dimension! Array size={X.shape}")
     ctx = _context(device)
     _upload(ctx, X, kw.get("lambda_", 1e-32))
-    post = {k: kw.pop(k) for k in ("clusterWmatrix", "acceptratio", "acceptfactor", "best", "nanaction") if k in kw}
-    for k in ("mixture", "resultdir", "casefilename", "loadall", "saveall", "method", "algorithm"):
+    post = {k: kw.pop(k) for k in ("clusterWmatrix", "acceptratio", "acceptfactor", "best", "nanaction", "saveall", "resultdir",
+                                   "casefilename") if k in kw}
+    loadall = kw.pop("loadall", False)
+    for k in ("mixture", "method", "algorithm"):
         kw.pop(k, None)
-    need_all_W = bool(post.get("clusterWmatrix")) or not post.get("best", True)
-    res, _ = _sweep(ctx, X, [int(nk)], int(nNMF), kw, need_all_W=need_all_W)
-    out = _execute_run_post(ctx, X, int(nk), int(nNMF), res[int(nk)], **post)
+    n, m = X.shape
+    res = None
+    if loadall and post.get("casefilename", "") != "":  # Exec:499-509
+        res = _loadall(post.get("resultdir", "."), post["casefilename"], n, m, int(nk), int(nNMF))
+        if res is not None:
+            post["saveall"] = False
+    if res is None:
+        need_all_W = bool(post.get("clusterWmatrix")) or not post.get("best", True) or bool(post.get("saveall"))
+        res = _sweep(ctx, X, [int(nk)], int(nNMF), kw, need_all_W=need_all_W)[0][int(nk)]
+    out = _execute_run_post(ctx, X, int(nk), int(nNMF), res, **post)
     return out if return_details else out[:5]
 
 
@@ -330,12 +420,12 @@ def check_x_hash(X, xfile, quiet=True):
     return h
 
 
-def _result_filename(resultdir, casefilename, n, m, nk, nNMF):
-    # Exec:265, 324: "<case>_<n>_<m>_<nk>_<nNMF>.jld"; the payload here is .npz with the same keys
-    return os.path.join(resultdir, f"{casefilename}_{n}_{m}_{nk}_{nNMF}.npz")
+def _result_filename(resultdir, casefilename, n, m, nk, nNMF, suffix=""):
+    # Exec:265, 324: "<case>_<n>_<m>_<nk>_<nNMF>.jld" (Exec:500, 651: "...-all.jld" for the saveall payload)
+    return os.path.join(resultdir, f"{casefilename}_{n}_{m}_{nk}_{nNMF}{suffix}{resultio.EXT}")
 
 
-def execute(X, nkrange, nNMF=10, *, cutoff=0.5, clusterWmatrix=False, mixture="null", method="simple",
+def execute(X, nkrange, nNMF=10, opts=None, *, cutoff=0.5, clusterWmatrix=False, mixture="null", method="simple",
             algorithm="multdiv", resultdir=".", load=True, save=True, casefilename="", loadonly=False, quiet=False,
             check_inputs=True, ordersignals=True, device=None, ctx=None, return_details=False, **kw):
     """NMFk.execute (Exec:178-233 for a range of k, Exec:236-329 for one k).
@@ -343,13 +433,23 @@ def execute(X, nkrange, nNMF=10, *, cutoff=0.5, clusterWmatrix=False, mixture="n
     nkrange: an int (-> 5-tuple W, H, fit, robustness, aic) or a range/list (-> 6-tuple with kopt).
     ctx: an nmfk Context on which set_X(X) has ALREADY been called (X resident in HBM, e.g. for repeated sweeps);
     by default the per-device context is used and X is uploaded here."""
+    single = isinstance(nkrange, (int, np.integer))
+    if opts is not None:  # the options-based overloads forward exactly these fields (Exec:33-47 range, Exec:50-65 one k)
+        if not isinstance(opts, ExecuteOptions):
+            raise TypeError("the fourth positional argument is an ExecuteOptions")
+        o = opts
+        fwd = dict(clusterWmatrix=o.clusterWmatrix, mixture=o.mixture, method=o.method, algorithm=o.algorithm,
+                   resultdir=o.resultdir, load=o.load, save=o.save, casefilename=o.casefilename, dims=o.dims)
+        fwd.update(dict(loadonly=o.loadonly, quiet=o.quiet, check_inputs=o.check_inputs, ordersignals=o.ordersignals) if single
+                   else dict(cutoff=o.cutoff))
+        return execute(X, nkrange, nNMF, device=device, ctx=ctx, return_details=return_details, **fwd, **kw)
+    kw.pop("dims", None)  # Exec:178, 236: `dims` only matters for tensors (N > 2), which this path rejects
     if not _is_sparse(X):
         X = np.asarray(X)
     if X.ndim > 2:
         raise ValueError("NMFk analysis can be executed for matrices!")
     if X.shape[0] * X.shape[1] == 0:
         raise ValueError(f"Input array has a zero dimension! Array size={X.shape}")  # Exec:242-244
-    single = isinstance(nkrange, (int, np.integer))
     ks = [int(nkrange)] if single else [int(k) for k in nkrange]
     if loadonly:  # Exec:245-251
         load, save = True, False
@@ -363,34 +463,44 @@ def execute(X, nkrange, nNMF=10, *, cutoff=0.5, clusterWmatrix=False, mixture="n
     aic = np.zeros(maxk, dtype=np.float32)
     fitquality[0], robustness[0] = np.inf, -1  # Exec:200-201
     details = {}
-    post = {k: kw.pop(k) for k in ("acceptratio", "acceptfactor", "best", "nanaction") if k in kw}
+    post = {k: kw.pop(k) for k in ("acceptratio", "acceptfactor", "best", "nanaction", "saveall") if k in kw}
+    loadall = kw.pop("loadall", False)
     if "Wfixed" in kw or "Hfixed" in kw:  # Exec:305-307
         ordersignals = False
 
-    if load or save:  # Exec:256-262 (the reference hashes X on every call, once per k; here only when the cache is in use)
-        xs = "_".join(str(v) for v in X.shape)
-        check_x_hash(X, os.path.join(resultdir, f"{casefilename or 'nmfk'}_x_matrix_{xs}.npz"), quiet=quiet)
+    # Result cache (Exec:256-303).  With several ranks (one process per GPU) only rank 0 touches the files: it reads the
+    # cached ranks and decides what is still to do, everybody else receives that decision -- every rank must enter the
+    # sharded sweep with the SAME list of ranks -- and the loaded factors.
+    from . import parallel
+
+    rank0 = parallel.world()[0] == 0
     todo, recheck = [], []
-    for nk in ks:  # Exec:264-303: per-k result cache
-        fn = _result_filename(resultdir, casefilename, n, m, nk, nNMF)
-        if load and not os.path.isfile(fn):  # Exec:266-269: old file-name convention
-            old = os.path.join(resultdir, f"{casefilename}-{nk}-{nNMF}.npz")
-            fn = old if os.path.isfile(old) else fn
-        if load and os.path.isfile(fn):
-            with np.load(fn) as z:
-                Wl, Hl = z["W"], z["H"]
+    if rank0:
+        if load or save:  # Exec:256-262 (the reference hashes X once per k; here once per call, when the cache is in use)
+            xs = "_".join(str(v) for v in X.shape)
+            check_x_hash(X, os.path.join(resultdir, f"{casefilename or 'nmfk'}_x_matrix_{xs}{resultio.EXT}"), quiet=quiet)
+        for nk in ks:  # Exec:264-303: per-k result cache
+            fn = _result_filename(resultdir, casefilename, n, m, nk, nNMF)
+            if load and not os.path.isfile(fn):  # Exec:266-269: old file-name convention
+                old = os.path.join(resultdir, f"{casefilename}-{nk}-{nNMF}{resultio.EXT}")
+                fn = old if os.path.isfile(old) else fn
+            if load and os.path.isfile(fn):
+                z = resultio.load(fn)
+                Wl, Hl = np.asarray(z["W"]), np.asarray(z["H"])
                 if Wl.shape == (n, nk) and Hl.shape == (nk, m):
                     W[nk - 1], H[nk - 1] = Wl, Hl
                     fitquality[nk - 1], robustness[nk - 1], aic[nk - 1] = z["fit"], z["robustness"], z["aic"]
                     recheck.append(nk)
                     continue
-            if not quiet:  # Exec:287-289
-                print(f"File {fn} contains inconsistent results; runs will be executed ...")
-        if loadonly:  # Exec:291-298 sentinel
-            W[nk - 1], H[nk - 1] = np.zeros((0, 0), np.float32), np.zeros((0, 0), np.float32)
-            fitquality[nk - 1], robustness[nk - 1], aic[nk - 1] = np.inf, -1, -np.inf
-            continue
-        todo.append(nk)
+                if not quiet:  # Exec:287-289
+                    print(f"File {fn} contains inconsistent results; runs will be executed ...")
+            if loadonly:  # Exec:291-298 sentinel
+                W[nk - 1], H[nk - 1] = np.zeros((0, 0), np.float32), np.zeros((0, 0), np.float32)
+                fitquality[nk - 1], robustness[nk - 1], aic[nk - 1] = np.inf, -1, -np.inf
+                continue
+            todo.append(nk)
+    if parallel.world()[1] > 1:
+        todo, recheck, W, H, fitquality, robustness, aic = parallel.bcast_object((todo, recheck, W, H, fitquality, robustness, aic))
 
     if ctx is None and (todo or not all(np.isinf(fitquality[[k - 1 for k in ks]]))):
         ctx = _context(device)
@@ -400,13 +510,25 @@ def execute(X, nkrange, nNMF=10, *, cutoff=0.5, clusterWmatrix=False, mixture="n
         if abs(fit - fitquality[nk - 1]) > np.finfo(np.float16).eps:
             warnings.warn(f"Fit quality is not consistent: {fit} != {fitquality[nk - 1]}")
             fitquality[nk - 1] = fit
-            np.savez(_result_filename(resultdir, casefilename, n, m, nk, nNMF), W=W[nk - 1], H=H[nk - 1],
-                     fit=fitquality[nk - 1], robustness=robustness[nk - 1], aic=aic[nk - 1])
+            if rank0:
+                resultio.save(_result_filename(resultdir, casefilename, n, m, nk, nNMF), W=W[nk - 1], H=H[nk - 1],
+                              fit=fitquality[nk - 1], robustness=robustness[nk - 1], aic=aic[nk - 1])
     if todo:
-        res, _ = _sweep(ctx, X, todo, int(nNMF), kw, need_all_W=bool(clusterWmatrix) or not post.get("best", True))
+        res = {}
+        if loadall and casefilename != "":  # Exec:499-509 per rank: restarts of an earlier run instead of new ones
+            for nk in todo:
+                r = _loadall(resultdir, casefilename, n, m, nk, int(nNMF)) if rank0 else None
+                r = parallel.bcast_object(r)
+                if r is not None:
+                    res[nk] = r
+        run = [nk for nk in todo if nk not in res]
+        if run:
+            need_all_W = bool(clusterWmatrix) or not post.get("best", True) or bool(post.get("saveall"))
+            res.update(_sweep(ctx, X, run, int(nNMF), kw, need_all_W=need_all_W)[0])
         for nk in todo:
+            sv = dict(post, saveall=bool(post.get("saveall")) and rank0 and nk in run)
             Wa, Ha, phi, sil, a, extra = _execute_run_post(ctx, X, nk, int(nNMF), res[nk], clusterWmatrix, quiet=quiet,
-                                                           **post)
+                                                           resultdir=resultdir, casefilename=casefilename, **sv)
             so = signalorder(Wa, Ha) if ordersignals else np.arange(nk)  # Exec:311-318
             W[nk - 1], H[nk - 1] = Wa[:, so], Ha[so, :]
             fitquality[nk - 1], robustness[nk - 1], aic[nk - 1] = phi, sil, a
@@ -414,10 +536,12 @@ def execute(X, nkrange, nNMF=10, *, cutoff=0.5, clusterWmatrix=False, mixture="n
             details[nk] = extra
             if not quiet:  # Exec:322
                 print("Signals: %2d Fit: %12.7g Silhouette: %12.7g AIC: %12.7g Signal order: %s" % (nk, phi, sil, a, so + 1))
-            if save:  # Exec:323-327
+            if save and rank0:  # Exec:323-327 (written to a temporary name and renamed: readers never see a partial file)
                 os.makedirs(resultdir, exist_ok=True)
-                np.savez(_result_filename(resultdir, casefilename, n, m, nk, nNMF), W=W[nk - 1], H=H[nk - 1],
-                         fit=fitquality[nk - 1], robustness=robustness[nk - 1], aic=aic[nk - 1])
+                resultio.save(_result_filename(resultdir, casefilename, n, m, nk, nNMF), W=W[nk - 1], H=H[nk - 1],
+                              fit=fitquality[nk - 1], robustness=robustness[nk - 1], aic=aic[nk - 1])
+        if save:
+            parallel.barrier()  # nobody starts the next call before rank 0 has finished writing
     if single:
         nk = ks[0]
         out = (W[nk - 1], H[nk - 1], fitquality[nk - 1], robustness[nk - 1], aic[nk - 1])

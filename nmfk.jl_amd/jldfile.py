@@ -1,0 +1,455 @@
+"""Minimal HDF5 reader / writer for the JLD files NMFk.jl keeps its results in (JLD.jl, file format "Julia data file
+(HDF5), version 0.1.3").
+
+Scope: what `JLD.save(filename, "W", W, "H", H, "fit", fit, "robustness", r, "aic", a)` (src/NMFkExecute.jl:323-327) and the
+`-all.jld` payload of `execute_run` (src/NMFkExecute.jl:650-654) contain -- numeric arrays, numeric scalars and vectors of
+arrays -- in the on-disk structures JLD.jl + libhdf5 produce for them and that the reference's own cached `.jld` files
+use (tests/golden/*.jld are two such files, written by Julia; tests/test_jldfile.py parses them with this reader):
+
+  * a 512-byte user block that starts with the JLD magic string, then an HDF5 version-0 superblock;
+  * version-1 object headers; groups as link-info + group-info + hard-link messages (the reader also follows the older
+    symbol-table form: v1 B-tree "TREE", symbol nodes "SNOD", local heap "HEAP"), datasets with dataspace (version 1,
+    maximum dimensions present) / datatype / fill-value / layout (version 3: compact up to 8 KB, else contiguous) /
+    modification-time messages; committed datatypes of /_types are followed through shared messages;
+  * little-endian data; Julia arrays keep their column-major bytes and the dataspace lists the dimensions REVERSED
+    (HDF5 is row-major), exactly as JLD.jl does;
+  * `Vector{Matrix{T}}` as a dataset of object references into the `/_refs` group (JLD's representation of arrays of
+    non-bits types), tagged with the attribute "julia type";
+  * the `/_creator` group with the scalar datasets JLD.jl reads on open (JULIA_MAJOR, JULIA_MINOR, JULIA_PATCH,
+    WORD_SIZE, ENDIAN_BOM) and the `/_types` group.
+There is no h5py / libhdf5 Python binding in the image and no Julia, so files written here are checked by reading them
+back with this module and by comparing their structure with the Julia-written golden files, not by JLD.jl itself.
+"""
+import struct
+
+import numpy as np
+
+MAGIC = b"Julia data file (HDF5), version 0.1.3"
+SIG = b"\x89HDF\r\n\x1a\n"
+UNDEF = 0xFFFFFFFFFFFFFFFF
+USERBLOCK = 512
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# reader
+# ---------------------------------------------------------------------------------------------------------------
+class _Reader:
+    def __init__(self, buf):
+        self.buf = buf
+        at = buf.find(SIG)
+        if at < 0:
+            raise ValueError("not an HDF5 file")
+        sb = buf[at:]
+        if sb[8] != 0:
+            raise ValueError(f"HDF5 superblock version {sb[8]} is not supported (JLD files written by libhdf5 use 0)")
+        if sb[13] != 8 or sb[14] != 8:
+            raise ValueError("only 8-byte offsets / lengths are supported")
+        self.base = struct.unpack_from("<Q", sb, 24)[0]
+        self.root_header = struct.unpack_from("<Q", sb, 56 + 8)[0]
+
+    def at(self, addr):
+        return self.base + addr
+
+    # --- groups ---------------------------------------------------------------------------------------------
+    def _heap_data(self, addr):
+        o = self.at(addr)
+        assert self.buf[o:o + 4] == b"HEAP"
+        size, _free, data = struct.unpack_from("<QQQ", self.buf, o + 8)
+        return self.at(data), size
+
+    def _tree_entries(self, addr, heap):
+        o = self.at(addr)
+        assert self.buf[o:o + 4] == b"TREE", "group B-tree expected"
+        ntype, level, used = struct.unpack_from("<BBH", self.buf, o + 4)
+        assert ntype == 0
+        out = []
+        p = o + 8 + 16
+        for i in range(used):
+            child = struct.unpack_from("<Q", self.buf, p + 8)[0]  # key_i, child_i
+            p += 16
+            out += self._tree_entries(child, heap) if level > 0 else self._snod(child, heap)
+        return out
+
+    def _snod(self, addr, heap):
+        o = self.at(addr)
+        assert self.buf[o:o + 4] == b"SNOD"
+        n = struct.unpack_from("<H", self.buf, o + 6)[0]
+        out = []
+        for i in range(n):
+            e = o + 8 + 40 * i
+            name_off, hdr = struct.unpack_from("<QQ", self.buf, e)
+            s = heap[0] + name_off
+            name = self.buf[s:self.buf.index(b"\0", s)].decode()
+            out.append((name, hdr))
+        return out
+
+    # --- object headers -------------------------------------------------------------------------------------
+    def messages(self, addr):
+        o = self.at(addr)
+        ver, _r, nmsg, _ref, hsize = struct.unpack_from("<BBHII", self.buf, o)
+        assert ver == 1, "version-1 object header expected"
+        blocks = [(o + 16, hsize)]
+        msgs = []
+        while blocks and len(msgs) < nmsg:
+            p, left = blocks.pop(0)
+            end = p + left
+            while p + 8 <= end and len(msgs) < nmsg:
+                mtype, msize, flags = struct.unpack_from("<HHB", self.buf, p)
+                body = self.buf[p + 8:p + 8 + msize]
+                p += 8 + msize
+                if mtype == 0x0010:  # continuation
+                    coff, clen = struct.unpack_from("<QQ", body, 0)
+                    blocks.append((self.at(coff), clen))
+                if flags & 2 and mtype == 0x0003:  # shared message: the datatype is committed (JLD's /_types group)
+                    ver = body[0]
+                    target = struct.unpack_from("<Q", body, 8 if ver == 1 else 2)[0]
+                    body = next(b for t, b in self.messages(target) if t == 0x0003)
+                msgs.append((mtype, body))
+        return msgs
+
+    def group_entries(self, hdr_addr):
+        """[(name, object header address)] of a group, None for a dataset.  Old style: symbol-table message -> B-tree +
+        local heap.  New style (what libhdf5 >= 1.8 writes for JLD's groups): link-info + group-info messages and one
+        link message per member in the object header ("compact" storage)."""
+        links, is_group = [], False
+        for mtype, body in self.messages(hdr_addr):
+            if mtype == 0x0011:
+                btree, heap = struct.unpack_from("<QQ", body, 0)
+                return self._tree_entries(btree, self._heap_data(heap))
+            if mtype in (0x0002, 0x000A):
+                is_group = True
+                if mtype == 0x0002 and struct.unpack_from("<Q", body, 2 + (8 if body[1] & 1 else 0))[0] != UNDEF:
+                    raise ValueError("densely stored groups (fractal heap) are not supported")
+            if mtype == 0x0006:
+                is_group = True
+                flags, p = body[1], 2
+                ltype = 0
+                if flags & 8:
+                    ltype, p = body[p], p + 1
+                if flags & 4:
+                    p += 8
+                if flags & 16:
+                    p += 1
+                nb = 1 << (flags & 3)
+                ln = int.from_bytes(body[p:p + nb], "little")
+                p += nb
+                name = body[p:p + ln].decode()
+                p += ln
+                if ltype == 0:
+                    links.append((name, struct.unpack_from("<Q", body, p)[0]))
+        return links if is_group else None
+
+    # --- message bodies -------------------------------------------------------------------------------------
+    @staticmethod
+    def dataspace(body):
+        ver, rank, flags = struct.unpack_from("<BBB", body, 0)
+        if ver == 1:
+            p = 8
+        else:
+            if body[3] == 2:  # null dataspace
+                return None
+            p = 4
+        return tuple(struct.unpack_from("<Q", body, p + 8 * i)[0] for i in range(rank))
+
+    def datatype(self, body, p=0):
+        """-> (descriptor, bytes consumed).  descriptor: numpy dtype, ("ref",), ("vlen", base), ("compound", fields)."""
+        cv, b0, b1, b2, size = struct.unpack_from("<BBBBI", body, p)
+        cls, ver = cv & 15, cv >> 4
+        q = p + 8
+        if cls == 0:  # fixed point
+            signed = bool(b0 & 8)
+            return np.dtype(("<i" if signed else "<u") + str(size)), q + 4 - p
+        if cls == 4:  # bit field (JLD: Bool)
+            return np.dtype("<u" + str(size)), q + 4 - p
+        if cls == 1:  # floating point
+            return np.dtype("<f" + str(size)), q + 12 - p
+        if cls == 3:  # fixed-length string
+            return np.dtype("S" + str(size)), q - p
+        if cls == 7:  # reference
+            return ("ref",), q - p
+        if cls == 9:  # variable length
+            base, used = self.datatype(body, q)
+            return ("vlen", base, bool(b0 & 1)), q + used - p
+        if cls == 6:  # compound
+            nmemb = b0 | (b1 << 8)
+            fields = []
+            for _ in range(nmemb):
+                e = body.index(b"\0", q)
+                name = body[q:e].decode()
+                if ver < 3:
+                    q += (e - q + 8) & ~7
+                    off = struct.unpack_from("<I", body, q)[0]
+                    q += 4 + (28 if ver == 1 else 0)
+                else:
+                    q = e + 1
+                    nb = 1 if size < 256 else 2 if size < 65536 else 4
+                    off = int.from_bytes(body[q:q + nb], "little")
+                    q += nb
+                t, used = self.datatype(body, q)
+                q += used
+                fields.append((name, off, t))
+            return ("compound", size, fields), q - p
+        raise ValueError(f"HDF5 datatype class {cls} is not supported")
+
+    def attributes(self, hdr_addr):
+        out = {}
+        for mtype, body in self.messages(hdr_addr):
+            if mtype != 0x000C:
+                continue
+            ver = body[0]
+            nsz, tsz, ssz = struct.unpack_from("<HHH", body, 2)
+            pad = (lambda v: (v + 7) & ~7) if ver == 1 else (lambda v: v)
+            p = 8 + (1 if ver == 3 else 0)
+            name = body[p:p + nsz].split(b"\0")[0].decode()
+            p += pad(nsz)
+            t, _ = self.datatype(body, p)
+            tbody = p
+            p += pad(tsz)
+            shape = self.dataspace(body[p:p + ssz])
+            p += pad(ssz)
+            out[name] = self._decode(t, shape, body[p:], body[tbody:tbody + tsz])
+        return out
+
+    def _decode(self, t, shape, raw, tbody=None):
+        count = int(np.prod(shape)) if shape else 1
+        if isinstance(t, np.dtype):
+            a = np.frombuffer(raw, dtype=t, count=count)
+            if t.kind == "S":
+                a = np.array([v.split(b"\0")[0].decode() for v in a], dtype=object)
+            if shape is None or shape == ():
+                return a[0]
+            return a.reshape(shape[::-1], order="F") if len(shape) > 1 else a.copy()
+        if t[0] == "ref":
+            return [struct.unpack_from("<Q", raw, 8 * i)[0] for i in range(count)]
+        if t[0] == "vlen":  # global-heap references: (length, collection address, index)
+            vals = []
+            for i in range(count):
+                ln, coll, idx = struct.unpack_from("<IQI", raw, 16 * i)
+                data = self._global_heap(coll, idx)
+                base = t[1]
+                if t[2] or (isinstance(base, np.dtype) and base.kind in "Su" and base.itemsize == 1):
+                    vals.append(data[:ln].decode(errors="replace"))
+                else:
+                    vals.append(np.frombuffer(data, dtype=base, count=ln).copy())
+            return vals[0] if shape in (None, ()) else vals
+        if t[0] == "compound":
+            recs = []
+            for i in range(count):
+                rec = {}
+                for name, off, ft in t[2]:
+                    rec[name] = self._decode(ft, (), raw[i * t[1] + off:])
+                recs.append(rec)
+            return recs[0] if shape in (None, ()) else recs
+        raise ValueError(t)
+
+    def _global_heap(self, coll, idx):
+        o = self.at(coll)
+        assert self.buf[o:o + 4] == b"GCOL"
+        size = struct.unpack_from("<Q", self.buf, o + 8)[0]
+        p = o + 16
+        while p < o + size:
+            i, _ref, _r, ln = struct.unpack_from("<HHIQ", self.buf, p)
+            if i == idx:
+                return self.buf[p + 16:p + 16 + ln]
+            if i == 0:
+                break
+            p += 16 + ((ln + 7) & ~7)
+        raise KeyError(idx)
+
+    def dataset(self, hdr_addr):
+        """-> (value, attributes, descriptor) of the dataset whose object header is at hdr_addr."""
+        shape = t = raw = None
+        for mtype, body in self.messages(hdr_addr):
+            if mtype == 0x0001:
+                shape = self.dataspace(body)
+            elif mtype == 0x0003:
+                t, _ = self.datatype(body)
+            elif mtype == 0x0008:
+                ver, cls = body[0], body[1]
+                assert ver == 3, "version-3 layout message expected"
+                if cls == 0:
+                    n = struct.unpack_from("<H", body, 2)[0]
+                    raw = body[4:4 + n]
+                elif cls == 1:
+                    addr, n = struct.unpack_from("<QQ", body, 2)
+                    raw = b"" if addr == UNDEF else self.buf[self.at(addr):self.at(addr) + n]
+                else:
+                    raise ValueError("chunked datasets are not supported")
+        if raw is None:  # a committed datatype (member of /_types), not a dataset
+            return None, self.attributes(hdr_addr), (t, None)
+        return self._decode(t, shape, raw), self.attributes(hdr_addr), (t, shape)
+
+
+def read_structure(path):
+    """Low-level view used by the tests: dict name -> dict(kind='group'|'dataset', attrs, [value, type, shape, children])."""
+    R = _Reader(open(path, "rb").read())
+
+    def walk(hdr):
+        ents = R.group_entries(hdr)
+        if ents is not None:
+            return dict(kind="group", attrs=R.attributes(hdr), children={name: walk(h) for name, h in ents}, header=hdr)
+        value, attrs, (t, shape) = R.dataset(hdr)
+        return dict(kind="dataset", attrs=attrs, value=value, type=t, shape=shape, header=hdr)
+
+    return walk(R.root_header), R
+
+
+def load(path, *names):
+    """JLD.load: dict of the top-level variables (all of them, or the named ones).  Arrays of references (Vector{Matrix})
+    come back as lists of arrays."""
+    root, R = read_structure(path)
+    byhdr = {}
+
+    def index(node):
+        byhdr[node["header"]] = node
+        for c in node.get("children", {}).values():
+            index(c)
+
+    index(root)
+    out = {}
+    for name, node in root["children"].items():
+        if name.startswith("_") or (names and name not in names) or node["kind"] != "dataset":
+            continue
+        v = node["value"]
+        if node["type"] and not isinstance(node["type"], np.dtype) and node["type"][0] == "ref":
+            v = [byhdr[h]["value"] for h in v]
+        out[name] = v
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# writer
+# ---------------------------------------------------------------------------------------------------------------
+_JTYPE = {"f4": "Float32", "f8": "Float64", "i4": "Int32", "i8": "Int64", "u1": "UInt8", "u8": "UInt64", "i2": "Int16", "u4": "UInt32"}
+
+
+def _pad8(b):
+    return b + b"\0" * (-len(b) % 8)
+
+
+def _dt_msg(dt):
+    dt = np.dtype(dt)
+    if dt.kind == "f":
+        exp_size, mant = {4: (8, 23), 8: (11, 52)}[dt.itemsize]
+        props = struct.pack("<HHBBBBI", 0, dt.itemsize * 8, mant, exp_size, 0, mant, {4: 127, 8: 1023}[dt.itemsize])
+        return struct.pack("<BBBBI", 0x11, 0x20, dt.itemsize * 8 - 1, 0, dt.itemsize) + props
+    if dt.kind in "iu":
+        return struct.pack("<BBBBI", 0x10, 0x08 if dt.kind == "i" else 0, 0, 0, dt.itemsize) + struct.pack("<HH", 0, dt.itemsize * 8)
+    if dt.kind == "S":
+        return struct.pack("<BBBBI", 0x13, 0x00, 0, 0, dt.itemsize)  # null-terminated ASCII
+    raise TypeError(dt)
+
+
+_REF_DT = struct.pack("<BBBBI", 0x17, 0, 0, 0, 8)  # object reference
+
+
+def _ds_msg(shape):
+    if shape is None:  # scalar
+        return struct.pack("<BBB5x", 1, 0, 0)
+    dims = b"".join(struct.pack("<Q", int(d)) for d in shape)
+    return struct.pack("<BBB5x", 1, len(shape), 1) + dims + dims  # version 1, maximum dimensions present (= dims)
+
+
+def _attr_msg(name, value):
+    """version-3 attribute message with a fixed-length UTF-8 string value (JLD's "julia type" tags)"""
+    nm = name.encode() + b"\0"
+    raw = value.encode() + b"\0"
+    t = struct.pack("<BBBBI", 0x13, 0x10, 0, 0, len(raw))  # string, null-terminated, UTF-8
+    sp = struct.pack("<BBB5x", 1, 0, 0)
+    return struct.pack("<BBHHHB", 3, 0, len(nm), len(t), len(sp), 1) + nm + t + sp + raw
+
+
+def _msg(mtype, body, flags=0):
+    body = _pad8(body)
+    return struct.pack("<HHB3x", mtype, len(body), flags) + body
+
+
+def _header(msgs):
+    body = b"".join(msgs)
+    return struct.pack("<BBHII4x", 1, 0, len(msgs), 1, len(body)) + body
+
+
+_FILL = struct.pack("<BBBB", 2, 1, 2, 1)           # fill value: version 2, allocate early, write if set, defined (default)
+_MTIME = struct.pack("<B3xI", 1, 0x60da8f04)       # object modification time, version 1
+_COMPACT_MAX = 8192                                # small datasets live inside their object header (layout class 0)
+
+
+class _Writer:
+    def __init__(self):
+        self.buf = bytearray(b"\0" * 96)  # superblock (addresses are relative to the end of the user block)
+
+    def alloc(self, data):
+        self.buf += b"\0" * (-len(self.buf) % 8)
+        addr = len(self.buf)
+        self.buf += data
+        return addr
+
+    def dataset(self, array=None, refs=None, attrs=()):
+        """writes the raw data (when it is not compact) then the object header; returns the header's address"""
+        if refs is not None:
+            raw, tmsg, shape = b"".join(struct.pack("<Q", r) for r in refs), _REF_DT, (len(refs),)
+        else:
+            a = np.asarray(array)
+            a = a.astype(a.dtype.newbyteorder("<"), copy=False)
+            raw, tmsg = np.asfortranarray(a).tobytes(order="F"), _dt_msg(a.dtype)
+            shape = None if a.ndim == 0 else a.shape[::-1]  # Julia column-major -> HDF5 dimensions reversed
+        if len(raw) <= _COMPACT_MAX:
+            layout = struct.pack("<BBH", 3, 0, len(raw)) + raw
+        else:
+            layout = struct.pack("<BBQQ", 3, 1, self.alloc(raw), len(raw))
+        msgs = [_msg(0x0001, _ds_msg(shape)), _msg(0x0003, tmsg, flags=1), _msg(0x0005, _FILL, flags=1), _msg(0x0008, layout),
+                _msg(0x0012, _MTIME)]
+        msgs += [_msg(0x000C, _attr_msg(k, v)) for k, v in attrs]
+        return self.alloc(_header(msgs))
+
+    def group(self, entries):
+        """group as libhdf5 writes it for JLD: link-info + group-info messages and one hard-link message per member in
+        the (version-1) object header"""
+        msgs = [_msg(0x0002, struct.pack("<BBQQ", 0, 0, UNDEF, UNDEF)), _msg(0x000A, struct.pack("<BB", 0, 0))]
+        for name, hdr in entries:
+            nm = name.encode()
+            if len(nm) > 255:
+                raise ValueError("link name too long")
+            msgs.append(_msg(0x0006, struct.pack("<BBBB", 1, 0x10, 1, len(nm)) + nm + struct.pack("<Q", hdr)))
+        return self.alloc(_header(msgs))
+
+    def finish(self, root_hdr):
+        sb = SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, 4, 16, 0)
+        sb += struct.pack("<QQQQ", USERBLOCK, UNDEF, len(self.buf), UNDEF)
+        sb += struct.pack("<QQII16x", 0, root_hdr, 0, 0)  # root symbol-table entry: nothing cached
+        self.buf[:96] = sb
+        return MAGIC + b"\0" * (USERBLOCK - len(MAGIC)) + bytes(self.buf)
+
+
+def _julia_type(a):
+    a = np.asarray(a)
+    return _JTYPE[a.dtype.str[1:]]
+
+
+def save(path, variables):
+    """JLD.save(path, name1, value1, ...).  values: numpy arrays / numpy scalars / Python floats and ints, or lists of
+    arrays (Vector{Matrix{T}}: reference datasets into /_refs)."""
+    W = _Writer()
+    top, refs = [], []
+    for name, v in variables.items():
+        if isinstance(v, (list, tuple)):
+            hdrs = []
+            for a in v:
+                a = np.asarray(a)
+                hdrs.append(W.dataset(a))
+                refs.append(("%08d" % (len(refs) + 1), hdrs[-1]))
+            inner = _julia_type(v[0]) if len(v) else "Float32"
+            nd = np.asarray(v[0]).ndim if len(v) else 2
+            top.append((name, W.dataset(refs=hdrs, attrs=[("julia type", f"Core.Array{{Core.Array{{Core.{inner},{nd}}},1}}")])))
+        else:
+            top.append((name, W.dataset(np.asarray(v))))
+    creator = W.group([("JULIA_PATCH", W.dataset(np.uint32(0))), ("JULIA_MAJOR", W.dataset(np.uint32(1))),
+                       ("WORD_SIZE", W.dataset(np.int64(64))), ("JULIA_MINOR", W.dataset(np.uint32(11))),
+                       ("ENDIAN_BOM", W.dataset(np.uint32(0x04030201)))])
+    top.append(("_creator", creator))
+    top.append(("_types", W.group([])))
+    if refs:
+        top.append(("_refs", W.group(refs)))
+    data = W.finish(W.group(top))
+    with open(path, "wb") as fh:
+        fh.write(data)

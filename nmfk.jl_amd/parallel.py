@@ -1,5 +1,9 @@
-"""Sharding of the flat (k, restart) work list over the GPUs of one node: one process per GPU,
-torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+"""Sharding of the flat (k, restart) work list over the GPUs of one node, one process per GPU.
+
+The product path is the C ABI: `attach(ctx)` joins the rank's Context to an RCCL communicator inside libnmfk_hip
+(nmfk_comm_create) and `Comm.mu_sweep` = nmfk_mu_sweep_sharded does the shard / all-gather on device buffers.
+The torch.distributed functions below (`broadcast_X`, `sharded_sweep`) are the same plan in Python: the CPU rehearsal of
+the N > 1 logic (gloo, tests/test_parallel_gloo.py) and the fallback when no communicator is attached.
 
 The reference's only parallelism is `Distributed.pmap` over the restarts of ONE k (src/NMFkExecute.jl:511-526),
 shipping X to a worker with every task.  Here the (k, restart) units of the WHOLE sweep are sharded (`plan_shards`: rank g owns restarts {g, g+N, ...} of
@@ -8,11 +12,61 @@ iterations, and W or only the best W per k) are exchanged in ONE padded all-gath
 rank can run the clustering step."""
 import numpy as np
 
+_comms = {}  # id(Context) -> _lib.Comm: ranks joined through the C ABI (nmfk_comm_*, RCCL inside libnmfk_hip)
+
+
+def attach(ctx):
+    """Joins this process' Context to the job's RCCL communicator THROUGH THE C ABI (nmfk_comm_create; the data path of
+    bench.py --gpus N and of execute() under torchrun).  torch.distributed (already initialised, any backend) only
+    carries the 128-byte unique id from rank 0 to the others."""
+    from . import _lib
+
+    d = _dist()
+    if d is None:
+        return None
+    if id(ctx) in _comms:
+        return _comms[id(ctx)]
+    box = [_lib.comm_unique_id() if d.get_rank() == 0 else None]
+    d.broadcast_object_list(box, src=0)
+    comm = _lib.Comm(ctx, d.get_world_size(), d.get_rank(), box[0])
+    _comms[id(ctx)] = comm
+    return comm
+
+
+def comm_of(ctx):
+    return _comms.get(id(ctx))
+
+
+def detach(ctx):
+    c = _comms.pop(id(ctx), None)
+    if c is not None:
+        c.close()
+
+
+def bcast_object(obj, src=0):
+    """Host-side object from rank `src` to everybody (cache decisions, seeds); identity without a process group."""
+    d = _dist()
+    if d is None:
+        return obj
+    box = [obj if d.get_rank() == src else None]
+    d.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def barrier():
+    d = _dist()
+    if d is not None:
+        d.barrier()
+
 
 def _dist():
+    import sys
+
+    if "torch" not in sys.modules:  # nobody in this process can have initialised a process group (and importing torch
+        return None                 # here would cost seconds and load a second copy of librccl next to libnmfk_hip's)
     try:
         import torch.distributed as dist
-    except Exception:  # torch absent: single process
+    except Exception:  # torch without distributed support: single process
         return None
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         return dist

@@ -547,22 +547,81 @@ def test_execute_cache_roundtrip(NMFk, tmp_path):
     assert W.shape == (0, 0) and H.shape == (0, 0) and fit == np.inf and rob == -1 and aic == -np.inf
     X = np.abs(np.random.default_rng(1).standard_normal((8, 6))).astype(np.float32)
     r1 = NMFk.execute(X, 2, 3, casefilename="case", resultdir=str(tmp_path), quiet=True, seed=1, maxiter=30)
-    assert os.path.isfile(tmp_path / "case_8_6_2_3.npz")
+    assert os.path.isfile(tmp_path / "case_8_6_2_3.jld")  # the reference's file name AND format (Exec:265, 323-327)
+    from nmfk_jl_amd import resultio
+
+    z = resultio.load(str(tmp_path / "case_8_6_2_3.jld"))
+    assert set(z) == {"W", "H", "fit", "robustness", "aic"} and z["W"].shape == (8, 2) and z["W"].dtype == np.float32
     r2 = NMFk.execute(X, 2, 3, casefilename="case", resultdir=str(tmp_path), quiet=True, seed=999, maxiter=30)
     np.testing.assert_array_equal(r1[0], r2[0])  # second call is served from the cache
     # X sidecar (check_x_hash!, Exec:68-93): written on the first call, a different X of the same shape warns
-    assert os.path.isfile(tmp_path / "case_x_matrix_8_6.npz.sha256")
+    assert os.path.isfile(tmp_path / "case_x_matrix_8_6.jld.sha256")
     with pytest.warns(UserWarning, match="hash mismatch"):
         with pytest.warns(UserWarning, match="Fit quality is not consistent"):  # Exec:274-283: new fit, re-saved
             r3 = NMFk.execute(X + 1, 2, 3, casefilename="case", resultdir=str(tmp_path), quiet=True, seed=1, maxiter=30)
     assert r3[2] != r1[2]
-    with np.load(tmp_path / "case_8_6_2_3.npz") as z:
-        assert float(z["fit"]) == float(r3[2])
+    assert float(resultio.load(str(tmp_path / "case_8_6_2_3.jld"))["fit"]) == float(r3[2])
     # old file-name convention (Exec:266-269)
-    os.replace(tmp_path / "case_8_6_2_3.npz", tmp_path / "case-2-3.npz")
+    os.replace(tmp_path / "case_8_6_2_3.jld", tmp_path / "case-2-3.jld")
     with pytest.warns(UserWarning):
         r4 = NMFk.execute(X + 1, 2, 3, casefilename="case", resultdir=str(tmp_path), quiet=True, seed=5, maxiter=30)
     np.testing.assert_array_equal(r4[0], r3[0])
+
+
+def test_saveall_loadall_payload(NMFk, oracle, tmp_path):
+    """Exec:499-509, 650-654: `saveall` writes the -all.jld payload with the reference's 12 variables; `loadall` then
+    serves the restarts from it (no new run: a different seed gives the same answer)."""
+    from nmfk_jl_amd import resultio
+
+    X = np.abs(np.random.default_rng(7).standard_normal((20, 9))).astype(np.float32)
+    a = NMFk.execute_run(X, 3, 5, seed=2, maxiter=60, saveall=True, casefilename="sv", resultdir=str(tmp_path), **NOSTOP)
+    fn = tmp_path / "sv_20_9_3_5-all.jld"
+    assert os.path.isfile(fn)
+    z = resultio.load(str(fn))
+    assert list(z) == ["W", "H", "Wmean", "Hmean", "Wvar", "Hvar", "Wbest", "Hbest", "fit", "Cluster Silhouettes",
+                       "Cluster assignments", "Cluster centroids"]
+    assert len(z["W"]) == 5 and z["W"][0].shape == (20, 3) and z["H"][0].shape == (3, 9) and z["fit"].shape == (5,)
+    assert z["Cluster assignments"].shape == (3, 5) and z["Cluster assignments"].dtype == np.int64
+    np.testing.assert_array_equal(z["Wbest"], a[0])
+    np.testing.assert_allclose(z["Hmean"].sum(axis=1), 1.0, atol=1e-3)
+    with pytest.warns(UserWarning, match="missing"):
+        NMFk.execute_run(X, 2, 5, seed=2, maxiter=10, loadall=True, casefilename="sv", resultdir=str(tmp_path), **NOSTOP)
+    b = NMFk.execute_run(X, 3, 5, seed=12345, maxiter=1, loadall=True, casefilename="sv", resultdir=str(tmp_path), **NOSTOP)
+    np.testing.assert_array_equal(b[0], a[0])
+    assert b[2] == a[2] and b[3] == a[3]
+    with pytest.raises(NameError):  # the reference dies with UndefVarError(clustersilhouettes) for nk = 1
+        NMFk.execute_run(X, 1, 2, seed=2, maxiter=10, saveall=True, casefilename="sv", resultdir=str(tmp_path), **NOSTOP)
+
+
+def test_execute_options_overloads_and_warnings(NMFk, tmp_path):
+    """ExecuteOptions (Exec:15-65) forwards its fields; zero rows / columns warn once per session (Mult:8-15); a scalar
+    weight makes the per-run objective check of Exec:602-607 speak."""
+    import nmfk_jl_amd.execute as E
+
+    X = np.abs(np.random.default_rng(3).standard_normal((12, 6))).astype(np.float32)
+    opts = NMFk.ExecuteOptions(load=False, save=False, quiet=True, cutoff=0.9)
+    a = NMFk.execute(X, range(2, 4), 4, opts, seed=3, maxiter=40)
+    b = NMFk.execute(X, range(2, 4), 4, load=False, save=False, quiet=True, cutoff=0.9, seed=3, maxiter=40)
+    assert a[5] == b[5]
+    np.testing.assert_array_equal(a[0][1], b[0][1])
+    w1 = NMFk.execute(X, 2, 4, NMFk.ExecuteOptions(load=False, save=False, quiet=True, ordersignals=False), seed=3, maxiter=40)
+    assert len(w1) == 5 and w1[0].shape == (12, 2)
+    Xz = X.copy()
+    Xz[3, :] = 0
+    Xz[:, 2] = 0
+    E._first_warning = True
+    with pytest.warns(UserWarning) as rec:
+        NMFk.execute(Xz, 2, 2, load=False, save=False, quiet=True, seed=1, maxiter=10)
+    msgs = [str(r.message) for r in rec]
+    assert any("in a row should not be 0" in t for t in msgs) and any("in a column should not be 0" in t for t in msgs)
+    import warnings as _w
+
+    with _w.catch_warnings(record=True) as rec2:  # second call: silent (first_warning is false now)
+        _w.simplefilter("always")
+        NMFk.execute(Xz, 2, 2, load=False, save=False, quiet=True, seed=1, maxiter=10)
+    assert not [r for r in rec2 if "should not be 0" in str(r.message)]
+    with pytest.warns(UserWarning, match="is very different"):
+        NMFk.execute_run(X, 2, 2, seed=1, maxiter=20, weight=2.0)
 
 
 def test_planted_rank_kopt_matches_oracle_fp32(NMFk, oracle):
@@ -861,7 +920,7 @@ def test_robustkmeans_krange_and_cache(NMFk, ctx, oracle, tmp_path):
     assert got["k"] == kbest and np.array_equal(got["assignments"], best["assignments"])
     assert abs(got["worst_silhouette"] - best["worst_silhouette"]) < 1e-6
     assert NMFk.robustkmeans(X[:, :2], [2, 3], 5, ctx=ctx) is None
-    # result cache (Clus:173-199, 236-244; .npz payload)
+    # result cache (Clus:173-199, 236-244; .npz payload: the reference stores a KmeansResult struct, which is not written here)
     r1, s1 = NMFk.robustkmeans(X, 3, 10, ctx=ctx, save=True, resultdir=str(tmp_path), casefilename="Hmatrix",
                                compute_silhouettes_flag=True)
     assert os.path.isfile(tmp_path / "Hmatrix-3-5_60-10.npz")

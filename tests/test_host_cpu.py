@@ -111,7 +111,7 @@ def test_x_hash_sidecar(NMFk, tmp_path):
     from nmfk_jl_amd.execute import check_x_hash, hash_sha256_hex
 
     X = np.arange(12, dtype=np.float32).reshape(3, 4)
-    xf = str(tmp_path / "c_x_matrix_3_4.npz")
+    xf = str(tmp_path / "c_x_matrix_3_4.jld")
     h = check_x_hash(X, xf)
     assert open(xf + ".sha256").read().strip() == h == hash_sha256_hex(np.asfortranarray(X))
     with warnings.catch_warnings():
@@ -157,7 +157,7 @@ def test_julia_shim_binds_the_declared_c_abi():
     jl = open(os.path.join(root, "julia", "NMFkHIP.jl")).read()
     lib = ctypes.CDLL(os.path.join(root, "nmfk.jl_amd", "libnmfk_hip.so"))
     calls = list(re.finditer(r"ccall\(\(:(\w+),\s*libnmfk\),\s*(\w+),\s*\(", jl))
-    assert len(calls) >= 8
+    assert len(calls) >= 14 and {"nmfk_multi_create", "nmfk_multi_set_X", "nmfk_multi_sweep", "nmfk_mu_sweep"} <= {c.group(1) for c in calls}
     for mm in calls:
         name = mm.group(1)
         assert name in protos, f"{name} is not declared in include/nmfk_hip.h"
@@ -181,6 +181,108 @@ def test_julia_shim_binds_the_declared_c_abi():
                 assert jt in ("Cdouble", "Float64"), (name, jt, ca)
             elif re.search(r"\bint\b", ca):
                 assert jt in ("Cint", "Int32"), (name, jt, ca)
+
+
+def _julia_function_kwargs(jl, head):
+    """keyword names of the Julia method whose definition starts with `head` (text up to the closing parenthesis)"""
+    import re
+
+    i = jl.index(head)
+    j, depth = jl.index("(", i), 0
+    k = j
+    while True:
+        depth += {"(": 1, ")": -1}.get(jl[k], 0)
+        k += 1
+        if depth == 0:
+            break
+    sig = jl[j + 1:k - 1]
+    if ";" not in sig:
+        return []
+    parts = _split_top(sig[sig.index(";") + 1:])
+    return [re.match(r"\s*(\w+)", q).group(1) for q in parts if q.strip() and not q.strip().endswith("...")]
+
+
+def test_julia_shim_accepts_every_keyword_of_the_reference_signatures():
+    """the keyword arguments of execute (range / single k), execute_run, execute_singlerun_compute and
+    NMFmultiplicative that reach this path, by NAME (tests/golden/reference_kwargs.json, extracted from the reference
+    by tests/golden/make_reference_kwargs.py; re-extracted and compared when /root/reference is present)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fix = os.path.join(root, "tests", "golden", "reference_kwargs.json")
+    ref = json.load(open(fix))
+    if os.path.isdir("/root/reference/src"):
+        out = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_reference_kwargs.py")],
+                             capture_output=True, text=True, check=True).stdout
+        assert json.loads(out) == ref, "tests/golden/reference_kwargs.json is stale"
+    jl = open(os.path.join(root, "julia", "NMFkHIP.jl")).read()
+    rng = _julia_function_kwargs(jl, "function execute(X::AbstractArray{T,N}, nkrange::Union{Vector{Int},AbstractUnitRange{Int}}, nNMF::Integer=10;")
+    one = _julia_function_kwargs(jl, "function execute(X::AbstractArray{T,N}, nk::Integer, nNMF::Integer=10;")
+    run = _julia_function_kwargs(jl, "function execute_run(X::AbstractMatrix{T}, nk::Int, nNMF::Int;")
+    many = _julia_function_kwargs(jl, "function execute_many(")
+    assert set(ref["execute_range"]) <= set(rng), set(ref["execute_range"]) - set(rng)
+    assert set(ref["execute_single"]) <= set(one), set(ref["execute_single"]) - set(one)
+    assert set(ref["execute_run"]) <= set(run), set(ref["execute_run"]) - set(run)
+    # defaults that decide behaviour: the cache is ON by default, like the reference (Exec:178, 236)
+    assert "load::Bool=true, save::Bool=true" in jl.replace("\n", " ").replace("\t", "")
+    # execute() forwards execute_run's keywords through execute_many (Exec:304 forwards kw...)
+    for name in ("acceptratio", "acceptfactor", "best", "nanaction", "loadall", "saveall", "weight", "veryquiet"):
+        assert name in many, name
+    # keywords consumed deeper down (Exec:729, Mult:24): peeled out of kw... by name
+    consumed = {"tol", "tolOF", "lambda", "maxreattempts", "maxbaditers", "maxiter", "stopconv", "Wfixed", "Hfixed", "Winit", "Hinit",
+                "seed", "normalizevector", "weight", "quiet"}
+    assert consumed <= set(ref["NMFmultiplicative"]) | {"quiet"}
+    for name in consumed - {"weight", "quiet"}:
+        assert (":" + name) in jl, f"NMFmultiplicative keyword {name} is not handled by the shim"
+    # the rest of execute_singlerun_compute's keywords select other solvers / options that default to off and are
+    # rejected loudly or meaningless here
+    for name in ("transpose", "deltas", "ratios", "mixture"):
+        assert name in run
+    assert set(ref["ExecuteOptions"]) == set(_struct_fields(jl, "Base.@kwdef struct ExecuteOptions"))
+    # exception types of the reference on this path
+    for needle in ('throw(ArgumentError("NMFk analysis can be executed for matrices!"))', "throw(ErrorException(msg))",
+                   'error("Input array has a zero dimension!', "@assert size(Winit) == (n, nk)",
+                   'error("Initial values for the W matrix entries include NaNs!")'):
+        assert needle in jl, needle
+    # and the Python mirror accepts the same names
+    import inspect
+
+    import nmfk_jl_amd as NMFk
+
+    py = set(inspect.signature(NMFk.execute).parameters)
+    assert set(ref["execute_range"]) - {"dims"} <= py and set(ref["execute_single"]) - {"dims"} <= py
+    assert set(ref["ExecuteOptions"]) == {f.name for f in __import__("dataclasses").fields(NMFk.ExecuteOptions)}
+
+
+def _struct_fields(jl, head):
+    import re
+
+    body = jl[jl.index(head):]
+    body = body[body.index("\n") + 1:body.index("\nend")]
+    return [re.match(r"\s*(\w+)", l).group(1) for l in body.split("\n") if l.strip()]
+
+
+def test_shard_plan_matches_the_python_plan():
+    """nmfk_shard_plan (C ABI, host arithmetic) against parallel.plan_shards: every restart owned exactly once, rank g
+    owns {g, g + N, ...}, every shard padded to ceil(nruns / N)."""
+    import nmfk_jl_amd as NMFk
+    from nmfk_jl_amd import _lib
+
+    for nruns in (1, 2, 5, 8, 32, 33):
+        for world in (1, 2, 3, 8):
+            c, chunks = NMFk.parallel.plan_shards([2, 3], nruns, world)
+            seen = []
+            for g in range(world):
+                cnt, pad = _lib.shard_plan(nruns, world, g)
+                assert pad == c
+                mine = [rs for q, rs, gg in chunks if gg == g and q == 0]
+                assert cnt == (len(mine[0]) if mine else 0)
+                seen += list(range(g, nruns, world))[:cnt]
+            assert sorted(seen) == list(range(nruns))
+    with pytest.raises(NMFk.NMFkError):
+        _lib.shard_plan(4, 2, 2)
 
 
 def test_three_term_bf16_split_is_fp32_accurate():

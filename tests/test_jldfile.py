@@ -1,0 +1,99 @@
+"""nmfk.jl_amd/jldfile.py against JLD files written by Julia itself (tests/golden/julia_written_*.jld) and in round trips."""
+import os
+
+import numpy as np
+import pytest
+
+from nmfk_jl_amd import jldfile, resultio  # noqa: E402  (conftest puts the repository root on sys.path)
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_reads_julia_written_files():
+    for name, n in (("julia_written_Hmatrix-2-2_10-1000.jld", 10), ("julia_written_Wmatrix-4-4_100-1000.jld", 100)):
+        path = os.path.join(GOLD, name)
+        assert open(path, "rb").read(len(jldfile.MAGIC)) == jldfile.MAGIC
+        root, R = jldfile.read_structure(path)
+        top = root["children"]
+        assert {"assignments", "best_silhouettes", "_creator", "_types", "_refs"} <= set(top)
+        cr = {k: int(v["value"]) for k, v in top["_creator"]["children"].items()}
+        assert cr["WORD_SIZE"] == 64 and cr["ENDIAN_BOM"] == 0x04030201 and cr["JULIA_MAJOR"] == 1
+        sil = top["best_silhouettes"]["value"]
+        assert sil.dtype == np.float64 and sil.shape == (n,) and np.all(np.abs(sil) <= 1)
+        tag = top["_types"]["children"]["00000001"]["attrs"]["julia type"]
+        assert tag.startswith("Clustering.KmeansResult{Core.Array{Core.Float64,2}")
+        km = top["assignments"]["value"]  # the KmeansResult struct: references into /_refs
+        byhdr = {c["header"]: c for c in top["_refs"]["children"].values()}
+        assign = byhdr[km["assignments_"][0]]["value"]
+        k = int(name.split("-")[1])
+        assert assign.shape == (n,) and set(assign) <= set(range(1, k + 1))
+        centers = byhdr[km["centers_"][0]]["value"]
+        assert centers.ndim == 2 and centers.shape[1] == k  # d x k, Julia's column-major order kept
+        assert km["iterations_"] >= 1 and km["converged_"] in (0, 1)
+        flat = jldfile.load(path)
+        assert "best_silhouettes" in flat and "_creator" not in flat
+
+
+def _messages(R, node):
+    return [(t, bytes(b)) for t, b in R.messages(node["header"])]
+
+
+def test_writer_uses_the_structures_julia_writes(tmp_path):
+    """A Float64 vector written here carries the same message types as Julia's `best_silhouettes`, with byte-identical
+    dataspace and datatype messages; groups are link-message groups like Julia's; the user block carries the JLD magic."""
+    ref_root, Rr = jldfile.read_structure(os.path.join(GOLD, "julia_written_Hmatrix-2-2_10-1000.jld"))
+    sil = ref_root["children"]["best_silhouettes"]
+    fn = str(tmp_path / "x.jld")
+    jldfile.save(fn, {"best_silhouettes": sil["value"], "n": np.int64(64)})
+    root, R = jldfile.read_structure(fn)
+    mine, theirs = _messages(R, root["children"]["best_silhouettes"]), _messages(Rr, sil)
+    strip = lambda ms: [(t, b) for t, b in ms if t != 0]  # Julia's headers are padded with NIL messages
+    assert [t for t, _ in strip(mine)] == [t for t, _ in strip(theirs)] == [0x0001, 0x0003, 0x0005, 0x0008, 0x0012]
+    for i in (0, 1, 2):  # dataspace, datatype, fill value: byte for byte
+        assert strip(mine)[i][1] == strip(theirs)[i][1]
+    assert strip(mine)[3][1][:4] == strip(theirs)[3][1][:4]  # layout: version 3, compact, 80 bytes
+    np.testing.assert_array_equal(root["children"]["best_silhouettes"]["value"], sil["value"])
+    word = ref_root["children"]["_creator"]["children"]["WORD_SIZE"]
+    assert strip(_messages(R, root["children"]["n"]))[1][1] == strip(_messages(Rr, word))[1][1]  # Int64 datatype message
+    kinds = lambda RR, node: sorted({t for t, _ in RR.messages(node["header"])} - {0, 0x10})
+    assert kinds(R, root) == kinds(Rr, ref_root) == [0x0002, 0x0006, 0x000A]
+    assert open(fn, "rb").read(512).startswith(jldfile.MAGIC) and open(fn, "rb").read()[512:520] == jldfile.SIG
+
+
+@pytest.mark.parametrize("n,m,k", [(15, 5, 3), (3000, 512, 16)])
+def test_result_file_roundtrip(tmp_path, n, m, k):
+    rng = np.random.default_rng(1)
+    W, H = rng.random((n, k), dtype=np.float32), rng.random((k, m), dtype=np.float32)
+    fn = str(tmp_path / f"case_{n}_{m}_{k}_10.jld")
+    resultio.save(fn, W=W, H=H, fit=np.float32(1.25), robustness=np.float32(0.5), aic=np.float32(-3.0))
+    z = resultio.load(fn)
+    assert set(z) == {"W", "H", "fit", "robustness", "aic"}  # the keys of src/NMFkExecute.jl:325
+    np.testing.assert_array_equal(z["W"], W)
+    np.testing.assert_array_equal(z["H"], H)
+    assert z["W"].dtype == np.float32 and float(z["fit"]) == 1.25 and float(z["aic"]) == -3.0
+    root, _ = jldfile.read_structure(fn)
+    assert root["children"]["W"]["shape"] == (k, n)  # HDF5 dimensions = Julia's reversed
+    assert not [f for f in os.listdir(tmp_path) if ".tmp" in f]
+
+
+def test_all_payload_roundtrip(tmp_path):
+    """the 12 variables of the -all.jld payload (src/NMFkExecute.jl:652), Vector{Matrix} as reference datasets"""
+    rng = np.random.default_rng(2)
+    R, n, m, k = 4, 20, 6, 3
+    Ws, Hs = [rng.random((n, k), dtype=np.float32) for _ in range(R)], [rng.random((k, m), dtype=np.float32) for _ in range(R)]
+    payload = {"W": Ws, "H": Hs, "Wmean": Ws[0], "Hmean": Hs[0], "Wvar": Ws[1], "Hvar": Hs[1], "Wbest": Ws[2], "Hbest": Hs[2],
+               "fit": np.arange(R, dtype=np.float32), "Cluster Silhouettes": np.ones(k, np.float32),
+               "Cluster assignments": np.tile(np.arange(1, k + 1, dtype=np.int64)[:, None], (1, R)),
+               "Cluster centroids": Hs[3]}
+    fn = str(tmp_path / "c-all.jld")
+    resultio.save(fn, **payload)
+    z = resultio.load(fn)
+    assert list(z) == list(payload)
+    for a, b in zip(z["W"], Ws):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(z["Cluster assignments"], payload["Cluster assignments"])
+    root, _ = jldfile.read_structure(fn)
+    assert root["children"]["W"]["attrs"]["julia type"] == "Core.Array{Core.Array{Core.Float32,2},1}"
+    assert len(root["children"]["_refs"]["children"]) == 2 * R
+    w, h, f = resultio.load(fn, "W", "H", "fit").values()  # JLD.load(filename, "W", "H", "fit") of Exec:503
+    assert len(w) == R and f.shape == (R,)

@@ -585,7 +585,14 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   };
   const int max_ws = T.max_wsplit;
   // phases of a two-phase sweep run one after the other, so each gets the geometry that fills the chip with ITS units
-  auto phase_of_k = [&](int k) { return hyb_phases && !use_hyb_k(k) ? 1 : 0; };
+  // Merged sweeps with a group on the split-operand MFMA kernel are phased too: the matrix-pipe groups first (that
+  // group and the ranks > 16), then the merged packed-VALU group.  Reason: packed-VALU results were seen to change
+  // (~1e-5 relative, run to run) while the MFMA group's objective kernel ran on the same CUs from another stream; the
+  // cause was not found ("Known hazard"), so kernels of the two kinds never share the GPU inside a sweep.
+  bool any_hyb_k = false;
+  for (int q = 0; q < nk; ++q) any_hyb_k = any_hyb_k || use_hyb_k(ks[q]);
+  const bool phased = hyb_phases || (merge > 0 && any_hyb_k);
+  auto phase_of_k = [&](int k) { return phased && !use_hyb_k(k) && !(merge > 0 && use_wide_k(k)) ? 1 : 0; };
   auto geometry = [&](int L, int D, int phase) {
     Geo g;
     auto wgs = [&](int ws) {  // workgroups of one half-step over all units of the phase
@@ -612,8 +619,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         g.slots = std::max(g.slots, (L + lane_tile(ks[q], g.wsplit) - 1) / lane_tile(ks[q], g.wsplit));
     return g;
   };
-  Geo ghp[2] = {geometry(m, n, 0), geometry(m, n, hyb_phases ? 1 : 0)};
-  Geo gwp[2] = {geometry(n, m, 0), geometry(n, m, hyb_phases ? 1 : 0)};
+  Geo ghp[2] = {geometry(m, n, 0), geometry(m, n, phased ? 1 : 0)};
+  Geo gwp[2] = {geometry(n, m, 0), geometry(n, m, phased ? 1 : 0)};
   if (ctx->sparse) {  // gather kernels: one lane element per thread, always finished in-kernel
     ghp[0] = ghp[1] = Geo{1, 1, n, 1, (m + NMFK_TILE - 1) / NMFK_TILE};
     gwp[0] = gwp[1] = Geo{1, 1, m, 1, (n + NMFK_TILE - 1) / NMFK_TILE};
@@ -648,7 +655,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     const int q = order[oi], k = ks[q];
     if (merge > 0 && k <= NMFK_MULTI_MAXK) continue;
     if (hyb_phases && use_hyb_k(k)) continue;
-    groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns, use_hyb_k(k) ? (k <= 8 ? 8 : 16) : 0, hyb_phases ? 1 : 0});
+    groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns, use_hyb_k(k) ? (k <= 8 ? 8 : 16) : 0, phase_of_k(k)});
     for (int r = 0; r < nruns; ++r) ulist.push_back({q, r});
   }
   // merged sweeps: the ranks of the split-operand MFMA kernel (its cost does not depend on the rank, one instantiation
@@ -664,7 +671,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if (G.count > 0) groups.push_back(G);
   }
   for (int g = 0; g < merge; ++g) {
-    Group G{0, 0, (int)ulist.size(), 0, 0, 0};
+    Group G{0, 0, (int)ulist.size(), 0, 0, phased ? 1 : 0};
     for (int oi = 0; oi < nk; ++oi) {
       const int q = order[oi];
       if (ks[q] > NMFK_MULTI_MAXK || use_hyb_k(ks[q])) continue;

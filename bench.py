@@ -30,11 +30,11 @@ PEAK_HBM_GBPS = 8000.0
 
 
 def _pmc_traffic():
-    """HBM bytes per launch of the dominant kernel (hyb_step_kernel<16,2,8>, 256 factorizations per launch):
+    """HBM bytes per launch of the dominant kernel (hyb_step_kernel<16,2,8,false>, 256 factorizations per launch):
     FETCH_SIZE x 2 + WRITE_SIZE, collected in separate rocprofv3 --pmc runs of this command (scripts/profile_bench.sh,
-    scripts/make_traffic.py -> profiles/r01/traffic.json); None if absent."""
+    scripts/make_traffic.py -> profiles/r02/traffic.json); None if absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r02", "traffic.json")) as fh:
             t = json.load(fh)
         return float(t["hbm_bytes_per_launch"])
     except Exception:
@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--compute", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-kopt-check", action="store_true", help="skip the planted-matrix 'same kopt' sweeps after the timed region")
     args = ap.parse_args()
 
     import torch
@@ -200,7 +201,7 @@ def main():
                 h, w = prof["h_step<mfma>"], prof["w_step<mfma>"]
                 tfd = (h["flops"] + w["flops"]) / ((h["ms"] + w["ms"]) * 1e-3) / 1e12
                 line["roofline"] = {
-                    "kernel": "hyb_step_kernel<16,2,8> (nmfk_step_hyb.hip): H and W half-step launches of the mixed-rank group "
+                    "kernel": "hyb_step_kernel<16,2,8,false> (nmfk_step_hyb.hip): H and W half-step launches of the mixed-rank group "
                               "(ranks 9..16 x 32 restarts = 256 factorizations per launch), alone on the GPU in phase 1 of the sweep",
                     "bound": "mfma", "achieved": tfd, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tfd / PEAK_FP32_TFLOPS,
                     "traffic": _pmc_traffic(),
@@ -213,7 +214,10 @@ def main():
                             "(fp32-accurate) and the numerators on the fp32 matrix pipe; the peak quoted is the fp32 MFMA = "
                             "fp32 vector peak of gfx950. The other ranks (2..8) run afterwards on step_kernel<KP> (packed "
                             "fp32 FMAs, concurrent streams); X is L2/Infinity-Cache resident, HBM is not the bound.",
-                    "hbm_algorithmic_GBps": xbytes / (loop["ms"] * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
+                    "x_GBps_if_every_restart_streamed_X": xbytes / (loop["ms"] * 1e-3) / 1e9,
+                    "x_GBps_note": "SURVEY 8d's 2*n*m*4 B per restart and iteration over the MU-loop time: an ON-DIE figure "
+                                   "(L2 / Infinity Cache serve X to the restarts of a launch), NOT HBM traffic and not to be "
+                                   "read against the 8 TB/s HBM peak; `traffic` is the measured HBM bytes per launch",
                 }
             else:
                 line["roofline"] = {
@@ -226,8 +230,26 @@ def main():
                             "MFMAs. The rank groups run concurrently, so a launch's duration is not exclusive GPU time and the "
                             "fraction is the aggregate over the MU loop. HBM view: X is L2/Infinity-Cache resident "
                             "(2 x 16.8 MB), so the algorithmic X bytes below are served on-die, not by HBM.",
-                    "hbm_algorithmic_GBps": xbytes / (loop["ms"] * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
+                    "x_GBps_if_every_restart_streamed_X": xbytes / (loop["ms"] * 1e-3) / 1e9,
+                    "x_GBps_note": "on-die figure (L2 / Infinity Cache), not HBM traffic",
                 }
+        if not args.no_kopt_check and world == 1 and (args.n, args.m, args.kmin, args.kmax, args.nruns) == (8192, 512, 2, 16, 32):
+            # "same kopt" half of the metric, outside the timed region: SURVEY 8d's planted rank-6 matrix through the same
+            # sweep in fp32 (the product) and in fp64 compute (the reference's arithmetic and stop decisions,
+            # oracle-verified by tests/test_gpu_parity.py::test_stop_rule_fp64_identical_iterations)
+            k0 = 6
+            W0 = ctx.fill_uniform(2, 0, args.n * k0).reshape(k0, args.n).T.astype(np.float64)
+            H0 = ctx.fill_uniform(2, args.n * k0, k0 * args.m).reshape(args.m, k0).T.astype(np.float64)
+            U = ctx.fill_uniform(2, args.n * k0 + k0 * args.m, args.n * args.m).reshape(args.m, args.n).T.astype(np.float64)
+            Xp = np.asfortranarray((W0 @ H0 + 0.01 * U).astype(np.float32))
+            ctx.set_profiling(False)
+            ctx.set_X(Xp)
+            kp32 = NMFk.execute(Xp, ks, args.nruns, load=False, save=False, quiet=True, seed=2, ctx=ctx)[5]
+            kp64 = NMFk.execute(Xp, ks, args.nruns, load=False, save=False, quiet=True, seed=2, ctx=ctx, compute="f64")[5]
+            line["config"]["kopt_planted"] = kp32
+            line["config"]["kopt_planted_f64_mode"] = kp64
+            line["config"]["kopt_planted_expected"] = k0
+            ctx.set_X(X)
         if not args.no_cpu_baseline:
             threads = min(32, len(os.sched_getaffinity(0)))
             line["cpu_baseline"] = cpu_baseline(X, ks, args.nruns, iters_by_k, threads)

@@ -103,9 +103,10 @@ struct Sampler {
 //   NMFK_MAX_WSPLIT   4 / 8: waves of a workgroup that may split a loop range
 //   NMFK_MFMA_SSE, NMFK_HYB_SSE   0: monitored objective of the MFMA groups on the packed-VALU objective kernel
 //   NMFK_STREAMS      concurrent rank-group streams (8);  NMFK_HOST_TIMING=1 prints the host's share of the loop
+//   NMFK_MERGE_PHASED 0: merged sweeps run their matrix-pipe groups and the packed-VALU group side by side again
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, hyb_groups = 1, merge = -1, phases = -1, max_wsplit = 8;
-  int wide_sse = 1, hyb_sse = 1, streams = 8, host_timing = 0;
+  int wide_sse = 1, hyb_sse = 1, streams = 8, host_timing = 0, merge_phased = 1;
 };
 Tuning read_tuning() {
   Tuning t;
@@ -128,6 +129,7 @@ Tuning read_tuning() {
   geti("NMFK_STREAMS", t.streams);
   t.streams = std::max(1, std::min(64, t.streams));
   geti("NMFK_HOST_TIMING", t.host_timing);
+  geti("NMFK_MERGE_PHASED", t.merge_phased);
   return t;
 }
 
@@ -522,8 +524,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   auto use_wide_k = [&](int k) { return wide_ok && k > 16; };
   // Ranks in [hyb_mink, 16]: split-operand MFMA half-step (nmfk_step_hyb.hip).  Its cost does not depend on the rank
   // and ONE instantiation serves all ranks, so its units share one launch group.  Two schedules use it:
-  //  * few restarts per rank (<= 8; a rank's share at 4-8 GPUs): a merged sweep, the ranks >= 6 as one group on it
-  //    beside one merged packed-VALU group of the small ranks (per-rank launches would be launch-bound);
+  //  * few restarts per rank (<= 8; a rank's share at 4-8 GPUs): a merged sweep, the ranks >= 6 as one group on it,
+  //    then one merged packed-VALU group of the small ranks (per-rank launches would be launch-bound); with <= 4
+  //    restarts every rank 2..16 joins the group and no packed-VALU launch is left;
   //  * many restarts per rank: a TWO-PHASE sweep -- the ranks >= k0 run FIRST, as one group with the GPU to themselves
   //    (its fp32 MFMAs and the packed FMAs of the other ranks' kernels share the multipliers, so the two kinds must not
   //    run side by side), then the other ranks on their per-rank packed-VALU launches.
@@ -550,7 +553,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     const double k0 = 8.8 + (wg_ns / Erel - 8.5 * 34.0) / 324.0;     // break-even rank (8.8 at 8192 x 512)
     // first rank of the group: the break-even (9 at the reference shape, also with 16 restarts per rank: 206 vs 216 ms
     // per 200 iterations; 2048 x 2048: 180 vs 294), 6 in merged sweeps
-    const int mk = hyb_mink >= 0 ? hyb_mink : (nruns <= 8 ? 6 : std::min(16, (int)ceil(k0)));
+    // (<= 4 restarts per rank, a rank's share at 8 GPUs: ALL ranks 2..16 on the group, one phase and no packed-VALU
+    // launches at all -- 124 vs 140 ms per 400 iterations at k = 2:16; with 8 restarts the two are level, 230 vs 226)
+    const int mk = hyb_mink >= 0 ? hyb_mink : (nruns <= 4 ? 2 : nruns <= 8 ? 6 : std::min(16, (int)ceil(k0)));
     int hyb_units = 0;
     double hyb_score = 0;  // what the group saves, in rank-restarts (a packed-VALU unit costs ~k, a unit of the group ~k0)
     for (int q = 0; q < nk; ++q)
@@ -591,7 +596,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // cause was not found ("Known hazard"), so kernels of the two kinds never share the GPU inside a sweep.
   bool any_hyb_k = false;
   for (int q = 0; q < nk; ++q) any_hyb_k = any_hyb_k || use_hyb_k(ks[q]);
-  const bool phased = hyb_phases || (merge > 0 && any_hyb_k);
+  const bool phased = hyb_phases || (merge > 0 && any_hyb_k && T.merge_phased);
   auto phase_of_k = [&](int k) { return phased && !use_hyb_k(k) && !(merge > 0 && use_wide_k(k)) ? 1 : 0; };
   auto geometry = [&](int L, int D, int phase) {
     Geo g;

@@ -341,17 +341,21 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
     constexpr int TRIP = 2 * CPB > 4 ? 2 * CPB : 4;
     const int fofs = c16 * ST::RS + 16 * (g & SUBMASK), nofs = ST::BFB + min(c16, KS - 1) * ST::FRS + g * 16;
     if (nchunks <= 0) return;
-    float sv[ST::NI][2];
-    int svrow;
+    // staging registers of TWO blocks: the rows of block b + 2 are requested at the start of block b and written to LDS
+    // during block b + 1 -- a whole block of latency even when a block is a single chunk (per-wave staging), where a
+    // request made and consumed within one chunk exposed the latency of the loop factor's rows (they come from beyond L2)
+    float sv[2][ST::NI][2];
+    int svrow[2];
     f32x4_t xr[4][NT];
     const int dlast = d0 + 16 * (nchunks - 1);
-    stage.load(d0, sv, svrow);
+    stage.load(d0, sv[0], svrow[0]);
     xload(d0, xr[0]);
     xload(min(d0 + 16, dlast), xr[1]);
-    stage.write(sb, sv, svrow);
+    if (nchunks > CPB) stage.load(d0 + 16 * CPB, sv[1], svrow[1]);
+    stage.write(sb, sv[0], svrow[0]);
     barrier();
-    // one trip; FULLT: every chunk of the trip exists, every block of it has a successor and no chunk touches the end
-    // of the loop range -> no guards in the unrolled body
+    // one trip; FULLT: every chunk of the trip exists, every block of it has a successor after next and no chunk touches
+    // the end of the loop range -> no guards in the unrolled body
     auto trip = [&](int c0, auto full_tag) __attribute__((always_inline)) {
       constexpr bool FULLT = decltype(full_tag)::value;
 #pragma unroll
@@ -359,15 +363,16 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
         const int c = c0 + ci;
         if (!FULLT && c >= nchunks) break;
         const int dch = d0 + 16 * c;
-        const int buf = (ci / CPB) & 1, ch = ci % CPB;
-        const bool more = FULLT || (c - ch + CPB < nchunks);  // a block follows the one this chunk belongs to
+        const int buf = (ci / CPB) & 1, ch = ci % CPB;  // block parity (trips hold an even number of blocks)
+        const bool more = FULLT || (c - ch + CPB < nchunks);       // a block follows the one this chunk belongs to
+        const bool more2 = FULLT || (c - ch + 2 * CPB < nchunks);  // and one after that
         xload(FULLT ? dch + 32 : min(dch + 32, dlast), xr[(ci + 2) & 3]);
-        // (vmcnt retires in order: issued AFTER this chunk's X prefetch, the rows of the next block -- they come from
-        // beyond L2 -- are not covered by the wait for X two chunks on, only by the one three chunks on)
-        if (ch == 0 && more) stage.load(dch + 16 * CPB, sv, svrow);
-        // the next block goes to the free LDS buffer BEFORE the block's last chunk, so that the conversion and the
-        // LDS writes overlap with that chunk's matrix work instead of sitting in front of the barrier
-        if (CPB > 1 && ch == CPB - 1 && more) stage.write(sb + (buf ^ 1) * ST::STB, sv, svrow);
+        // (vmcnt retires in order: the staging requests go out AFTER this chunk's X prefetch)
+        if (ch == 0 && more2) stage.load(dch + 32 * CPB, sv[buf], svrow[buf]);
+        // the next block (requested a block ago) goes to the free LDS buffer BEFORE this block's last chunk: conversion
+        // and LDS writes overlap with that chunk's matrix work instead of sitting in front of the barrier
+        const bool last_of_block = ch == CPB - 1 || (!FULLT && c == nchunks - 1);
+        if (last_of_block && more) stage.write(sb + (buf ^ 1) * ST::STB, sv[buf ^ 1], svrow[buf ^ 1]);
         __builtin_amdgcn_sched_barrier(0);  // loads stay in front of the arithmetic they overlap with
         {
           const char *b = sb + buf * ST::STB;
@@ -379,13 +384,10 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
           chunk(dch, xr[ci & 3], av, bn, !FULLT && dch + 16 > d1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ch == CPB - 1 || (!FULLT && c == nchunks - 1)) {  // end of a block
-          if (CPB == 1 && more) stage.write(sb + (buf ^ 1) * ST::STB, sv, svrow);
-          barrier();
-        }
+        if (last_of_block) barrier();
       }
     };
-    constexpr int AHEAD = CPB > 2 ? CPB : 2;
+    constexpr int AHEAD = 2 * CPB > 2 ? 2 * CPB : 2;
     int c0 = 0;
     for (; c0 + TRIP + AHEAD <= nchunks; c0 += TRIP) trip(c0, std::true_type());
     for (; c0 < nchunks; c0 += TRIP) trip(c0, std::false_type());

@@ -11,7 +11,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "hyb"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 A = NMFk.Context(0); A.set_X(X)
 B = NMFk.Context(0); B.set_X(X)
-ksA, R = [2, 3, 5], 4
+ksA, R = [int(v) for v in os.environ.get("KSA", "2,3,5").split(",")], 4
 seedsA = np.array([[NMFk.run_seed(11, k, r) for r in range(R)] for k in ksA], dtype=np.uint64)
 stop = False
 def burn():
@@ -21,14 +21,15 @@ def burn():
     env_iters = int(os.environ.get("BITERS", "40"))
     while not stop:
         B.mu_sweep(ksB, RB, seeds=seedsB, maxiter=env_iters, **NOSTOP)
-ref = A.mu_sweep(ksA, R, seeds=seedsA, maxiter=40, **NOSTOP)
+extra = dict(compute=NMFk.COMPUTE_F64) if os.environ.get("AF64") else {}
+ref = A.mu_sweep(ksA, R, seeds=seedsA, maxiter=40, **NOSTOP, **extra)
 for phase in ("alone", "with " + mode):
     th = None
     if phase != "alone":
         th = threading.Thread(target=burn); th.start(); time.sleep(0.2)
     bad = 0
     for i in range(reps):
-        res = A.mu_sweep(ksA, R, seeds=seedsA, maxiter=40, **NOSTOP)
+        res = A.mu_sweep(ksA, R, seeds=seedsA, maxiter=40, **NOSTOP, **extra)
         for k in ksA:
             if not ((res[k]["W"] == ref[k]["W"]).all() and (res[k]["H"] == ref[k]["H"]).all()):
                 bad += 1

@@ -314,16 +314,22 @@ def test_mfma_group_monitored_objective(NMFk, ctx, oracle):
     assert (w2["iters"] > 10).all()
 
 
-def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle):
-    """Sweeps with <= 4 restarts per rank (a rank's share at 8 GPUs): by default the ranks 6..16 run as ONE mixed-rank
-    launch group on the split-operand MFMA half-step, the smaller ranks on the merged packed-VALU kernel, wider ranks on
-    their own kernels.  Against the oracle (same tolerance as everywhere) and against the all-VALU grouping (NMFK_HYB=0)."""
+@pytest.mark.parametrize("R", [4, 8])
+def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle, R):
+    """Sweeps with <= 8 restarts per rank (a rank's share at 4-8 GPUs): by default the ranks kmin..16 run as ONE mixed-rank
+    launch group on the split-operand MFMA half-step (kmin = 2 up to 4 restarts, 6 above), smaller ranks on the merged
+    packed-VALU kernel in a second phase, wider ranks on their own kernels.  Against the oracle (same tolerance as
+    everywhere) and against the all-VALU grouping (NMFK_HYB=0)."""
     n, m = 700, 130
     X = (0.05 + oracle.uniform_fill(33, 0, n * m)).reshape(n, m).astype(np.float32)
     ctx.set_X(X)
-    ks, R, iters = [2, 3, 5, 6, 8, 13, 16, 20], 4, 40
+    ks, iters = [2, 3, 5, 6, 8, 13, 16, 20], 40
+    kmin = 2 if R <= 4 else 6
     seeds = _seeds(NMFk, 11, ks, R)
     a = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
+    info = ctx.last_sweep_info()
+    assert info["mfma_group_units"] == R * sum(kmin <= k <= 16 for k in ks), info
+    assert info["phases"] == (1 if kmin == 2 else 2) and info["merged_valu_groups"] == (0 if kmin == 2 else 1), info
     os.environ["NMFK_HYB"] = "0"
     try:
         b = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
@@ -333,13 +339,34 @@ def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle):
         for r in range(R):
             e = _rel(a[k]["W"][r] @ a[k]["H"][r], b[k]["W"][r] @ b[k]["H"][r], X)
             assert e <= 5e-6, (k, r, e)
-            if k < 6 or k > 16:
+            if k < kmin or k > 16:
                 assert e == 0.0  # not on the MFMA group: the same kernels in both runs
         W0, H0 = oracle.init_factors(int(seeds[q, 0]), n, m, k)
         ref = oracle.singlerun(X, k, W0, H0, maxiter=iters, **NOSTOP)
         assert _rel(a[k]["W"][0] @ a[k]["H"][0], ref["W"] @ ref["H"], X) <= 1e-4
         assert abs(a[k]["objvalue"][0] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
     assert max(_rel(a[13]["W"][r] @ a[13]["H"][r], b[13]["W"][r] @ b[13]["H"][r], X) for r in range(R)) > 0.0  # it did run
+
+
+def test_up_to_four_restarts_all_ranks_on_the_mfma_group(NMFk, ctx, oracle):
+    """Up to 4 restarts per rank (a rank's share at 8 GPUs): every rank 2..16 runs on the split-operand MFMA group in ONE
+    phase, no packed-VALU launch (nmfk_mu_sweep's rule); k = 1 and k > 16 keep their kernels.  Against the oracle."""
+    n, m = 700, 130
+    X = (0.05 + oracle.uniform_fill(35, 0, n * m)).reshape(n, m).astype(np.float32)
+    ctx.set_X(X)
+    for ks, R in (([2, 3, 4, 7, 12, 16], 2), ([2, 5, 9, 20], 1)):
+        iters = 40
+        seeds = _seeds(NMFk, 13, ks, R)
+        a = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
+        info = ctx.last_sweep_info()
+        assert info["mfma_group_units"] == R * sum(k <= 16 for k in ks) and info["merged_valu_groups"] == 0, info
+        assert info["phases"] == 1
+        for q, k in enumerate(ks):
+            for r in range(R):
+                W0, H0 = oracle.init_factors(int(seeds[q, r]), n, m, k)
+                ref = oracle.singlerun(X, k, W0, H0, maxiter=iters, **NOSTOP)
+                assert _rel(a[k]["W"][r] @ a[k]["H"][r], ref["W"] @ ref["H"], X) <= 1e-4, (k, r)
+                assert abs(a[k]["objvalue"][r] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
 
 
 @pytest.mark.parametrize("compute", ["f32", "f64"])
@@ -970,7 +997,7 @@ def test_merged_sweep_is_bitwise_reproducible_run_to_run(NMFk, oracle):
     n, m = 700, 130
     X = (0.05 + oracle.uniform_fill(33, 0, n * m)).reshape(n, m).astype(np.float32)
     ctx = NMFk.Context(0)
-    ks, R = [2, 3, 5, 6, 8, 13, 16, 20], 4
+    ks, R = [2, 3, 5, 6, 8, 13, 16, 20], 8
     seeds = _seeds(NMFk, 11, ks, R)
     ref = None
     for rep in range(30):

@@ -26,11 +26,11 @@
 namespace {
 
 void free_sparse(nmfk_ctx *ctx) {
-  void *ps[] = {ctx->colptr, ctx->rowidx, ctx->rowptr, ctx->colidx, ctx->vcsc, ctx->vcsr};
+  void *ps[] = {ctx->colptr, ctx->rowptr, ctx->rec_csc, ctx->rec_csr};
   for (void *q : ps)
     if (q) (void)hipFree(q);
-  ctx->colptr = ctx->rowidx = ctx->rowptr = ctx->colidx = nullptr;
-  ctx->vcsc = ctx->vcsr = nullptr;
+  ctx->colptr = ctx->rowptr = nullptr;
+  ctx->rec_csc = ctx->rec_csr = nullptr;
   ctx->sparse = false;
   ctx->nnz = 0;
 }
@@ -102,11 +102,11 @@ struct Sampler {
 //   NMFK_HYB_PHASES   0 / 1: force the one-phase / two-phase sweep
 //   NMFK_MAX_WSPLIT   4 / 8: waves of a workgroup that may split a loop range
 //   NMFK_MFMA_SSE, NMFK_HYB_SSE   0: monitored objective of the MFMA groups on the packed-VALU objective kernel
-//   NMFK_STREAMS      concurrent rank-group streams (8);  NMFK_HOST_TIMING=1 prints the host's share of the loop
+//   NMFK_STREAMS      concurrent rank-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1 prints the host's share of the loop
 //   NMFK_MERGE_PHASED 0: merged sweeps run their matrix-pipe groups and the packed-VALU group side by side again
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, hyb_groups = 1, merge = -1, phases = -1, max_wsplit = 8;
-  int wide_sse = 1, hyb_sse = 1, streams = 8, host_timing = 0, merge_phased = 1;
+  int wide_sse = 1, hyb_sse = 1, streams = -1, host_timing = 0, merge_phased = 1;
 };
 Tuning read_tuning() {
   Tuning t;
@@ -127,7 +127,7 @@ Tuning read_tuning() {
   geti("NMFK_MFMA_SSE", t.wide_sse);
   geti("NMFK_HYB_SSE", t.hyb_sse);
   geti("NMFK_STREAMS", t.streams);
-  t.streams = std::max(1, std::min(64, t.streams));
+  if (t.streams >= 0) t.streams = std::max(1, std::min(64, t.streams));
   geti("NMFK_HOST_TIMING", t.host_timing);
   geti("NMFK_MERGE_PHASED", t.merge_phased);
   return t;
@@ -318,17 +318,24 @@ NMFK_EXPORT int nmfk_set_X_csc(nmfk_ctx *ctx, int64_t n, int64_t m, int64_t nnz,
   const size_t nzs = (size_t)std::max<int64_t>(nz, 1);
   HIPCHECK(hipMalloc((void **)&ctx->colptr, sizeof(int32_t) * (m + 1)));
   HIPCHECK(hipMalloc((void **)&ctx->rowptr, sizeof(int32_t) * (n + 1)));
-  HIPCHECK(hipMalloc((void **)&ctx->rowidx, sizeof(int32_t) * nzs));
-  HIPCHECK(hipMalloc((void **)&ctx->colidx, sizeof(int32_t) * nzs));
-  HIPCHECK(hipMalloc((void **)&ctx->vcsc, sizeof(float) * nzs));
-  HIPCHECK(hipMalloc((void **)&ctx->vcsr, sizeof(float) * nzs));
+  HIPCHECK(hipMalloc((void **)&ctx->rec_csc, sizeof(int2) * nzs));
+  HIPCHECK(hipMalloc((void **)&ctx->rec_csr, sizeof(int2) * nzs));
+  HIPCHECK(hipMemset(ctx->rec_csc, 0, sizeof(int2) * nzs));
+  HIPCHECK(hipMemset(ctx->rec_csr, 0, sizeof(int2) * nzs));
   HIPCHECK(hipMemcpy(ctx->colptr, cp.data(), sizeof(int32_t) * (m + 1), hipMemcpyHostToDevice));
   HIPCHECK(hipMemcpy(ctx->rowptr, rp.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
   if (nz > 0) {
-    HIPCHECK(hipMemcpy(ctx->rowidx, ri.data(), sizeof(int32_t) * nz, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(ctx->colidx, ci.data(), sizeof(int32_t) * nz, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(ctx->vcsc, vc.data(), sizeof(float) * nz, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(ctx->vcsr, vr.data(), sizeof(float) * nz, hipMemcpyHostToDevice));
+    std::vector<int2> rec((size_t)nz);
+    for (int64_t p = 0; p < nz; ++p) {
+      rec[p].x = ri[p];
+      memcpy(&rec[p].y, &vc[p], 4);
+    }
+    HIPCHECK(hipMemcpy(ctx->rec_csc, rec.data(), sizeof(int2) * nz, hipMemcpyHostToDevice));
+    for (int64_t p = 0; p < nz; ++p) {
+      rec[p].x = ci[p];
+      memcpy(&rec[p].y, &vr[p], 4);
+    }
+    HIPCHECK(hipMemcpy(ctx->rec_csr, rec.data(), sizeof(int2) * nz, hipMemcpyHostToDevice));
   }
   ctx->sparse = true;
   ctx->nnz = nz;
@@ -626,8 +633,13 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   };
   Geo ghp[2] = {geometry(m, n, 0), geometry(m, n, phased ? 1 : 0)};
   Geo gwp[2] = {geometry(n, m, 0), geometry(n, m, phased ? 1 : 0)};
-  if (ctx->sparse) {  // gather kernels: one lane element per thread, always finished in-kernel
-    ghp[0] = ghp[1] = Geo{1, 1, n, 1, (m + NMFK_TILE - 1) / NMFK_TILE};
+  if (ctx->sparse) {  // gather kernels, always finished in-kernel; the H half-step's slots are per pass (see NmfkSparseArgs)
+    int slots_h = 1;
+    for (int q = 0; q < nk; ++q) {
+      const int sl = nmfk_sp_slot(nmfk_padded_k(ks[q]), 1);
+      slots_h = std::max(slots_h, (m + sl - 1) / sl);
+    }
+    ghp[0] = ghp[1] = Geo{1, 1, n, 1, slots_h};
     gwp[0] = gwp[1] = Geo{1, 1, m, 1, (n + NMFK_TILE - 1) / NMFK_TILE};
   }
   const int Sh = std::max(ghp[0].S, ghp[1].S), Sw = std::max(gwp[0].S, gwp[1].S);  // (sizes the partial-numerator buffers)
@@ -660,7 +672,14 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     const int q = order[oi], k = ks[q];
     if (merge > 0 && k <= NMFK_MULTI_MAXK) continue;
     if (hyb_phases && use_hyb_k(k)) continue;
-    groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns, use_hyb_k(k) ? (k <= 8 ? 8 : 16) : 0, phase_of_k(k)});
+    // sparse X: one kernel instantiation serves every rank with the same number of lanes per lane element, so those
+    // ranks share a launch group (31 per-rank launches of 16 units each left the GPU half empty: 33 -> 21 ms)
+    if (ctx->sparse && !groups.empty() && nmfk_sp_lpr(groups.back().kp) == nmfk_sp_lpr(nmfk_padded_k(k))) {
+      groups.back().kp = std::max(groups.back().kp, nmfk_padded_k(k));
+      groups.back().count += nruns;
+    } else {
+      groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns, use_hyb_k(k) ? (k <= 8 ? 8 : 16) : 0, phase_of_k(k)});
+    }
     for (int r = 0; r < nruns; ++r) ulist.push_back({q, r});
   }
   // merged sweeps: the ranks of the split-operand MFMA kernel (its cost does not depend on the rank, one instantiation
@@ -702,10 +721,12 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         rd.osumH = (int64_t)B.take(sizeof(double) * (size_t)PH * kp);
         rd.ossepart = (int64_t)B.take(sizeof(double) * (tiles_n + 1));  // sparse objective: slot 0 = <W'W, HH'>
         rd.ocanon = (int64_t)B.take(sizeof(int32_t) * (size_t)m);
+        rd.ogram = ctx->sparse ? (int64_t)B.take(sizeof(double) * nmfk_gram_doubles(n, m, kp)) : 0;
         rd.seed = seeds ? seeds[(size_t)q * nruns + r] : 0;
         // slots the unit's kernels write: the fused half-step one per lane tile, the grid-parallel helpers any count
         const Geo &gh = ghp[phase_of_k(k)], &gw = gwp[phase_of_k(k)];
         rd.nsH = gh.fused ? (m + lane_tile(k, gh.wsplit) - 1) / lane_tile(k, gh.wsplit) : PH;
+        if (ctx->sparse) rd.nsH = (m + nmfk_sp_slot(kp, 1) - 1) / nmfk_sp_slot(kp, 1);
         rd.nsW = gw.fused ? (n + lane_tile(k, gw.wsplit) - 1) / lane_tile(k, gw.wsplit) : PW;
         rd.hyb = rd.pad0 = 0;
         if (use_hyb_k(k)) rd.hyb = (merge > 0 || hyb_phases || k > 8) ? 16 : 8;
@@ -880,8 +901,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   NmfkSparseArgs sph, spw;  // CSC view (H half-step), CSR view (W half-step, objective)
   sph.arena = A;
   sph.ptr = ctx->colptr;
-  sph.idx = ctx->rowidx;
-  sph.val = ctx->vcsc;
+  sph.rec = ctx->rec_csc;
+  sph.nrec = (int32_t)std::max<int64_t>(ctx->nnz, 1);
   sph.runs = d_runs;
   sph.state = d_state;
   sph.L = m;
@@ -890,10 +911,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   sph.PW = PW;
   sph.PH = PH;
   sph.force = 0;
+  sph.split = 1;
   spw = sph;
+  spw.split = 0;
   spw.ptr = ctx->rowptr;
-  spw.idx = ctx->colidx;
-  spw.val = ctx->vcsr;
+  spw.rec = ctx->rec_csr;
   spw.L = n;
   spw.which = 1;
   const bool sparse = ctx->sparse;
@@ -906,7 +928,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   const bool wide_sse = T.wide_sse != 0;
   auto use_hyb = [&](const Group &G) { return G.hyb != 0; };
   const bool hyb_sse = T.hyb_sse != 0;  // objective of those groups on the matrix pipe
-  const int max_streams = T.streams;
+  // sparse X: the (few, large) launch groups run one after the other -- side by side their gathers evict each other's
+  // factor rows from L2 (29.2 vs 31.7 ms per iteration on BASELINE configs[3])
+  const int max_streams = T.streams > 0 ? T.streams : (ctx->sparse ? 1 : 8);
   const int NS = std::min(ngroups, max_streams);
   while ((int)ctx->gstreams.size() < NS) {
     hipStream_t gs;
@@ -1347,6 +1371,7 @@ NMFK_EXPORT int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float
     rd.osumW = (int64_t)B.take(sizeof(double) * kp);
     rd.osumH = (int64_t)B.take(sizeof(double) * kp);
     rd.ossepart = (int64_t)B.take(sizeof(double) * (tiles + 1));
+    rd.ogram = (int64_t)B.take(sizeof(double) * nmfk_gram_doubles(n, m, kp));
     if (ctx->scratch.ensure(B.off)) return fail(NMFK_ERR_HIP, "out of device memory");
     char *S = ctx->scratch.p;
     void *ptrs[2] = {S + oWi, S + oHi};
@@ -1372,8 +1397,8 @@ NMFK_EXPORT int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float
     NmfkSparseArgs sp;
     sp.arena = S;
     sp.ptr = ctx->rowptr;
-    sp.idx = ctx->colidx;
-    sp.val = ctx->vcsr;
+    sp.rec = ctx->rec_csr;
+    sp.nrec = (int32_t)std::max<int64_t>(ctx->nnz, 1);
     sp.runs = ia.runs;
     sp.state = ia.state;
     sp.L = n;
@@ -1381,6 +1406,7 @@ NMFK_EXPORT int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float
     sp.it = 0;
     sp.PW = sp.PH = 1;
     sp.force = 1;
+    sp.split = 0;
     nmfk_launch_sp_obj_f32(&sp, n, m, 0, 0, 1.0, 0, 1, st);
     nmfk_launch_sum_parts_f32(S, ia.runs, 1, tiles + 1, (double *)(S + oOut), st);
     HIPCHECK(hipGetLastError());

@@ -27,7 +27,18 @@ struct NmfkRun {
   // split-operand MFMA half-step (nmfk_step_hyb.hip): hyb = split width KS (8 or 16; 0 = unit does not use it)
   int32_t hyb;
   int32_t pad0;
+  int64_t ogram;     // sparse X: double[nmfk_gram_doubles()] partial Gram matrices of the factors (objective)
 };
+
+// sparse objective: <W'W, HH'> from partial Gram matrices over chunks of NMFK_GRAM_ROWS factor rows; a chunk's rows
+// are split once more (rp parts) when the matrix is a single 16 x 16 block, so that the four waves all have work
+#define NMFK_GRAM_ROWS 4096
+static inline int nmfk_gram_nb(int kp) { return (kp + 15) / 16; }
+static inline int nmfk_gram_rp(int kp) { return nmfk_gram_nb(kp) * nmfk_gram_nb(kp) >= 4 ? 1 : 4; }
+static inline size_t nmfk_gram_doubles(int64_t n, int64_t m, int kp) {
+  const size_t chunks = (size_t)((n + NMFK_GRAM_ROWS - 1) / NMFK_GRAM_ROWS + (m + NMFK_GRAM_ROWS - 1) / NMFK_GRAM_ROWS);
+  return chunks * nmfk_gram_rp(kp) * nmfk_gram_nb(kp) * nmfk_gram_nb(kp) * 256;
+}
 
 // Stop-rule state machine of NMFmultiplicative (Mult:57-63), one per unit, device resident.
 struct NmfkState {
@@ -87,12 +98,17 @@ struct NmfkSseArgs {
 struct NmfkSparseArgs {
   char *arena;
   const int32_t *ptr;   // CSC colptr (H half-step) or CSR rowptr (W half-step), length L + 1
-  const int32_t *idx;   // row indices / column indices
-  const float *val;
+  const int2 *rec;      // the non-zeros as records (.x = row / column index, .y = the fp32 value's bits), >= 1 entry
+  int32_t nrec;         // number of records allocated (>= 1): loads past a lane element's range are clamped to it
   const NmfkRun *runs;
   const NmfkState *state;
   int32_t L, which, it, PW, PH, force;
+  int32_t split;  // half-step: 1 = a workgroup walks ONE pass of its tile (NMFK_TILE / LPR lane elements) and owns a
+                  // sum-table slot of that size -- LPR x the workgroups (the H half-step has few lane elements)
 };
+// lanes per lane element of the sparse kernels (four signals each) and lane elements per sum-table slot
+static inline int nmfk_sp_lpr(int kp) { return kp <= 4 ? 1 : kp <= 8 ? 2 : kp <= 16 ? 4 : kp <= 32 ? 8 : 16; }
+static inline int nmfk_sp_slot(int kp, int split) { return split ? 256 / nmfk_sp_lpr(kp) : 256; }
 
 struct NmfkCheckArgs {
   char *arena;

@@ -67,8 +67,9 @@ struct nmfk_ctx {
   // sparse X (nmfk_set_X_csc): CSC for the H half-step, CSR for the W half-step and the objective
   bool sparse = false;
   int64_t nnz = 0;
-  int32_t *colptr = nullptr, *rowidx = nullptr, *rowptr = nullptr, *colidx = nullptr;
-  float *vcsc = nullptr, *vcsr = nullptr;
+  // the non-zeros are (index, value) records of 8 bytes, so that a walk costs one load per non-zero
+  int32_t *colptr = nullptr, *rowptr = nullptr;
+  int2 *rec_csc = nullptr, *rec_csr = nullptr;
   int64_t nan_count = 0, zero_count = 0;
   double lambda = 1e-32;
   // workspaces

@@ -948,100 +948,256 @@ __global__ __launch_bounds__(NMFK_TILE) void mfma_sse_kernel(NmfkSseArgs g, int 
 // ------------------------------------------------------------------------------------------------------
 // Sparse X (BASELINE configs[3]: zeros stay zeros).  In the reference a zero becomes lambda = 1e-32 (Mult:17-18), so
 // its ratio X/(W*H) is ~1e-32 and only the stored non-zeros contribute to the numerators: the gather form below is
-// the reference arithmetic to < 1e-30.  One thread per output element (a column of H via CSC, a row of W via CSR)
-// walks its non-zeros and gathers the other factor's k-vector (contiguous in the signal-major layout):
-//     p = <a, b_d>;  q = x / p;  acc += q * b_d ;   A_new = A .* acc ./ sumB   (fused finish, always S == 1)
-// HBM/L2-gather bound: 8 B (index + value) + 4k B of gathered factor per non-zero.
+// the reference arithmetic to < 1e-30.  Per output lane element l (a column of H via CSC, a row of W via CSR) and
+// non-zero (d, x) of it:      p = <a_l, b_d>;  q = x / p;  acc_l += q * b_d ;   A_new = A .* acc ./ sumB  (fused finish)
+// The walk is bound by the gathers of b_d (one row of the other factor, kp*4 bytes, per non-zero), so they are made
+// as cheap as the hardware allows: a lane element is owned by a GROUP of LPR adjacent lanes, lane `sub` holding the
+// signals [4 sub, 4 sub + 4) of a, acc and of every gathered row -- ONE 16-byte load per lane fetches a whole row
+// per group, 64 / LPR rows per wave instruction (a thread per lane element reading its row with kp/4 loads touched
+// 64 different cache lines with every instruction: 6 % of HBM speed in round 1).  The non-zeros are 8-byte
+// (index, value) records; the lanes of a group read consecutive records with one load and hand them round
+// (ds_bpermute), the partial dot products are added across the group by DPP butterflies (every lane of the group
+// gets the same bits).  A workgroup still owns NMFK_TILE lane elements = one slot of the sum table and walks them in
+// LPR passes of NMFK_TILE / LPR groups.
 // ------------------------------------------------------------------------------------------------------
-template <int KP>
-__global__ __launch_bounds__(NMFK_TILE) void sp_step_kernel(NmfkSparseArgs g, int u0) {
+typedef T sp_vec4 __attribute__((ext_vector_type(4)));
+typedef T sp_vec4u __attribute__((ext_vector_type(4), aligned(sizeof(T))));
+template <int CTRL>
+__device__ __forceinline__ float sp_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double sp_dpp(double v) {
+  const int2 w = __builtin_bit_cast(int2, v);
+  int2 r;
+  r.x = __builtin_amdgcn_update_dpp(0, w.x, CTRL, 0xf, 0xf, false);
+  r.y = __builtin_amdgcn_update_dpp(0, w.y, CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, r);
+}
+// sum over the LPR lanes of a group, the same bits in every lane (quad_perm xor 1, xor 2, row_half_mirror, row_mirror)
+template <int LPR>
+__device__ __forceinline__ T sp_group_sum(T s) {
+  if (LPR >= 2) s += sp_dpp<0xB1>(s);
+  if (LPR >= 4) s += sp_dpp<0x4E>(s);
+  if (LPR >= 8) s += sp_dpp<0x141>(s);
+  if (LPR >= 16) s += sp_dpp<0x140>(s);
+  return s;
+}
+
+// the lanes' view of the factor rows and the walk over a lane element's non-zeros, shared by the half-step and the
+// objective.  f(t, live, x, p, b): record t of the chunk, `live` false past the end of the range (x = 0 then),
+// p = <a, b_d> (the same bits in every lane of the group), b = this lane's four signals of the gathered row.
+template <int LPR>
+struct SpWalk {
+  static constexpr int RL = LPR >= 4 ? 1 : 4 / LPR;  // records a lane fetches per block
+  static constexpr int NB = LPR * RL;                // records per block of a group (4, 4, 4, 8, 16)
+  static constexpr int CH = NB < 8 ? NB : 8;         // gathers in flight per lane
+  int kp, sub, sofs;
+  bool on, ragged, cm[4];
+  __device__ __forceinline__ void init(int kp_, int tid) {
+    kp = kp_;
+    sub = tid % LPR;
+    on = 4 * sub < kp;  // this lane holds signals of the factor rows
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cm[e] = 4 * sub + e < kp;  // ... and which of its four exist
+    ragged = (kp & 3) != 0;  // (wave-uniform) rows end inside a lane's four signals: the tail lane reads into the next row
+    sofs = on ? 4 * sub : 0;  // lanes beyond the row re-read its first signals (same address: no traffic)
+  }
+  // Nothing may USE a gathered value between the loads of a chunk: a select or a branch right behind a load makes
+  // the compiler wait for vmcnt(0) on the spot and the gathers run one after the other.  Masking happens in keep().
+  __device__ __forceinline__ sp_vec4 row4(const T *__restrict__ F, int r) const {
+    return *(const sp_vec4u *)(F + (int64_t)r * kp + sofs);
+  }
+  __device__ __forceinline__ sp_vec4 keep(sp_vec4 v) const {
+    if (ragged) {
+#pragma unroll
+      for (int e = 1; e < 4; ++e) v[e] = cm[e] ? v[e] : (T)0;
+    }
+    return v;
+  }
+  __device__ __forceinline__ sp_vec4 lane_row(const T *__restrict__ F, int r) const {
+    sp_vec4 a = keep(row4(F, r));
+    if (!on) a = (sp_vec4)((T)0);
+    return a;
+  }
+  template <class Fn>
+  __device__ __forceinline__ void walk(const NmfkSparseArgs &g, const T *__restrict__ B, const sp_vec4 a, int p0, int p1,
+                                       Fn &&f) const {
+    // a block's records: lane `sub` of the group fetches RL consecutive ones (clamped to the array), one block ahead
+    int2 rec[RL], nxt[RL];
+#pragma unroll
+    for (int j = 0; j < RL; ++j) nxt[j] = g.rec[min(p0 + sub * RL + j, g.nrec - 1)];
+    for (int pp = p0; pp < p1; pp += NB) {
+#pragma unroll
+      for (int j = 0; j < RL; ++j) {
+        rec[j] = nxt[j];
+        nxt[j] = g.rec[min(pp + NB + sub * RL + j, g.nrec - 1)];
+      }
+#pragma unroll
+      for (int c0 = 0; c0 < NB; c0 += CH) {
+        sp_vec4 b[CH];
+        T x[CH];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {  // all gathers of the chunk first: they overlap
+          const int ti = c0 + t;
+          int d = rec[ti % RL].x, xb = rec[ti % RL].y;
+          if (LPR > 1) {
+            d = __shfl(d, ti / RL, LPR);
+            xb = __shfl(xb, ti / RL, LPR);
+          }
+          const bool live = pp + ti < p1;  // (records past the lane element's range: x = 0)
+          x[t] = live ? (T)__builtin_bit_cast(float, xb) : (T)0;
+          b[t] = row4(B, live ? d : 0);
+        }
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+          b[t] = keep(b[t]);
+          T s = a[0] * b[t][0];
+#pragma unroll
+          for (int e = 1; e < 4; ++e) s = fma_t(a[e], b[t][e], s);
+          f(t, pp + c0 + t < p1, x[t], sp_group_sum<LPR>(s), b[t]);
+        }
+      }
+    }
+  }
+};
+
+template <int LPR>
+__global__ __launch_bounds__(NMFK_TILE) void sp_step_kernel(NmfkSparseArgs g, int u0, int cnt) {
+  constexpr int GPW = NMFK_TILE / LPR;  // groups (lane elements in flight) per workgroup
   __shared__ double lds[5 * NMFK_MAX_K];
-  const int u = u0 + blockIdx.y;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.split) {
+    // H half-step: the gathered factor is W (up to 12.8 MB per unit, beyond one XCD's 4 MB of L2), but the columns'
+    // non-zeros are sorted by row, so the workgroups of a unit sweep W top-down together and share a moving window
+    // of it -- if they sit behind the SAME L2.  Workgroups go round-robin over the 8 XCDs in linear-id order:
+    // linear id -> (xcd, slot), slot -> (group of 8 units, workgroup of the unit); unit = 8 * group + xcd.
+    // (measured: L2 hit rate of the gathers 19 % with the units spread over the XCDs)
+    const int lin = by * gridDim.x + bx, xcd = lin & 7, slot = lin >> 3;
+    by = (slot / gridDim.x) * 8 + xcd;
+    bx = slot - (slot / gridDim.x) * gridDim.x;
+    if (by >= cnt) return;  // (the launcher rounds the unit dimension up to a multiple of 8)
+  }
+  const int u = u0 + by;
   if (!g.force && !g.state[u].active) return;
   const NmfkRun rd = g.runs[u];
+  const int kp = rd.kp, k = rd.k;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x;
-  const int l = tile * NMFK_TILE + tid;
-  const bool valid = l < g.L;
-  const int lc = valid ? l : 0;
+  const int grp = tid / LPR;
+  const int npz = g.split ? LPR : 1, ppw = LPR / npz;  // workgroups per tile, passes per workgroup
+  const int tile = bx / npz, pz = bx - tile * npz, slot = bx;
   const T *__restrict__ Hcur = NMFK_PTR(const T, g, NMFK_HOFF(rd, g.it));
   const T *__restrict__ Hnew = NMFK_PTR(const T, g, NMFK_HOFF(rd, g.it + 1));
   const T *__restrict__ Wt = NMFK_PTR(const T, g, rd.oWt);
   const T *__restrict__ A = g.which == 0 ? Hcur : Wt;
   const T *__restrict__ B = g.which == 0 ? Wt : Hnew;
-  T a[KP], acc[KP];
-#pragma unroll
-  for (int c = 0; c < KP; ++c) {
-    a[c] = A[c + (int64_t)lc * KP];
-    acc[c] = (T)0;
-  }
-  const int p0 = valid ? g.ptr[lc] : 0, p1 = valid ? g.ptr[lc + 1] : 0;
-  for (int pp = p0; pp < p1; ++pp) {
-    const int d = g.idx[pp];
-    const T x = (T)g.val[pp];
-    const T *__restrict__ b = B + (int64_t)d * KP;
-    T bv[KP];
-#pragma unroll
-    for (int c = 0; c < KP; ++c) bv[c] = b[c];
-    T pr = (T)0;
-#pragma unroll
-    for (int c = 0; c < KP; ++c) pr = fma_t(a[c], bv[c], pr);
-    const T q = div_t(x, pr);
-#pragma unroll
-    for (int c = 0; c < KP; ++c) acc[c] = fma_t(bv[c], q, acc[c]);
-  }
-  // fused finish (same as the dense kernel's): denominators from the other factor's sum table
-  const double *sumB = NMFK_PTR(const double, g, g.which == 0 ? rd.osumW : rd.osumH);
-  const int PB = g.which == 0 ? g.PW : g.PH;
-  double *den = lds;
-  if (tid < KP) {
-    double sd = 0;
-    for (int q = 0; q < PB; ++q) sd += sumB[q * KP + tid];
-    den[tid] = sd;
-  }
-  __syncthreads();
   T *__restrict__ Anew = g.which == 0 ? NMFK_PTR(T, g, NMFK_HOFF(rd, g.it + 1)) : NMFK_PTR(T, g, rd.oWt);
-  double *sumA = NMFK_PTR(double, g, g.which == 0 ? rd.osumH : rd.osumW) + (int64_t)tile * KP;
-  double *red = den + NMFK_MAX_K;
-  const int k = rd.k;
-#pragma unroll
-  for (int c = 0; c < KP; ++c) {
-    T v = a[c] * acc[c] / (T)den[c];
-    if (c >= k || !valid) v = (T)0;
-    if (valid) Anew[c + (int64_t)lc * KP] = v;
-    const double sv = wave_sum((double)v);
-    if (lane == 0) red[wave * KP + c] = sv;
+
+  // denominators: the other factor's sum table (hundreds of slots).  All threads share the work -- thread (j, c) adds
+  // the slots j, j + TPS, ... of signal c, then the TPS partial sums are added in order: a fixed order, so reproducible
+  double *den = lds, *red = den + NMFK_MAX_K;  // red: [256] here, [4][4 * LPR] at the end
+  {
+    const double *sumB = NMFK_PTR(const double, g, g.which == 0 ? rd.osumW : rd.osumH);
+    const int PB = g.which == 0 ? rd.nsW : rd.nsH;  // (the slots behind them are zero)
+    const int kq = kp <= 4 ? 4 : kp <= 8 ? 8 : kp <= 16 ? 16 : kp <= 32 ? 32 : 64, tps = NMFK_TILE / kq;
+    const int c = tid % kq, j = tid / kq;
+    double sd = 0;
+    if (c < kp) {
+#pragma unroll 4
+      for (int q = j; q < PB; q += tps) sd += sumB[q * kp + c];
+    }
+    red[tid] = sd;
+    __syncthreads();
+    if (tid < kp) {
+      sd = 0;
+      for (int jj = 0; jj < tps; ++jj) sd += red[jj * kq + tid];
+      den[tid] = sd;
+    }
   }
   __syncthreads();
-  if (tid < KP) sumA[tid] = (red[tid] + red[KP + tid]) + (red[2 * KP + tid] + red[3 * KP + tid]);
+
+  SpWalk<LPR> w;
+  w.init(kp, tid);
+  const int sub = w.sub;
+  double vs[4] = {0, 0, 0, 0};  // this lane's share of the sums of the new factor's signals 4 sub .. 4 sub + 3
+#pragma unroll 1
+  for (int pass = pz * ppw; pass < (pz + 1) * ppw; ++pass) {
+    const int l = tile * NMFK_TILE + pass * GPW + grp;
+    const bool valid = l < g.L;
+    const int lc = valid ? l : 0;
+    const sp_vec4 a = w.lane_row(A, lc);
+    sp_vec4 acc = (sp_vec4)((T)0);
+    const int p0 = valid ? g.ptr[lc] : 0, p1 = valid ? g.ptr[lc + 1] : 0;
+    w.walk(g, B, a, p0, p1, [&](int, bool live, T x, T pr, const sp_vec4 &b) __attribute__((always_inline)) {
+      const T q = live ? div_t(x, pr) : (T)0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fma_t(b[e], q, acc[e]);
+    });
+    // fused finish of the pass (Mult:67 / Mult:70 order)
+    if (w.on) {
+      sp_vec4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * sub + e;
+        v[e] = (c < k && valid) ? a[e] * acc[e] / (T)den[c < kp ? c : 0] : (T)0;
+        vs[e] += (double)v[e];
+      }
+      if (valid) {
+        T *dst = Anew + (int64_t)lc * kp + 4 * sub;
+        if (w.cm[3]) {
+          *(sp_vec4u *)dst = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (w.cm[e]) dst[e] = v[e];
+        }
+      }
+    }
+  }
+  // sums of the new factor over the workgroup's lane elements -> slot `tile`: lanes of equal `sub` across the groups
+  // of a wave (xor butterflies over the group index), then the four waves in order
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    double v = vs[e];
+#pragma unroll
+    for (int o = 32; o >= LPR; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane < LPR) red[wave * 4 * LPR + 4 * sub + e] = v;
+  }
+  __syncthreads();
+  if (tid < kp && slot < (g.which == 0 ? g.PH : g.PW)) {
+    double *sumA = NMFK_PTR(double, g, g.which == 0 ? rd.osumH : rd.osumW) + (int64_t)slot * kp;
+    sumA[tid] = (red[tid] + red[4 * LPR + tid]) + (red[2 * 4 * LPR + tid] + red[3 * 4 * LPR + tid]);
+  }
 }
 
 // objective on sparse X:  sum_all (x - p)^2 = sum_nz [(x - p)^2 - p^2] + sum_all p^2,  sum_all p^2 = <W'W, HH'>.
-// part 1: non-zero terms, one thread per row (CSR), fp64 accumulation, one partial per workgroup
-template <int KP>
+// part 1: the non-zero terms, the same walk over the rows (CSR) as the W half-step, fp64 accumulation, one partial per
+// workgroup (= 256 rows) in ossepart[1 + tile]
+template <int LPR>
 __device__ __forceinline__ void sp_obj_body(const NmfkSparseArgs &g, const NmfkRun &rd, const T *__restrict__ H, double weight,
                                             double *sh) {
-  const int i = blockIdx.x * NMFK_TILE + threadIdx.x;
-  const bool valid = i < g.L;
-  const int ic = valid ? i : 0;
+  constexpr int GPW = NMFK_TILE / LPR;
+  const int tid = threadIdx.x, grp = tid / LPR;
   const T *__restrict__ Wt = NMFK_PTR(const T, g, rd.oWt);
-  T a[KP];
-#pragma unroll
-  for (int c = 0; c < KP; ++c) a[c] = Wt[c + (int64_t)ic * KP];
-  const int p0 = valid ? g.ptr[ic] : 0, p1 = valid ? g.ptr[ic + 1] : 0;
+  SpWalk<LPR> w;
+  w.init(rd.kp, tid);
   double s = 0;
-  for (int pp = p0; pp < p1; ++pp) {
-    const T *__restrict__ b = H + (int64_t)g.idx[pp] * KP;
-    T pr = (T)0;
-#pragma unroll
-    for (int c = 0; c < KP; ++c) pr = fma_t(a[c], b[c], pr);
-    const double x = (double)g.val[pp], p = (double)pr;
-    s += (x - p) * (x - p) - p * p;
+#pragma unroll 1
+  for (int pass = 0; pass < LPR; ++pass) {
+    const int i = blockIdx.x * NMFK_TILE + pass * GPW + grp;
+    const bool valid = i < g.L;
+    const int ic = valid ? i : 0;
+    const sp_vec4 a = w.lane_row(Wt, ic);
+    const int p0 = valid ? g.ptr[ic] : 0, p1 = valid ? g.ptr[ic + 1] : 0;
+    w.walk(g, H, a, p0, p1, [&](int, bool live, T x, T pr, const sp_vec4 &) __attribute__((always_inline)) {
+      const double xd = (double)x, p = (double)pr;
+      s += live ? (xd - p) * (xd - p) - p * p : 0.0;
+    });
   }
+  if (w.sub != 0) s = 0;  // every lane of a group holds the group's terms
   s = block_sum(s * weight * weight, sh);
   if (threadIdx.x == 0) NMFK_PTR(double, g, rd.ossepart)[1 + blockIdx.x] = s;
 }
-#define NMFK_SPOBJ_CASE(KP) sp_obj_body<KP>(g, rd, H, weight, sh)
 __global__ __launch_bounds__(NMFK_TILE) void sp_obj_kernel(NmfkSparseArgs g, int hsel, int total_iters, double weight, int u0) {
   __shared__ double sh[8];
   const int u = u0 + blockIdx.y;
@@ -1050,64 +1206,84 @@ __global__ __launch_bounds__(NMFK_TILE) void sp_obj_kernel(NmfkSparseArgs g, int
   const NmfkRun rd = g.runs[u];
   const int sel = hsel >= 0 ? hsel : ((st.active ? total_iters : st.iters) & 1);
   const T *H = NMFK_PTR(const T, g, NMFK_HOFF(rd, sel));
-  NMFK_DISPATCH_KP(rd.kp, NMFK_SPOBJ_CASE)
+  if (rd.kp <= 4)
+    sp_obj_body<1>(g, rd, H, weight, sh);
+  else if (rd.kp <= 8)
+    sp_obj_body<2>(g, rd, H, weight, sh);
+  else if (rd.kp <= 16)
+    sp_obj_body<4>(g, rd, H, weight, sh);
+  else if (rd.kp <= 32)
+    sp_obj_body<8>(g, rd, H, weight, sh);
+  else
+    sp_obj_body<16>(g, rd, H, weight, sh);
 }
 
-// part 2: <W'W, HH'> -> ssepart[0].  One workgroup per unit; Gram matrices accumulated in fp64, pairs (a, b) over
-// threads, factor rows staged through LDS in chunks of 64.
-__global__ __launch_bounds__(NMFK_TILE) void sp_gram_kernel(NmfkSparseArgs g, int n, int m, int hsel, int total_iters,
-                                                           double weight, int u0) {
-  __shared__ T chunk[64 * NMFK_MAX_K];
-  __shared__ double gw[NMFK_MAX_K * NMFK_MAX_K];
-  __shared__ double sh[8];
-  const int u = u0 + blockIdx.x;
+// part 2: <W'W, HH'> -> ssepart[0].  Stage 1 (grid: row chunks of W then of H, units): the partial Gram matrix of
+// NMFK_GRAM_ROWS rows of a factor on the fp64 matrix pipe (v_mfma_f64_16x16x4_f64: A = 4 rows x 16 signals transposed,
+// B = the same rows x 16 signals, one 16 x 16 block of F'F per wave task), written as it leaves the accumulators:
+// both factors use the same layout and the inner product of stage 2 is elementwise, so the layout never matters.
+typedef double sp_f64x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(NMFK_TILE) void sp_gram_part_kernel(NmfkSparseArgs g, int n, int m, int hsel, int total_iters,
+                                                                int u0) {
+  const int u = u0 + blockIdx.y;
   const NmfkState st = g.state[u];
   if (!g.force && !st.active) return;
   const NmfkRun rd = g.runs[u];
   const int sel = hsel >= 0 ? hsel : ((st.active ? total_iters : st.iters) & 1);
-  const T *Wt = NMFK_PTR(const T, g, rd.oWt);
-  const T *H = NMFK_PTR(const T, g, NMFK_HOFF(rd, sel));
-  const int kp = rd.kp, npair = kp * kp, tid = threadIdx.x;
+  const int kp = rd.kp, nb = (kp + 15) / 16, nblk = nb * nb, rp = nblk >= 4 ? 1 : 4;
+  const int cw = (n + NMFK_GRAM_ROWS - 1) / NMFK_GRAM_ROWS;
+  const bool isW = (int)blockIdx.x < cw;
+  const T *__restrict__ F = isW ? NMFK_PTR(const T, g, rd.oWt) : NMFK_PTR(const T, g, NMFK_HOFF(rd, sel));
+  const int len = isW ? n : m, cidx = isW ? blockIdx.x : blockIdx.x - cw;
+  const int r0 = cidx * NMFK_GRAM_ROWS, r1 = min(len, r0 + NMFK_GRAM_ROWS);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, lq = lane >> 4;
+  double *out = NMFK_PTR(double, g, rd.ogram);
+  for (int task = wave; task < nblk * rp; task += NMFK_TILE / 64) {
+    const int blk = task % nblk, part = task / nblk, bi = blk / nb, bj = blk - bi * nb;
+    const int q = ((((r1 - r0) + rp - 1) / rp) + 3) & ~3;
+    const int s0 = min(r1, r0 + part * q), s1 = min(r1, s0 + q);
+    const int ca = 16 * bi + l16, cb = 16 * bj + l16;
+    const bool va = ca < kp, vb = cb < kp;
+    const T *__restrict__ Fa = F + (va ? ca : 0), *__restrict__ Fb = F + (vb ? cb : 0);
+    sp_f64x4 acc = {0, 0, 0, 0};
+    constexpr int UN = 8;
+    for (int r = s0; r < s1; r += 4 * UN) {
+      T av[UN], bv[UN];
+#pragma unroll
+      for (int i = 0; i < UN; ++i) {
+        const int row = min(r + 4 * i + lq, len - 1);
+        av[i] = Fa[(int64_t)row * kp];
+        bv[i] = Fb[(int64_t)row * kp];
+      }
+#pragma unroll
+      for (int i = 0; i < UN; ++i) {
+        const bool ok = r + 4 * i + lq < s1;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ok && va) ? (double)av[i] : 0.0, (ok && vb) ? (double)bv[i] : 0.0, acc, 0, 0, 0);
+      }
+    }
+    const int pidx = (isW ? 0 : cw * rp) + cidx * rp + part;
+    *(sp_f64x4 *)(out + ((int64_t)pidx * nblk + blk) * 256 + lane * 4) = acc;
+  }
+}
+// stage 2 (one workgroup per unit): the partial matrices of each factor added in order, then their inner product
+__global__ __launch_bounds__(NMFK_TILE) void sp_gram_dot_kernel(NmfkSparseArgs g, int n, int m, double weight, int u0) {
+  __shared__ double sh[8];
+  const int u = u0 + blockIdx.x;
+  if (!g.force && !g.state[u].active) return;
+  const NmfkRun rd = g.runs[u];
+  const int kp = rd.kp, nb = (kp + 15) / 16, nblk = nb * nb, rp = nblk >= 4 ? 1 : 4;
+  const int npw = ((n + NMFK_GRAM_ROWS - 1) / NMFK_GRAM_ROWS) * rp, nph = ((m + NMFK_GRAM_ROWS - 1) / NMFK_GRAM_ROWS) * rp;
+  const double *part = NMFK_PTR(const double, g, rd.ogram);
+  const int64_t msz = (int64_t)nblk * 256;
   double total = 0;
-  for (int pass = 0; pass < 2; ++pass) {  // pass 0: G = W'W kept in LDS; pass 1: <G, HH'>
-    const T *F = pass == 0 ? Wt : H;
-    const int len = pass == 0 ? n : m;
-    double accp[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) accp[q] = 0;
-    for (int r0 = 0; r0 < len; r0 += 64) {
-      const int rows = min(64, len - r0);
-      __syncthreads();
-      for (int e = tid; e < rows * kp; e += NMFK_TILE) chunk[e] = F[(int64_t)r0 * kp + e];
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int pr = tid + q * NMFK_TILE;
-        if (pr < npair) {
-          const int a = pr % kp, b = pr / kp;
-          double sacc = 0;
-          for (int r = 0; r < rows; ++r) sacc += (double)chunk[r * kp + a] * (double)chunk[r * kp + b];
-          accp[q] += sacc;
-        }
-      }
-    }
-    if (pass == 0) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int pr = tid + q * NMFK_TILE;
-        if (pr < npair) gw[pr] = accp[q];
-      }
-      __syncthreads();
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int pr = tid + q * NMFK_TILE;
-        if (pr < npair) total += accp[q] * gw[pr];
-      }
-    }
+  for (int e = threadIdx.x; e < msz; e += NMFK_TILE) {
+    double gw = 0, gh = 0;
+    for (int q = 0; q < npw; ++q) gw += part[q * msz + e];
+    for (int q = 0; q < nph; ++q) gh += part[(npw + q) * msz + e];
+    total += gw * gh;
   }
   total = block_sum(total * weight * weight, sh);
-  if (tid == 0) NMFK_PTR(double, g, rd.ossepart)[0] = total;
+  if (threadIdx.x == 0) NMFK_PTR(double, g, rd.ossepart)[0] = total;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1522,9 +1698,19 @@ void nmfk_launch_step_mfma_wide_f32(const NmfkStepArgs &a, const NmfkStepArgs *d
 
 void NMFK_NAME(nmfk_launch_sp_step)(const void *argsv, int kp, int u0, int cnt, hipStream_t s) {
   const NmfkSparseArgs &a = *(const NmfkSparseArgs *)argsv;
-  const dim3 grid((a.L + NMFK_TILE - 1) / NMFK_TILE, cnt), blk(NMFK_TILE);
-#define NMFK_SP_CASE(KP) hipLaunchKernelGGL((sp_step_kernel<KP>), grid, blk, 0, s, a, u0)
-  NMFK_DISPATCH_KP(kp, NMFK_SP_CASE)
+  // lanes per lane element: four signals each; split: a workgroup per pass
+  const dim3 grid(((a.L + NMFK_TILE - 1) / NMFK_TILE) * (a.split ? nmfk_sp_lpr(kp) : 1), a.split ? (cnt + 7) / 8 * 8 : cnt);
+  const dim3 blk(NMFK_TILE);
+  if (kp <= 4)
+    hipLaunchKernelGGL((sp_step_kernel<1>), grid, blk, 0, s, a, u0, cnt);
+  else if (kp <= 8)
+    hipLaunchKernelGGL((sp_step_kernel<2>), grid, blk, 0, s, a, u0, cnt);
+  else if (kp <= 16)
+    hipLaunchKernelGGL((sp_step_kernel<4>), grid, blk, 0, s, a, u0, cnt);
+  else if (kp <= 32)
+    hipLaunchKernelGGL((sp_step_kernel<8>), grid, blk, 0, s, a, u0, cnt);
+  else
+    hipLaunchKernelGGL((sp_step_kernel<16>), grid, blk, 0, s, a, u0, cnt);
 }
 
 // objective of units [u0, u0 + cnt): ssepart[0] = <W'W, HH'>, ssepart[1 + tile] = non-zero terms
@@ -1533,7 +1719,9 @@ void NMFK_NAME(nmfk_launch_sp_obj)(const void *argsv, int n, int m, int hsel, in
   const NmfkSparseArgs &a = *(const NmfkSparseArgs *)argsv;  // CSR view: L = n
   hipLaunchKernelGGL(sp_obj_kernel, dim3((a.L + NMFK_TILE - 1) / NMFK_TILE, cnt), dim3(NMFK_TILE), 0, s, a, hsel,
                      total_iters, weight, u0);
-  hipLaunchKernelGGL(sp_gram_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, n, m, hsel, total_iters, weight, u0);
+  const int chunks = (n + NMFK_GRAM_ROWS - 1) / NMFK_GRAM_ROWS + (m + NMFK_GRAM_ROWS - 1) / NMFK_GRAM_ROWS;
+  hipLaunchKernelGGL(sp_gram_part_kernel, dim3(chunks, cnt), dim3(NMFK_TILE), 0, s, a, n, m, hsel, total_iters, u0);
+  hipLaunchKernelGGL(sp_gram_dot_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, n, m, weight, u0);
 }
 
 void NMFK_NAME(nmfk_launch_reduce)(const NmfkStepArgs &a, int u0, int cnt, hipStream_t s) {

@@ -22,7 +22,8 @@ ctx = N.Context(0)
 t = time.perf_counter()
 ctx.set_X_sparse(X)
 print(f"upload + CSR build: {time.perf_counter() - t:.2f}s, nnz kept {ctx.nnz}")
-ks = list(range(2, kmax + 1))
+kmin = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+ks = list(range(kmin, kmax + 1))
 seeds = np.array([[N.run_seed(1, k, r) for r in range(R)] for k in ks], dtype=np.uint64)
 ctx.mu_sweep(ks, R, seeds=seeds, maxiter=10, maxbaditers=10 ** 9)
 t = time.perf_counter()
@@ -32,4 +33,4 @@ bytes_alg = sum((2 * ctx.nnz * 8 + 4 * (n + m) * k * 4) * R for k in ks) * iters
 flops = sum(8.0 * ctx.nnz * k * R for k in ks) * iters
 print(f"{len(ks) * R} units: {1e3 * dt / iters:.2f} ms/iter (incl. checks + D2H of results), "
       f"{bytes_alg / dt / 1e9:.0f} GB/s algorithmic = {bytes_alg / dt / 8e12:.1%} of 8 TB/s, {flops / dt / 1e12:.2f} TFLOP/s; "
-      f"obj[k=2]={res[2]['objvalue'][0]:.3f} obj[k={kmax}]={res[kmax]['objvalue'][0]:.3f}")
+      f"obj[k={kmin}]={res[kmin]['objvalue'][0]:.3f} obj[k={kmax}]={res[kmax]['objvalue'][0]:.3f}")

@@ -867,7 +867,7 @@ def _sparse_case(oracle, n, m, fill, seed):
 
 
 @pytest.mark.parametrize("compute,tol", [("f64", 1e-6), ("f32", 1e-4)])
-@pytest.mark.parametrize("k", [1, 4, 7, 16, 20])
+@pytest.mark.parametrize("k", [1, 4, 7, 16, 20, 40])
 def test_sparse_gather_path_matches_dense_oracle(NMFk, ctx, oracle, compute, tol, k):
     """BASELINE configs[3] semantics: the CSC/CSR gather kernels against the DENSE Float64 oracle (zeros -> lambda)."""
     n, m = 300, 96

@@ -939,16 +939,29 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   }
   if (!ctx->poll_stream) HIPCHECK(hipStreamCreateWithFlags(&ctx->poll_stream, hipStreamNonBlocking));
   hipStream_t poll = ctx->poll_stream;
+  // the sweep's events live in a holder that destroys them on EVERY way out (the error returns of HIPCHECK / fail()
+  // below included)
+  struct EventBag {
+    std::vector<hipEvent_t> all;
+    ~EventBag() {
+      for (hipEvent_t e : all) (void)hipEventDestroy(e);
+    }
+    hipError_t make(hipEvent_t *e, unsigned flags) {
+      const hipError_t r = hipEventCreateWithFlags(e, flags);
+      if (r == hipSuccess) all.push_back(*e);
+      return r;
+    }
+  } events;
   std::vector<hipEvent_t> gev(2 * (size_t)NS);
-  for (auto &e : gev) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto &e : gev) HIPCHECK(events.make(&e, hipEventDisableTiming));
   hipEvent_t snap_ev[2], start_ev;
-  HIPCHECK(hipEventCreateWithFlags(&snap_ev[0], hipEventDisableTiming));
-  HIPCHECK(hipEventCreateWithFlags(&snap_ev[1], hipEventDisableTiming));
-  HIPCHECK(hipEventCreateWithFlags(&start_ev, hipEventDisableTiming));
+  HIPCHECK(events.make(&snap_ev[0], hipEventDisableTiming));
+  HIPCHECK(events.make(&snap_ev[1], hipEventDisableTiming));
+  HIPCHECK(events.make(&start_ev, hipEventDisableTiming));
   hipEvent_t loop_t0 = nullptr, loop_t1 = nullptr;
   if (ctx->profiling) {
-    HIPCHECK(hipEventCreate(&loop_t0));
-    HIPCHECK(hipEventCreate(&loop_t1));
+    HIPCHECK(events.make(&loop_t0, hipEventDefault));
+    HIPCHECK(events.make(&loop_t1, hipEventDefault));
     HIPCHECK(hipEventRecord(loop_t0, st));
   }
   HIPCHECK(hipEventRecord(start_ev, st));  // init done
@@ -1180,10 +1193,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     HIPCHECK(hipMemcpyAsync(h_iters[q].data(), A + o_iters[q], sizeof(int32_t) * nruns, hipMemcpyDeviceToHost, st));
   }
   HIPCHECK(hipStreamSynchronize(st));
-  (void)hipEventDestroy(snap_ev[0]);
-  (void)hipEventDestroy(snap_ev[1]);
-  (void)hipEventDestroy(start_ev);
-  for (auto &e : gev) (void)hipEventDestroy(e);
 
   // sse_out (Mult:125); it may be device memory: stage through a host vector.  Unweighted: normnan(X - W*H)^2.
   if (sse_out) {
@@ -1214,8 +1223,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         for (int r = 0; r < nruns; ++r)
           E.flops += 4.0 * n * (double)m * ks[q] * (double)h_iters[q][r] * ((P.Hfixed ? 0 : 1) + (P.Wfixed ? 0 : 1));
     }
-    (void)hipEventDestroy(loop_t0);
-    (void)hipEventDestroy(loop_t1);
     for (const Sample &sm : prof.samples) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, ctx->events[sm.e0], ctx->events[sm.e1]) != hipSuccess) continue;

@@ -268,9 +268,8 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
   };
   // one chunk of 16 loop steps from the staged operands (av: split rows of the chunk, bn: its transposed block);
   // MASK: the chunk crosses the end of the loop range, ratios of the steps >= d1 are dropped
-  auto chunk = [&](int dch, const f32x4_t (&xcur)[NT], const u32x4_t (&av)[NM], const f32x4_t &bn, bool mask)
-                   __attribute__((always_inline)) {
-    f32x4_t p[NT];
+  // first product of a chunk: p[t][r] = <a_l, b_d> at d = dch + 4g + r, l = l0 + 16t + c16
+  auto chunk_p = [&](const u32x4_t (&av)[NM], f32x4_t (&p)[NT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -278,7 +277,10 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
 #pragma unroll
       for (int t = 0; t < NT; ++t)
         p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[j]), bop[t][j], p[t], 0, 0, 0);
-    // p[t][r] = <a_l, b_d> at d = dch + 4g + r, l = l0 + 16t + c16
+  };
+  // ratios and second product (or the objective's residuals)
+  auto chunk_n = [&](int dch, const f32x4_t (&xcur)[NT], const f32x4_t (&p)[NT], const f32x4_t &bn, bool mask)
+                     __attribute__((always_inline)) {
     if (OBJ) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -294,9 +296,15 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        q[t][r] = hyb_div(xcur[t][r], p[t][r]);
-        if (mask) q[t][r] = (dch + 4 * g + r < d1) ? q[t][r] : 0.0f;
+      for (int r = 0; r < 4; r += 2) {  // (pairs: one v_pk_mul_f32 for two ratios)
+        const f32x2_t rc = {__builtin_amdgcn_rcpf(p[t][r]), __builtin_amdgcn_rcpf(p[t][r + 1])};
+        const f32x2_t q2 = (f32x2_t){xcur[t][r], xcur[t][r + 1]} * rc;
+        q[t][r] = q2.x;
+        q[t][r + 1] = q2.y;
+        if (mask) {
+          q[t][r] = (dch + 4 * g + r < d1) ? q[t][r] : 0.0f;
+          q[t][r + 1] = (dch + 4 * g + r + 1 < d1) ? q[t][r + 1] : 0.0f;
+        }
       }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -356,8 +364,15 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
     barrier();
     // one trip; FULLT: every chunk of the trip exists, every block of it has a successor after next and no chunk touches
     // the end of the loop range -> no guards in the unrolled body
+    u32x4_t avn[NM];  // first-product operands of the next chunk (guard-free trips only), see trip()
+#pragma unroll
+    for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(sb + fofs + hyb_sa<KS>(j, g) * (KS * 2));
     auto trip = [&](int c0, auto full_tag) __attribute__((always_inline)) {
       constexpr bool FULLT = decltype(full_tag)::value;
+      // the first product's operands of the NEXT chunk of a block are read from LDS right behind this chunk's first
+      // product (into the registers it has just freed): their latency hides behind the ratios and the second product
+      // instead of sitting in front of the next chunk's MFMAs.  (Not across a block's end: the other buffer is only
+      // valid behind the barrier.)
 #pragma unroll
       for (int ci = 0; ci < TRIP; ++ci) {
         const int c = c0 + ci;
@@ -374,17 +389,37 @@ __global__ __launch_bounds__(512) void hyb_step_kernel(char *arena, const float 
         const bool last_of_block = ch == CPB - 1 || (!FULLT && c == nchunks - 1);
         if (last_of_block && more) stage.write(sb + (buf ^ 1) * ST::STB, sv[buf ^ 1], svrow[buf ^ 1]);
         __builtin_amdgcn_sched_barrier(0);  // loads stay in front of the arithmetic they overlap with
-        {
-          const char *b = sb + buf * ST::STB;
-          u32x4_t av[NM];
+        // The block's barrier sits HERE, in front of its last chunk's arithmetic: every wave has written its part of
+        // the next block and has fetched its last operands of this one (the second product's block below; the first
+        // product's came with the previous chunk), so this buffer is free for the block after next and the last chunk
+        // can already fetch the next block's first operands behind its first product.
+        const char *b = sb + buf * ST::STB;
+        f32x4_t bn = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (!OBJ) bn = *(const f32x4_t *)(b + nofs + ch * 16 * ST::FRS);
+        constexpr bool PRE = FULLT;
+        u32x4_t av[NM];
+        if (!PRE) {
 #pragma unroll
           for (int j = 0; j < NM; ++j) av[j] = *(const u32x4_t *)(b + ch * 16 * ST::RS + fofs + hyb_sa<KS>(j, g) * (KS * 2));
-          f32x4_t bn = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          if (!OBJ) bn = *(const f32x4_t *)(b + nofs + ch * 16 * ST::FRS);
-          chunk(dch, xr[ci & 3], av, bn, !FULLT && dch + 16 > d1);
+        }
+        if (last_of_block) barrier();
+        {
+          if (PRE) {
+#pragma unroll
+            for (int j = 0; j < NM; ++j) av[j] = avn[j];
+          }
+          f32x4_t p[NT];
+          chunk_p(av, p);
+          if (PRE) {  // (FULLT: a next chunk and, at a block's end, a next block exist)
+            const char *bnx = ch + 1 < CPB ? b + (ch + 1) * 16 * ST::RS : sb + (buf ^ 1) * ST::STB;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(bnx + fofs + hyb_sa<KS>(j, g) * (KS * 2));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          chunk_n(dch, xr[ci & 3], p, bn, !FULLT && dch + 16 > d1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (last_of_block) barrier();
       }
     };
     constexpr int AHEAD = 2 * CPB > 2 ? 2 * CPB : 2;

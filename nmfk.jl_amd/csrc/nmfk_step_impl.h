@@ -1376,6 +1376,53 @@ __device__ __forceinline__ void sse_body(const NmfkSseArgs &g, const NmfkRun &rd
   if (threadIdx.x == 0) NMFK_PTR(double, g, rd.ossepart)[blockIdx.x] = ssum;
 }
 
+// fp32 compute, no weight array, not the final normnan pass: two rows per thread as packed pairs (v_pk_fma_f32 with the
+// scalar H entries), residuals squared in fp32 and added in fp32 over FOUR columns before they enter the fp64 sum.
+// (A partial of 8 squares of ~0.1 carries ~1e-7 relative rounding noise, unbiased; over the 4.2e6 entries of the
+// BASELINE shape that is ~3e-10 of the objective, 1e-4 absolute on 3.5e5 -- the stop rule's tolOF is 1e-3.  The
+// per-element fp64 version cost as much as 4 half-steps per check at k <= 8: 20 % of the packed-VALU ranks' time.)
+// One partial per workgroup = 512 rows: slot 2b, slot 2b + 1 is zeroed.
+template <int KP>
+__device__ __forceinline__ void sse_body_pk(const NmfkSseArgs &g, const NmfkRun &rd, const float *__restrict__ H, double *sh) {
+  const int tid = threadIdx.x, i0 = blockIdx.x * 2 * NMFK_TILE + tid, i1 = i0 + NMFK_TILE;
+  const bool v0 = i0 < g.n, v1 = i1 < g.n;
+  const int c0 = v0 ? i0 : 0, c1 = v1 ? i1 : 0;
+  const float *__restrict__ Wt = NMFK_PTR(const float, g, rd.oWt);
+  f32x2 a2[KP];
+#pragma unroll
+  for (int c = 0; c < KP; ++c) a2[c] = (f32x2){Wt[c + (int64_t)c0 * KP], Wt[c + (int64_t)c1 * KP]};
+  const float *__restrict__ xp0 = g.Xc + c0, *__restrict__ xp1 = g.Xc + c1;
+  const float w = (float)g.weight;
+  const f32x2 w2 = {v0 ? w : 0.f, v1 ? w : 0.f};  // rows past the end contribute nothing
+  double ssum = 0.0;
+  auto column = [&](int j) __attribute__((always_inline)) -> float {
+    const float *__restrict__ b = H + (int64_t)j * KP;
+    f32x2 p2 = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KP; ++c) p2 = __builtin_elementwise_fma(a2[c], (f32x2)(b[c]), p2);
+    const f32x2 x2 = {xp0[(int64_t)j * g.n], xp1[(int64_t)j * g.n]};
+    f32x2 e2 = (x2 - p2) * w2;
+    e2.x = x2.x == x2.x ? e2.x : 0.f;  // missing entries (NaN) do not count
+    e2.y = x2.y == x2.y ? e2.y : 0.f;
+    const f32x2 q = e2 * e2;
+    return q.x + q.y;
+  };
+  int j = 0;
+  for (; j + 4 <= g.m; j += 4) {
+    float s4 = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) s4 += column(j + jj);
+    ssum += (double)s4;
+  }
+  for (; j < g.m; ++j) ssum += (double)column(j);
+  ssum = block_sum(ssum, sh);
+  if (tid == 0) {
+    double *part = NMFK_PTR(double, g, rd.ossepart);
+    part[2 * blockIdx.x] = ssum;
+    if (2 * (int)blockIdx.x + 1 < (g.n + NMFK_TILE - 1) / NMFK_TILE) part[2 * blockIdx.x + 1] = 0.0;
+  }
+}
+
 #define NMFK_SSE_CASE(KP) sse_body<KP>(g, rd, H, sh)
 __global__ __launch_bounds__(NMFK_TILE) void sse_kernel(NmfkSseArgs g, int u0) {
   __shared__ double sh[8];
@@ -1386,6 +1433,19 @@ __global__ __launch_bounds__(NMFK_TILE) void sse_kernel(NmfkSseArgs g, int u0) {
   const int sel = g.hsel >= 0 ? g.hsel : ((st.active ? g.total_iters : st.iters) & 1);
   const T *H = NMFK_PTR(const T, g, NMFK_HOFF(rd, sel));
   NMFK_DISPATCH_KP(rd.kp, NMFK_SSE_CASE)
+}
+#define NMFK_SSEPK_CASE(KP) sse_body_pk<KP>(g, rd, (const float *)H, sh)
+__global__ __launch_bounds__(NMFK_TILE) void sse_pk_kernel(NmfkSseArgs g, int u0) {
+  __shared__ double sh[8];
+  const int u = u0 + blockIdx.y;
+  const NmfkState st = g.state[u];
+  if (!st.active) return;
+  const NmfkRun rd = g.runs[u];
+  const int sel = g.hsel >= 0 ? g.hsel : ((st.active ? g.total_iters : st.iters) & 1);
+  const T *H = NMFK_PTR(const T, g, NMFK_HOFF(rd, sel));
+  if (sizeof(T) == 4) {
+    NMFK_DISPATCH_KP(rd.kp, NMFK_SSEPK_CASE)
+  }
 }
 
 // out[u] = sum of the objective partials of unit u (fixed order)
@@ -1730,7 +1790,10 @@ void NMFK_NAME(nmfk_launch_reduce)(const NmfkStepArgs &a, int u0, int cnt, hipSt
 
 void NMFK_NAME(nmfk_launch_sse)(const NmfkSseArgs &a, int u0, int cnt, hipStream_t s) {
   const int ntile = (a.n + NMFK_TILE - 1) / NMFK_TILE;
-  hipLaunchKernelGGL(sse_kernel, dim3(ntile, cnt), dim3(NMFK_TILE), 0, s, a, u0);
+  if (sizeof(T) == 4 && !a.Wgt && !a.force && a.n >= 2 * NMFK_TILE)  // the loop's monitored objective, fp32 compute
+    hipLaunchKernelGGL(sse_pk_kernel, dim3((ntile + 1) / 2, cnt), dim3(NMFK_TILE), 0, s, a, u0);
+  else
+    hipLaunchKernelGGL(sse_kernel, dim3(ntile, cnt), dim3(NMFK_TILE), 0, s, a, u0);
 }
 
 void NMFK_NAME(nmfk_launch_sum_parts)(char *arena, const NmfkRun *runs, int nunits, int ntile, double *out, hipStream_t s) {

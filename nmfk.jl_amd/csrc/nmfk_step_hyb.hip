@@ -21,6 +21,10 @@
 #include <algorithm>
 #include <type_traits>
 
+#ifndef NMFK_HYB_CPB
+#define NMFK_HYB_CPB 4  // chunks of 16 loop steps per staged block of a workgroup (one barrier per block)
+#endif
+
 namespace {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
     for (; c0 < nchunks; c0 += TRIP) trip(c0, std::false_type());
   };
   if (OBJ) {
-    HybStage<KS, 4, 64 * NW, false> stage;
+    HybStage<KS, NMFK_HYB_CPB, 64 * NW, false> stage;
     stage.init(B, k, D, tid);
     run(stage, sbase, [] { HYB_BARRIER(); });
     // workgroup sum in wave order (fixed order => reproducible), one partial per workgroup
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
     return;
   }
   if (ws == 1) {
-    HybStage<KS, 4, 64 * NW, true> stage;
+    HybStage<KS, NMFK_HYB_CPB, 64 * NW, true> stage;
     stage.init(B, k, D, tid);
     run(stage, sbase, [] { HYB_BARRIER(); });
   } else {
@@ -556,9 +560,9 @@ void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, 
   const int ntile = (a.L + lpw - 1) / lpw;
   const dim3 grid(ntile * a.S, cnt), blk(64 * nwaves);
   const size_t cross = ws > 1 ? (size_t)(ws - 1) * NT * 4 * 64 * sizeof(float) : 0;
-  // two staged blocks of 4 chunks per workgroup (wsplit = 1) / of one chunk per wave (wsplit > 1): HybStage::STB
+  // two staged blocks of NMFK_HYB_CPB chunks per workgroup (wsplit = 1) / of one chunk per wave (wsplit > 1): HybStage::STB
   const size_t chunkb = 3 * (size_t)(ks / 8) * 256 + 4 * 256;
-  const size_t stage = ws > 1 ? (size_t)ws * 2 * chunkb : 2 * 4 * chunkb;
+  const size_t stage = ws > 1 ? (size_t)ws * 2 * chunkb : 2 * NMFK_HYB_CPB * chunkb;
   const size_t ldsb = sizeof(double) * 9 * 16 + std::max(cross, stage);
   if (ks == 8)
     hipLaunchKernelGGL((hyb_step_kernel<8, NT, NW, false>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
@@ -581,7 +585,7 @@ void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double w
   constexpr int NT = NMFK_HYB_NT, NW = NMFK_HYB_NW;
   const int lpw = 16 * NT * NW;  // = NMFK_TILE: the partials line up with sse_kernel's
   const dim3 grid((w.L + lpw - 1) / lpw, cnt), blk(64 * NW);
-  const size_t ldsb = sizeof(double) * 9 * 16 + 2 * 4 * 3 * (size_t)(ks / 8) * 256;  // two blocks of split planes
+  const size_t ldsb = sizeof(double) * 9 * 16 + 2 * NMFK_HYB_CPB * 3 * (size_t)(ks / 8) * 256;  // two blocks of split planes
   if (ks == 8)
     hipLaunchKernelGGL((hyb_step_kernel<8, NT, NW, true>), grid, blk, ldsb, s, w.arena, w.Xalt, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
   else

@@ -11,7 +11,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "hyb"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 A = NMFk.Context(0); A.set_X(X)
 B = NMFk.Context(0); B.set_X(X)
-ksA, R = [int(v) for v in os.environ.get("KSA", "2,3,5").split(",")], 4
+ksA, R = [int(v) for v in os.environ.get("KSA", "2,3,5").split(",")], int(os.environ.get("RA", "8"))
 seedsA = np.array([[NMFk.run_seed(11, k, r) for r in range(R)] for k in ksA], dtype=np.uint64)
 stop = False
 def burn():

@@ -7,7 +7,7 @@ os.environ.setdefault("NMFK_MERGE_PHASED", "0")
 import numpy as np
 import nmfk_jl_amd as NMFk, nmfk_oracle as oracle
 iters = int(sys.argv[1]); R = 8
-n, m = 700, 130
+n, m = int(os.environ.get("N", 700)), int(os.environ.get("M", 130))
 X = (0.05 + oracle.uniform_fill(33, 0, n * m)).reshape(n, m).astype(np.float32)
 ctx = NMFk.Context(0)
 ks = [2, 3, 5, 6, 8, 13, 16, 20]

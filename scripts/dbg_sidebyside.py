@@ -12,7 +12,7 @@ R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 n, m = (int(os.environ.get("N", 700)), int(os.environ.get("M", 130)))
 X = (0.05 + oracle.uniform_fill(33, 0, n * m)).reshape(n, m).astype(np.float32)
 ctx = NMFk.Context(0)
-ks = [2, 3, 5, 6, 8, 13, 16, 20]
+ks = [int(v) for v in os.environ.get("KS", "2,3,5,6,8,13,16,20").split(",")]
 seeds = np.array([[NMFk.run_seed(11, k, r) for r in range(R)] for k in ks], dtype=np.uint64)
 ref, bad, prev, badprev = None, {}, None, {}
 for rep in range(reps):

@@ -15,7 +15,7 @@ seeds = np.array([[NMFk.run_seed(11, k, r) for r in range(R)] for k in ks], dtyp
 os.environ["NMFK_STREAMS"] = "1"
 ctx.set_X(X); ref = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, maxbaditers=10 ** 9)
 del os.environ["NMFK_STREAMS"]
-for rep in range(6):
+for rep in range(int(os.environ.get('REPS', 6))):
     ctx.set_X(X); res = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, maxbaditers=10 ** 9)
     for k in (2, 3, 5):
         for f in ("H", "W"):

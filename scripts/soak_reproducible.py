@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Soak test of the SHIPPED schedules: the same sweep repeated, every repetition must reproduce the first bit for bit.
+  merged phased (8 restarts), all-MFMA merged (4 restarts), two-phase (16 restarts at 2048 x 512), per-rank (HYB=0)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import nmfk_jl_amd as NMFk
+ctx = NMFk.Context(0)
+def case(name, n, m, ks, R, iters, reps, env=None):
+    for k_, v_ in (env or {}).items(): os.environ[k_] = v_
+    X = np.asfortranarray(0.05 + ctx.fill_uniform(33, 0, n * m).reshape(m, n).T)
+    seeds = np.array([[NMFk.run_seed(11, k, r) for r in range(R)] for k in ks], dtype=np.uint64)
+    ref, bad, t0 = None, 0, time.time()
+    for rep in range(reps):
+        ctx.set_X(X)
+        res = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, maxbaditers=10 ** 9)
+        if ref is None:
+            ref, info = res, ctx.last_sweep_info(); continue
+        bad += any(not ((res[k]["W"] == ref[k]["W"]).all() and (res[k]["H"] == ref[k]["H"]).all() and (res[k]["objvalue"] == ref[k]["objvalue"]).all()) for k in ks)
+    for k_ in (env or {}): del os.environ[k_]
+    print(f"{name:34s} {n}x{m} R={R} iters={iters}: {bad} of {reps - 1} repetitions differ  ({time.time() - t0:.0f} s)  {info}", flush=True)
+ks = [2, 3, 5, 6, 8, 13, 16, 20]
+case("merged, two phases", 700, 130, ks, 8, 40, 200)
+case("merged, all ranks on the MFMA group", 700, 130, ks, 4, 40, 200)
+case("merged, two phases", 8192, 512, list(range(2, 17)), 8, 30, 40)
+case("merged, all on the MFMA group", 8192, 512, list(range(2, 17)), 4, 30, 40)
+case("two-phase sweep", 2048, 512, list(range(2, 17)), 16, 30, 40)
+case("two-phase sweep (bench shape)", 8192, 512, list(range(2, 17)), 32, 20, 12)
+case("packed-VALU only", 700, 130, ks, 8, 40, 100, {"NMFK_HYB": "0"})

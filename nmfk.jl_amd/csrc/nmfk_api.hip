@@ -531,9 +531,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   auto use_wide_k = [&](int k) { return wide_ok && k > 16; };
   // Ranks in [hyb_mink, 16]: split-operand MFMA half-step (nmfk_step_hyb.hip).  Its cost does not depend on the rank
   // and ONE instantiation serves all ranks, so its units share one launch group.  Two schedules use it:
-  //  * few restarts per rank (<= 8; a rank's share at 4-8 GPUs): a merged sweep, the ranks >= 6 as one group on it,
-  //    then one merged packed-VALU group of the small ranks (per-rank launches would be launch-bound); with <= 4
-  //    restarts every rank 2..16 joins the group and no packed-VALU launch is left;
+  //  * few restarts per rank (<= 8; a rank's share at 4-8 GPUs): the ranks >= 6 as one group on it, the small ranks
+  //    beside it on their per-rank packed-VALU launches; with <= 4 restarts every rank 2..16 joins the group and no
+  //    packed-VALU launch is left;
   //  * many restarts per rank: a TWO-PHASE sweep -- the ranks >= k0 run FIRST, as one group with the GPU to themselves
   //    (its fp32 MFMAs and the packed FMAs of the other ranks' kernels share the multipliers, so the two kinds must not
   //    run side by side), then the other ranks on their per-rank packed-VALU launches.
@@ -586,24 +586,28 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   }
   if (T.phases >= 0) hyb_phases = hyb_on && merge == 0 && T.phases != 0;
   if (hyb_mink < 0) hyb_mink = 5;
+  // The mixed-rank packed-VALU kernel (step_kernel_multi) is used only on request (NMFK_MERGE) and in fp64 compute: its
+  // fp32 instantiation gives run-to-run different results while split-operand MFMA kernels run on the same GPU -- from
+  // another stream, another context or another PROCESS ("Known hazard"; scripts/dbg_twoproc.sh) -- and the
+  // per-rank kernels, which do not, cost 3 % more in the few-restart sweeps it was made for.
+  const bool valu_merged = merge > 0 && (merge_env || f64);
   auto use_hyb_k = [&](int k) { return hyb_on && hyb_fits && k <= 16 && k >= hyb_mink; };
   // lane elements per workgroup (= per sum-table slot) of the half-step kernel a rank runs
   auto lane_tile = [&](int k, int ws) {
     if (ctx->sparse) return NMFK_TILE;
     if (use_wide_k(k)) return nmfk_mfma_wide_lane_tile(ws);
     if (use_hyb_k(k)) return nmfk_hyb_lane_tile(ws);
-    if (merge > 0 && k <= NMFK_MULTI_MAXK && !use_hyb_k(k)) return (ws > 1 ? 64 : NMFK_TILE) * NMFK_MULTI_LB;
+    if (valu_merged && k <= NMFK_MULTI_MAXK && !use_hyb_k(k)) return (ws > 1 ? 64 : NMFK_TILE) * NMFK_MULTI_LB;
     return (ws > 1 ? 64 : NMFK_TILE) * NMFK_LB_OF(nmfk_padded_k(k));
   };
   const int max_ws = T.max_wsplit;
   // phases of a two-phase sweep run one after the other, so each gets the geometry that fills the chip with ITS units
-  // Merged sweeps with a group on the split-operand MFMA kernel are phased too: the matrix-pipe groups first (that
-  // group and the ranks > 16), then the merged packed-VALU group.  Reason: packed-VALU results were seen to change
-  // (~1e-5 relative, run to run) while the MFMA group's objective kernel ran on the same CUs from another stream; the
-  // cause was not found ("Known hazard"), so kernels of the two kinds never share the GPU inside a sweep.
+  // When the mixed-rank packed-VALU kernel is REQUESTED beside a group on the split-operand MFMA kernel the sweep is
+  // phased too: the matrix-pipe groups first (that group and the ranks > 16), then the merged packed-VALU group -- the
+  // two kinds of kernel must not share the GPU ("Known hazard").
   bool any_hyb_k = false;
   for (int q = 0; q < nk; ++q) any_hyb_k = any_hyb_k || use_hyb_k(ks[q]);
-  const bool phased = hyb_phases || (merge > 0 && any_hyb_k && T.merge_phased);
+  const bool phased = hyb_phases || (valu_merged && any_hyb_k && T.merge_phased);
   auto phase_of_k = [&](int k) { return phased && !use_hyb_k(k) && !(merge > 0 && use_wide_k(k)) ? 1 : 0; };
   auto geometry = [&](int L, int D, int phase) {
     Geo g;
@@ -670,7 +674,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ulist.reserve(nunits);
   for (int oi = 0; oi < nk; ++oi) {
     const int q = order[oi], k = ks[q];
-    if (merge > 0 && k <= NMFK_MULTI_MAXK) continue;
+    if (merge > 0 && k <= NMFK_MULTI_MAXK && (use_hyb_k(k) || valu_merged)) continue;
     if (hyb_phases && use_hyb_k(k)) continue;
     // sparse X: one kernel instantiation serves every rank with the same number of lanes per lane element, so those
     // ranks share a launch group (31 per-rank launches of 16 units each left the GPU half empty: 33 -> 21 ms)
@@ -694,7 +698,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     }
     if (G.count > 0) groups.push_back(G);
   }
-  for (int g = 0; g < merge; ++g) {
+  for (int g = 0; g < (valu_merged ? merge : 0); ++g) {
     Group G{0, 0, (int)ulist.size(), 0, 0, phased ? 1 : 0};
     for (int oi = 0; oi < nk; ++oi) {
       const int q = order[oi];

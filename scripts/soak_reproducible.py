@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Soak test of the SHIPPED schedules: the same sweep repeated, every repetition must reproduce the first bit for bit.
-  merged phased (8 restarts), all-MFMA merged (4 restarts), two-phase (16 restarts at 2048 x 512), per-rank (HYB=0)."""
+"""Soak test of the SHIPPED schedules: the same sweep repeated, every repetition must reproduce the first bit for bit."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,10 +20,12 @@ def case(name, n, m, ks, R, iters, reps, env=None):
     for k_ in (env or {}): del os.environ[k_]
     print(f"{name:34s} {n}x{m} R={R} iters={iters}: {bad} of {reps - 1} repetitions differ  ({time.time() - t0:.0f} s)  {info}", flush=True)
 ks = [2, 3, 5, 6, 8, 13, 16, 20]
-case("merged, two phases", 700, 130, ks, 8, 40, 200)
-case("merged, all ranks on the MFMA group", 700, 130, ks, 4, 40, 200)
-case("merged, two phases", 8192, 512, list(range(2, 17)), 8, 30, 40)
-case("merged, all on the MFMA group", 8192, 512, list(range(2, 17)), 4, 30, 40)
+case("8 restarts: MFMA group + per-rank", 700, 130, ks, 8, 40, 200)
+case("4 restarts: all on the MFMA group", 700, 130, ks, 4, 40, 200)
+case("8 restarts: MFMA group + per-rank", 8192, 512, list(range(2, 17)), 8, 30, 40)
+case("4 restarts: all on the MFMA group", 8192, 512, list(range(2, 17)), 4, 30, 40)
 case("two-phase sweep", 2048, 512, list(range(2, 17)), 16, 30, 40)
 case("two-phase sweep (bench shape)", 8192, 512, list(range(2, 17)), 32, 20, 12)
+case("8 restarts, 400 repetitions", 700, 130, ks, 8, 40, 400)
+case("requested merged kernel, phased", 700, 130, ks, 8, 40, 100, {"NMFK_HYB": "1", "NMFK_HYB_MINK": "6", "NMFK_MERGE": "1"})
 case("packed-VALU only", 700, 130, ks, 8, 40, 100, {"NMFK_HYB": "0"})

@@ -17,7 +17,8 @@ seeds = np.array([[NMFk.run_seed(11, k, r) for r in range(R)] for k in ks], dtyp
 ref, bad, prev, badprev = None, {}, None, {}
 for rep in range(reps):
     ctx.set_X(X)
-    res = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=int(os.environ.get("ITERS", 20)), maxbaditers=10 ** 9)
+    res = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=int(os.environ.get("ITERS", 20)), maxbaditers=10 ** 9,
+                       **({"compute": NMFk.COMPUTE_F64} if os.environ.get("COMPUTE") == "f64" else {}))
     if ref is None:
         ref = res; print(ctx.last_sweep_info()); continue
     for k in ks:

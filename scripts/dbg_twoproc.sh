@@ -18,5 +18,5 @@ print("burner: sweeps", nsw, ctx.last_sweep_info(), flush=True)
 PY
 BURN=$!
 sleep 8
-NMFK_HYB=0 KS=2,3,5 timeout -k 5 100 python scripts/dbg_sidebyside.py ${REPS:-400} ${RCHK:-4} 2>&1 | tail -2
+NMFK_HYB=0 KS=${CHK_KS:-2,3,5} timeout -k 5 100 python scripts/dbg_sidebyside.py ${REPS:-400} ${RCHK:-4} 2>&1 | tail -2
 wait $BURN

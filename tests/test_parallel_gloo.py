@@ -134,3 +134,89 @@ def test_single_process_passthrough(oracle):
     params = NMFk.default_params(maxiter=10)
     res = NMFk.parallel.sharded_sweep(_oracle_sweep(X), [2], 2, seeds, None, None, params, 5, 4)
     assert res[2]["W"].shape == (2, 5, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# execute_run's solution filters on the GATHERED results of two ranks (Exec:552-596, 640-658), incl. the lean exchange
+# (need_all_W=False: a rank holds the W of its own restarts and of the best one only).  The clustering / silhouette /
+# fit calls of the post-processing go to a stand-in context built on the CPU oracle (tests may use it); on the GPU box
+# the same host code runs with the real Context (tests/test_gpu_branches.py).
+# ---------------------------------------------------------------------------------------------------------
+class _OracleCtx:
+    nan_count = 0
+
+    def __init__(self, oracle, X):
+        self.o, self.X = oracle, X
+
+    def cluster_silhouette(self, Hs):
+        labels, cent = self.o.clustersolutions(list(Hs), 32)
+        _, ps, cs = self.o.finalize_silhouettes(list(Hs), labels, 32)
+        return labels, cent, ps, cs
+
+    def cluster_stats(self, Ws, Hs, labels):
+        return self.o.cluster_stats(list(Ws), list(Hs), labels)
+
+    def frobenius(self, W, H):
+        return self.o.frobenius(self.X, W, H)
+
+
+_FILTER_CASES = [dict(acceptratio=0.5), dict(acceptfactor=1.5), dict(best=False), dict(best=False, acceptratio=0.75),
+                 dict(nanaction="removed")]
+
+
+def _filter_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import warnings
+    import torch.distributed as dist
+    import nmfk_jl_amd as NMFk
+    import nmfk_oracle as oracle
+
+    E = sys.modules[NMFk.execute.__module__]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        n, m, k, R = 24, 10, 3, 6
+        W0 = oracle.uniform_fill(71, 0, n * k).reshape(n, k)
+        H0 = oracle.uniform_fill(72, 0, k * m).reshape(k, m)
+        X = (W0 @ H0 + 0.05 * oracle.uniform_fill(73, 0, n * m).reshape(n, m)).astype(np.float32)
+        seeds = np.array([[NMFk.run_seed(9, k, r) for r in range(R)]], dtype=np.uint64)
+        params = NMFk.default_params(maxiter=80, maxbaditers=10 ** 9)
+        out = []
+        for opts in _FILTER_CASES:
+            lean = opts.get("best", True)  # Exec:655-658: best=true needs the W of the best restart only
+            res = NMFk.parallel.sharded_sweep(_oracle_sweep(X), [k], R, seeds, None, None, params, n, m, need_all_W=not lean)[k]
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                Wa, Ha, phi, sil, aic, extra = E._execute_run_post(_OracleCtx(oracle, X), X, k, R, res, **opts)
+            out.append(dict(Wa=np.asarray(Wa), Ha=np.asarray(Ha), phi=phi, sil=sil, aic=aic, labels=np.asarray(extra["labels"]),
+                            idxsort=np.asarray(extra["idxsort"])))
+        q.put((rank, X, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_execute_run_filters_on_two_ranks(oracle):
+    import nmfk_jl_amd as NMFk
+
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_filter_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, X, a), (_, _, b) = got
+    n, m = X.shape
+    k, R = 3, 6
+    inits = [oracle.init_factors(NMFk.run_seed(9, k, r), n, m, k) for r in range(R)]
+    for opts, ra, rb in zip(_FILTER_CASES, a, b):
+        for key in ra:  # every rank reaches the same answer ...
+            np.testing.assert_array_equal(np.asarray(ra[key]), np.asarray(rb[key]))
+        ref = oracle.execute_run(X, k, R, inits, maxiter=80, maxbaditers=10 ** 9, **opts)  # ... the unsharded one
+        assert (ra["idxsort"] == ref["idxsort"]).all() and (ra["labels"] == ref["labels"]).all(), opts
+        assert abs(ra["phi"] - ref["phi"]) <= 1e-5 * ref["phi"] and abs(ra["sil"] - ref["minsilhouette"]) <= 1e-5
+        np.testing.assert_allclose(ra["Wa"] @ ra["Ha"], ref["Wa"] @ ref["Ha"], rtol=1e-4, atol=1e-6)

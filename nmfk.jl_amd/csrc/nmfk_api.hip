@@ -98,7 +98,8 @@ struct Sampler {
 //   NMFK_MFMA_WIDE    0: ranks > 16 on the packed-VALU kernel instead of the all-MFMA one
 //   NMFK_HYB          0 / 1: split-operand MFMA half-step off / on for the ranks >= NMFK_HYB_MINK (default: automatic)
 //   NMFK_HYB_GROUPS   mixed-rank launch groups of that kernel in merged sweeps (1)
-//   NMFK_MERGE        g: the ranks <= 16 share g mixed-rank packed-VALU launch groups (default: by restarts per rank)
+//   NMFK_MERGE        g: the ranks <= 16 share g mixed-rank launch groups (default: by restarts per rank; the packed-VALU
+//                     form exists for fp64 compute only unless built with NMFK_WITH_MERGED_F32)
 //   NMFK_HYB_PHASES   0 / 1: force the one-phase / two-phase sweep
 //   NMFK_MAX_WSPLIT   4 / 8: waves of a workgroup that may split a loop range
 //   NMFK_MFMA_SSE, NMFK_HYB_SSE   0: monitored objective of the MFMA groups on the packed-VALU objective kernel
@@ -586,11 +587,13 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   }
   if (T.phases >= 0) hyb_phases = hyb_on && merge == 0 && T.phases != 0;
   if (hyb_mink < 0) hyb_mink = 5;
-  // The mixed-rank packed-VALU kernel (step_kernel_multi) is used only on request (NMFK_MERGE) and in fp64 compute: its
-  // fp32 instantiation gives run-to-run different results while split-operand MFMA kernels run on the same GPU -- from
-  // another stream, another context or another PROCESS ("Known hazard"; scripts/dbg_twoproc.sh) -- and the
-  // per-rank kernels, which do not, cost 3 % more in the few-restart sweeps it was made for.
-  const bool valu_merged = merge > 0 && (merge_env || f64);
+  // The mixed-rank packed-VALU kernel (step_kernel_multi) serves fp64 compute only.  Its fp32 instantiation returns
+  // different results while ANY wave on the same CU issues gfx950's 128-bit-operand matrix instructions -- our MFMA
+  // group on another stream, or a bf16 GEMM of another process ("Known hazard";
+  // profiles/r02/merged_kernel_hazard.txt) -- and is not built unless NMFK_WITH_MERGED_F32 is set at compile time
+  // (then NMFK_MERGE requests it).  The per-rank kernels, which are not affected, cost 3 % more in the few-restart
+  // sweeps it was made for.
+  const bool valu_merged = merge > 0 && (f64 || (merge_env && NMFK_WITH_MERGED_F32 != 0));
   auto use_hyb_k = [&](int k) { return hyb_on && hyb_fits && k <= 16 && k >= hyb_mink; };
   // lane elements per workgroup (= per sum-table slot) of the half-step kernel a rank runs
   auto lane_tile = [&](int k, int ws) {
@@ -1023,8 +1026,10 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_step_hyb_f32(hs, d_hs, G.hyb, G.begin, G.count, gs);
         else if (G.kp == 0 && f64)
           nmfk_launch_step_multi_f64(hs, d_hs, G.begin, G.count, gs);
+#if NMFK_WITH_MERGED_F32
         else if (G.kp == 0)
           nmfk_launch_step_multi_f32(hs, d_hs, G.begin, G.count, gs);
+#endif
         else if (f64)
           nmfk_launch_step_f64(hs, d_hs, G.kp, G.begin, G.count, gs);
         else if (use_wide(G))
@@ -1050,8 +1055,10 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_step_hyb_f32(ws, d_ws, G.hyb, G.begin, G.count, gs);
         else if (G.kp == 0 && f64)
           nmfk_launch_step_multi_f64(ws, d_ws, G.begin, G.count, gs);
+#if NMFK_WITH_MERGED_F32
         else if (G.kp == 0)
           nmfk_launch_step_multi_f32(ws, d_ws, G.begin, G.count, gs);
+#endif
         else if (f64)
           nmfk_launch_step_f64(ws, d_ws, G.kp, G.begin, G.count, gs);
         else if (use_wide(G))

@@ -551,6 +551,7 @@ __global__ __launch_bounds__(2 * NMFK_TILE, NMFK_MINWAVES(KP)) void step_kernel(
   step_body<KP, LB, NANS>(arena, X, gp, runs + u, it, lds, uf ? blockIdx.y : blockIdx.x);
 }
 
+#if !defined(NMFK_IS_F32) || NMFK_WITH_MERGED_F32  // (fp32: see NMFK_WITH_MERGED_F32)
 // One launch for units of DIFFERENT ranks (all <= 16, so that they share the lane tile 64/256 * NMFK_LB): used when a
 // sweep has so few restarts per rank that per-rank launches leave the loop launch-bound (strong scaling over many
 // GPUs).  The register allocation is that of the widest case, which is irrelevant when the chip is not full anyway.
@@ -582,6 +583,7 @@ __global__ __launch_bounds__(2 * NMFK_TILE, NMFK_MULTI_MINWAVES) void step_kerne
     default: break;
   }
 }
+#endif
 
 #ifdef NMFK_IS_F32
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -1693,6 +1695,7 @@ void NMFK_NAME(nmfk_launch_step)(const NmfkStepArgs &a, const NmfkStepArgs *darg
   NMFK_DISPATCH_KP(kp, NMFK_LAUNCH_CASE)
 }
 
+#if !defined(NMFK_IS_F32) || NMFK_WITH_MERGED_F32
 void NMFK_NAME(nmfk_launch_step_multi)(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int u0, int cnt, hipStream_t s) {
   constexpr int LB = NMFK_MULTI_LB;
   const int ws = a.wsplit;
@@ -1707,6 +1710,7 @@ void NMFK_NAME(nmfk_launch_step_multi)(const NmfkStepArgs &a, const NmfkStepArgs
   else
     hipLaunchKernelGGL((step_kernel_multi<false>), grid, blk, ldsb, s, a.arena, a.X, a.runs, a.state, dargs, a.it, u0, uf);
 }
+#endif
 
 #ifdef NMFK_IS_F32
 // all-MFMA half-step for 16 < kp <= 64 (fp32, no missing data, D >= 16)

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Which CUs do the masks of scripts/dbg_cumask.sh select?  (scratch/cu_map.hip)
+cd $(dirname $0)/..
+echo "== no mask"; ./scratch/cu_map
+echo "== 0:0-127"; HSA_CU_MASK=0:0-127 ./scratch/cu_map
+echo "== 0:128-255"; HSA_CU_MASK=0:128-255 ./scratch/cu_map
+echo "== even CUs"; HSA_CU_MASK=0:0-31,64-95,128-159,192-223 ./scratch/cu_map
+echo "== odd CUs"; HSA_CU_MASK=0:32-63,96-127,160-191,224-255 ./scratch/cu_map
+echo "== 0:0-31"; HSA_CU_MASK=0:0-31 ./scratch/cu_map

@@ -27,5 +27,5 @@ case("4 restarts: all on the MFMA group", 8192, 512, list(range(2, 17)), 4, 30, 
 case("two-phase sweep", 2048, 512, list(range(2, 17)), 16, 30, 40)
 case("two-phase sweep (bench shape)", 8192, 512, list(range(2, 17)), 32, 20, 12)
 case("8 restarts, 400 repetitions", 700, 130, ks, 8, 40, 400)
-case("requested merged kernel, phased", 700, 130, ks, 8, 40, 100, {"NMFK_HYB": "1", "NMFK_HYB_MINK": "6", "NMFK_MERGE": "1"})
+case("old request for the merged kernel (not built: per-rank)", 700, 130, ks, 8, 40, 100, {"NMFK_HYB": "1", "NMFK_HYB_MINK": "6", "NMFK_MERGE": "1"})
 case("packed-VALU only", 700, 130, ks, 8, 40, 100, {"NMFK_HYB": "0"})

@@ -5,7 +5,7 @@ echo "== beside the bf16 MFMA burner"
 timeout -k 5 170 ./scratch/burner 0 ${SECS:-100} &
 BURN=$!
 sleep 3
-timeout -k 5 160 ./scratch/pk_victim ${REPS:-200}
+timeout -k 5 160 ./scratch/pk_victim ${REPS:-200} $ONLY
 kill $BURN 2>/dev/null; wait $BURN
 echo "== alone"
-timeout -k 5 100 ./scratch/pk_victim 60
+timeout -k 5 100 ./scratch/pk_victim 60 $ONLY

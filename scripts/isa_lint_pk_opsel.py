@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""ISA lint for the gfx950 hazard of DESIGN.md ("Known hazard"): a packed fp32 VALU instruction (v_pk_fma_f32,
+v_pk_mul_f32, v_pk_add_f32) whose src1 is a VGPR pair read with op_sel[1] = 1 -- the low result half takes the ODD
+register of src1 -- returns wrong low halves in the lanes 48-63 while another wave on the CU issues 128-bit-operand
+matrix instructions (scratch/pk_victim.hip G=1, G=4; scratch/burner.hip mode 0).  The same select on src0, src2 or on an
+SGPR pair, and op_sel_hi, are safe.  This script compiles every kernel TU of libnmfk_hip.so to gfx950 assembly and lists
+the kernels that contain the unsafe form.  Exit code 1 if any does.   usage: isa_lint_pk_opsel.py [extra hipcc flags]"""
+import os, re, subprocess, sys, tempfile
+from concurrent.futures import ThreadPoolExecutor
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "nmfk.jl_amd", "csrc")
+TUS = ["nmfk_step_f32.hip", "nmfk_step_f64.hip", "nmfk_step_hyb.hip", "nmfk_cluster.hip", "nmfk_kmeans.hip", "nmfk_api.hip", "nmfk_comm.hip"]
+VF = {"nmfk_step_f32.hip", "nmfk_step_hyb.hip"}  # (Makefile: -mllvm -amdgpu-mfma-vgpr-form)
+PK = re.compile(r"^\s*(v_pk_(?:fma|mul|add)_f32)\s+(.*)$")
+
+
+def unsafe(line):
+    m = PK.match(line)
+    if not m:
+        return False
+    ops = m.group(2)
+    sel = re.search(r"\bop_sel:\[([01,]+)\]", ops)
+    if not sel:
+        return False
+    bits = sel.group(1).split(",")
+    if len(bits) < 2 or bits[1] != "1":
+        return False
+    args = [a.strip() for a in re.split(r",\s*(?![^\[]*\])", ops.split(" op_sel")[0])]
+    return len(args) >= 3 and args[2].startswith("v")  # dst, src0, src1, ...
+
+
+def scan(path):
+    out, cur = {}, None
+    for line in open(path):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = m.group(1)
+        elif line.startswith(".Lfunc_end"):
+            cur = None
+        elif cur and unsafe(line):
+            out.setdefault(cur, []).append(line.strip())
+    return out
+
+
+def compile_tu(tu, extra, tmp):
+    s = os.path.join(tmp, tu + ".s")
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--cuda-device-only", "-S"] + extra
+    if tu in VF:
+        cmd += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+    subprocess.run(cmd + [os.path.join(CSRC, tu), "-o", s], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return tu, scan(s)
+
+
+def main():
+    extra = sys.argv[1:]
+    bad = 0
+    with tempfile.TemporaryDirectory() as tmp, ThreadPoolExecutor(4) as ex:
+        for tu, hits in ex.map(lambda t: compile_tu(t, extra, tmp), TUS):
+            n = sum(len(v) for v in hits.values())
+            print(f"{tu}: {n} unsafe packed instruction(s) in {len(hits)} kernel(s)")
+            for k, v in hits.items():
+                name = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()
+                print(f"    {name[:110]}: {len(v)}   e.g. {v[0]}")
+            bad += n
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

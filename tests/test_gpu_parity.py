@@ -995,11 +995,12 @@ def test_robustkmeans_rows_of_W_at_bench_size(NMFk, ctx, oracle):
 def test_merged_sweep_is_bitwise_reproducible_run_to_run(NMFk, oracle, forced_merged_kernel):
     """A sweep with few restarts per rank -- a split-operand MFMA group, a k > 16 group and the small ranks -- repeated:
     every repetition must reproduce the first bit for bit.  Regression test for the hazard met in round 2 (DESIGN.md,
-    "Known hazard"): the fp32 mixed-rank packed-VALU kernel returns different factors while a wave on the same CU issues
-    gfx950's 128-bit-operand matrix instructions (our MFMA group, or any bf16 GEMM of another process).  The library no
-    longer contains that kernel: the small ranks run on their per-rank launches beside the group, one phase -- also when
-    the old request for it is made (NMFK_HYB=1 NMFK_MERGE=1).  scripts/dbg_*.sh and scratch/burner.hip keep the
-    reproducers (they need a build with -DNMFK_WITH_MERGED_F32=1)."""
+    "Known hazard"): packed fp32 instructions with op_sel[1] = 1 on a VGPR src1 return wrong low halves in the lanes
+    48-63 while a wave on the same CU issues gfx950's 128-bit-operand matrix instructions (our MFMA group, or any bf16
+    GEMM of another process); first seen in the fp32 mixed-rank packed-VALU kernel.  The generated code no longer
+    contains that form (tests/test_isa_lint.py) and the mixed-rank fp32 kernel is not built by default: the small ranks
+    run on their per-rank launches beside the group, one phase -- also when the old request for it is made
+    (NMFK_HYB=1 NMFK_MERGE=1).  scripts/dbg_*.sh, scratch/burner.hip and scratch/pk_victim.hip keep the reproducers."""
     n, m = 700, 130
     X = (0.05 + oracle.uniform_fill(33, 0, n * m)).reshape(n, m).astype(np.float32)
     ctx = NMFk.Context(0)

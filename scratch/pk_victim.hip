@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void victim_use(float *out, const float *in, i
 //   0 v_pk_fma_f32 op_sel_hi:[1,0,1] (VGPR)      1 v_pk_fma_f32 op_sel:[0,1,0] on a VGPR src1      2 v_pk_fma_f32 op_sel:[1,0,0] on a VGPR src0
 //   3 v_pk_fma_f32 op_sel:[0,1,0] on an SGPR src1  4 v_pk_mul_f32 op_sel:[0,1]  (VGPR)              5 v_pk_add_f32 op_sel:[0,1] (VGPR)
 //   6 v_pk_fma_f32 op_sel:[0,0,1] on the VGPR accumulator          7 v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1] (swap the halves of src1)
+//   8 v_pk_add_f32 op_sel:[0,1] on a VGPR src1                     9 v_pk_mov_b32 op_sel:[1,0] op_sel_hi:[0,1]
 template <int G>
 __global__ __launch_bounds__(256) void victim_sel(float *out, const float *in, int iters) {
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -275,6 +276,12 @@ __global__ __launch_bounds__(256) void victim_sel(float *out, const float *in, i
         asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[1,0]" : "+v"(acc[j]) : "v"(t));
       }
       if (G == 6) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "+v"(acc[j]) : "v"(a[j]), "v"(b[j]));
+      if (G == 8) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(acc[j]) : "v"(a[j]), "v"(b[j]));
+      if (G == 9) {
+        f32x2 t;
+        asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a[j]), "v"(b[j]));
+        asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[j]) : "v"(t));
+      }
       if (G == 7) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(acc[j]) : "v"(a[j]), "v"(b[j]));
     }
   }
@@ -303,7 +310,7 @@ static void run(const char *name, float *d_out, const float *d_in, int nwg, int 
     else if (rcpn == 101)
       hipLaunchKernelGGL((victim_ld<1>), dim3(nwg), dim3(256), 0, 0, d_out, d_in, iters);
 #define SELCASE(G) else if (rcpn == 300 + G) hipLaunchKernelGGL((victim_sel<G>), dim3(nwg), dim3(256), 0, 0, d_out, d_in, iters);
-    SELCASE(0) SELCASE(1) SELCASE(2) SELCASE(3) SELCASE(4) SELCASE(5) SELCASE(6) SELCASE(7)
+    SELCASE(0) SELCASE(1) SELCASE(2) SELCASE(3) SELCASE(4) SELCASE(5) SELCASE(6) SELCASE(7) SELCASE(8) SELCASE(9)
 #undef SELCASE
 #define USECASE(F) else if (rcpn == 200 + F) hipLaunchKernelGGL((victim_use<F>), dim3(nwg), dim3(256), 0, 0, d_out, d_in, iters);
     USECASE(0) USECASE(1) USECASE(2) USECASE(4) USECASE(6) USECASE(8) USECASE(16) USECASE(24) USECASE(32) USECASE(10) USECASE(12) USECASE(28) USECASE(30)
@@ -380,5 +387,7 @@ int main(int argc, char **argv) {
   run<35, 1>("G=5: v_pk_add_f32 op_sel:[1,0] on a VGPR src0", d_out, d_in, nwg, iters, reps, 305);
   run<36, 1>("G=6: v_pk_fma_f32 op_sel:[0,0,1] on the VGPR accumulator", d_out, d_in, nwg, iters, reps, 306);
   run<37, 1>("G=7: v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1] (halves of src1 swapped)", d_out, d_in, nwg, iters, reps, 307);
+  run<38, 1>("G=8: v_pk_add_f32 op_sel:[0,1] on a VGPR src1", d_out, d_in, nwg, iters, reps, 308);
+  run<39, 1>("G=9: v_pk_mov_b32 op_sel:[1,0] op_sel_hi:[0,1]", d_out, d_in, nwg, iters, reps, 309);
   return 0;
 }

@@ -98,16 +98,15 @@ struct Sampler {
 //   NMFK_MFMA_WIDE    0: ranks > 16 on the packed-VALU kernel instead of the all-MFMA one
 //   NMFK_HYB          0 / 1: split-operand MFMA half-step off / on for the ranks >= NMFK_HYB_MINK (default: automatic)
 //   NMFK_HYB_GROUPS   mixed-rank launch groups of that kernel in merged sweeps (1)
-//   NMFK_MERGE        g: the ranks <= 16 share g mixed-rank launch groups (default: by restarts per rank; the packed-VALU
-//                     form exists for fp64 compute only unless built with NMFK_WITH_MERGED_F32)
+//   NMFK_MERGE        g: the ranks <= 16 share g mixed-rank packed-VALU launch groups (default: by restarts per rank)
 //   NMFK_HYB_PHASES   0 / 1: force the one-phase / two-phase sweep
 //   NMFK_MAX_WSPLIT   4 / 8: waves of a workgroup that may split a loop range
 //   NMFK_MFMA_SSE, NMFK_HYB_SSE   0: monitored objective of the MFMA groups on the packed-VALU objective kernel
 //   NMFK_STREAMS      concurrent rank-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1 prints the host's share of the loop
-//   NMFK_MERGE_PHASED 0: merged sweeps run their matrix-pipe groups and the packed-VALU group side by side again
+//   NMFK_MERGE_PHASED 1: merged sweeps run their matrix-pipe groups first and the packed-VALU group behind them (default: side by side)
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, hyb_groups = 1, merge = -1, phases = -1, max_wsplit = 8;
-  int wide_sse = 1, hyb_sse = 1, streams = -1, host_timing = 0, merge_phased = 1;
+  int wide_sse = 1, hyb_sse = 1, streams = -1, host_timing = 0, merge_phased = 0;
 };
 Tuning read_tuning() {
   Tuning t;
@@ -587,13 +586,10 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   }
   if (T.phases >= 0) hyb_phases = hyb_on && merge == 0 && T.phases != 0;
   if (hyb_mink < 0) hyb_mink = 5;
-  // The mixed-rank packed-VALU kernel (step_kernel_multi) serves fp64 compute only.  Its fp32 instantiation returns
-  // different results while ANY wave on the same CU issues gfx950's 128-bit-operand matrix instructions -- our MFMA
-  // group on another stream, or a bf16 GEMM of another process ("Known hazard";
-  // profiles/r02/merged_kernel_hazard.txt) -- and is not built unless NMFK_WITH_MERGED_F32 is set at compile time
-  // (then NMFK_MERGE requests it).  The per-rank kernels, which are not affected, cost 3 % more in the few-restart
-  // sweeps it was made for.
-  const bool valu_merged = merge > 0 && (f64 || (merge_env && NMFK_WITH_MERGED_F32 != 0));
+  // The ranks <= 16 that are not on the MFMA group share `merge` mixed-rank packed-VALU launch groups (step_kernel_multi)
+  // when the sweep has few restarts per rank.  (Round 2 met the gfx950 packed-fp32 hazard in this kernel first -- DESIGN.md,
+  // "Known hazard"; its generated code is free of the unsafe instruction form now and checked by tests/test_isa_lint.py.)
+  const bool valu_merged = merge > 0 && (f64 || NMFK_WITH_MERGED_F32 != 0);
   auto use_hyb_k = [&](int k) { return hyb_on && hyb_fits && k <= 16 && k >= hyb_mink; };
   // lane elements per workgroup (= per sum-table slot) of the half-step kernel a rank runs
   auto lane_tile = [&](int k, int ws) {
@@ -605,9 +601,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   };
   const int max_ws = T.max_wsplit;
   // phases of a two-phase sweep run one after the other, so each gets the geometry that fills the chip with ITS units
-  // When the mixed-rank packed-VALU kernel is REQUESTED beside a group on the split-operand MFMA kernel the sweep is
-  // phased too: the matrix-pipe groups first (that group and the ranks > 16), then the merged packed-VALU group -- the
-  // two kinds of kernel must not share the GPU ("Known hazard").
+  // NMFK_MERGE_PHASED=1 (A/B switch): a merged sweep runs its matrix-pipe groups first and the mixed-rank packed-VALU group
+  // behind them instead of side by side (slower: 140 vs 117 ms per 400 iterations at 4 restarts per rank).
   bool any_hyb_k = false;
   for (int q = 0; q < nk; ++q) any_hyb_k = any_hyb_k || use_hyb_k(ks[q]);
   const bool phased = hyb_phases || (valu_merged && any_hyb_k && T.merge_phased);

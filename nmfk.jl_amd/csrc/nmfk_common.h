@@ -201,10 +201,10 @@ static inline int nmfk_padded_k(int k) {
 #define NMFK_XBUF 1          // X entries through buffer loads (scalar address arithmetic); 0 = global loads
 #endif
 #ifndef NMFK_WITH_MERGED_F32
-#define NMFK_WITH_MERGED_F32 0  // the fp32 instantiation of the mixed-rank packed-VALU kernel is NOT built by default: its results
-                                // change while any wave on the same CU issues gfx950's 128-bit-operand matrix instructions
-                                // (our MFMA group, a bf16 GEMM of another process, ...; DESIGN.md "Known hazard",
-                                // profiles/r02/merged_kernel_hazard.txt).  1 builds it for the scripts that demonstrate that.
+#define NMFK_WITH_MERGED_F32 1  // 0: build libnmfk_hip.so without the fp32 instantiation of the mixed-rank packed-VALU kernel.
+                                // (It is where the gfx950 packed-fp32 hazard of DESIGN.md was first seen; with the
+                                // broadcast-first operand rule of nmfk_step_impl.h its code no longer contains the unsafe
+                                // instruction form -- scripts/isa_lint_pk_opsel.py, tests/test_isa_lint.py.)
 #endif
 #ifndef NMFK_MULTI_MAXK
 #define NMFK_MULTI_MAXK 16    // widest rank served by the mixed-rank kernel (8, 12, 14 or 16); wider ranks keep their own launches

@@ -348,7 +348,13 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
       // (2 or 4 independent partial sums instead of one chain of KP dependent FMAs: no gain measured)
       T2 pp[1] = {splat2((T)0)};
 #pragma unroll
-      for (int c = 0; c < KP; ++c) pp[0] = fma2(splat2(bv[c]), ae[EP ? c : 0], pp[0]);
+      for (int c = 0; c < KP; ++c) {
+#ifdef NMFK_UNSAFE_OPERAND_ORDER  // (scripts/build_hazard_lib.sh: the order that makes hipcc emit the unsafe select)
+        pp[0] = fma2(ae[EP ? c : 0], splat2(bv[c]), pp[0]);
+#else
+        pp[0] = fma2(splat2(bv[c]), ae[EP ? c : 0], pp[0]);
+#endif
+      }
       T2 p2 = pp[0];
       T2 x2 = {(T)xf[0], (T)xf[LB - 1]};
       if (NANS) {

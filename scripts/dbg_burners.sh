@@ -2,8 +2,7 @@
 # Known hazard: the fp32 merged packed-VALU kernel (checker process: must reproduce its first result bit for
 # bit) beside SYNTHETIC neighbours that keep one hardware unit busy each (scratch/burner.hip).
 cd $(dirname $0)/..
-# the kernel under test is not in the default build: scripts/build_hazard_lib.sh
-[ -z "$NMFK_HIP_LIB" ] && [ -e nmfk.jl_amd/libnmfk_hip_merged_f32.so ] && export NMFK_HIP_LIB=$PWD/nmfk.jl_amd/libnmfk_hip_merged_f32.so
+# (to see the hazard again: build the library from a commit before the broadcast-first operand rule, or with the rule reverted)
 for spec in "burner 0" "burner_vf 0" "burner 1" "burner_vf 1" "burner 2" "burner 3" "burner 4" "burner 5"; do
   set -- $spec
   echo "== $1 mode $2"

@@ -8,8 +8,7 @@
 #             scalar caches)                        (mask bit i: XCD i%8, shader engine (i/8)%4, CU i/32 -- scripts/dbg_cumap.sh)
 #   nows      no masks, checker without the loop split over the waves of a workgroup (NMFK_MAX_WSPLIT=1)
 cd $(dirname $0)/..
-# the kernel under test is not in the default build: scripts/build_hazard_lib.sh
-[ -z "$NMFK_HIP_LIB" ] && [ -e nmfk.jl_amd/libnmfk_hip_merged_f32.so ] && export NMFK_HIP_LIB=$PWD/nmfk.jl_amd/libnmfk_hip_merged_f32.so
+# (to see the hazard again: build the library from a commit before the broadcast-first operand rule, or with the rule reverted)
 mode=${1:-none}
 case $mode in
   none) CM=""; BM="";;

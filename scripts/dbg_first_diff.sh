@@ -2,8 +2,7 @@
 # usage: dbg_first_diff.sh <burner mode> <label> [ENV=... for the checker]   (checker: scripts/dbg_first_diff.py)
 # The checker computes its reference alone, then the burner starts (another process) and the repetitions begin.
 cd $(dirname $0)/..
-# the kernel under test is not in the default build: scripts/build_hazard_lib.sh
-[ -z "$NMFK_HIP_LIB" ] && [ -e nmfk.jl_amd/libnmfk_hip_merged_f32.so ] && export NMFK_HIP_LIB=$PWD/nmfk.jl_amd/libnmfk_hip_merged_f32.so
+# (to see the hazard again: build the library from a commit before the broadcast-first operand rule, or with the rule reverted)
 mode=$1; label=$2; shift 2
 echo "== $label  (burner mode $mode; $*)"
 hs=/tmp/nmfk_hs_$$; rm -f $hs.ref $hs.go

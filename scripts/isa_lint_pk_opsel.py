@@ -26,7 +26,7 @@ def unsafe(line):
     if len(bits) < 2 or bits[1] != "1":
         return False
     args = [a.strip() for a in re.split(r",\s*(?![^\[]*\])", ops.split(" op_sel")[0])]
-    return len(args) >= 3 and args[2].startswith("v")  # dst, src0, src1, ...
+    return len(args) >= 3 and re.match(r"v(\[|\d)", args[2]) is not None  # dst, src0, src1, ...: a VGPR (not vcc)
 
 
 def scan(path):

@@ -34,13 +34,14 @@ def sweep(name, n, m, ks, R, iters, reps, **kw):
     cases.append((f"{name}  {n}x{m} R={R} iters={iters}", run, reps))
 
 ks = [2, 3, 5, 6, 8, 13, 16, 20]
-sweep("8 restarts: MFMA group + per-rank", 700, 130, ks, 8, 40, 150)
+sweep("8 restarts: MFMA group + merged VALU", 700, 130, ks, 8, 40, 150)
 sweep("4 restarts: all on the MFMA group", 700, 130, ks, 4, 40, 150)
 sweep("32 restarts: two phases", 2048, 512, list(range(2, 17)), 32, 20, 20)
 sweep("fp64 compute (merged fp64 kernel)", 700, 130, [2, 3, 5, 8], 4, 20, 60, compute=NMFk.COMPUTE_F64)
-sweep("8 restarts, bench shape", 8192, 512, list(range(2, 17)), 8, 20, 12)
+sweep("8 restarts, bench shape: MFMA group + merged VALU", 8192, 512, list(range(2, 17)), 8, 20, 12)
 sweep("32 restarts, bench shape: two phases", 8192, 512, list(range(2, 17)), 32, 10, 6)
 sweep("wide ranks", 1024, 256, [20, 32, 48, 64], 4, 20, 40)
+sweep("6 restarts, ranks 2:12 (merged VALU beside the group)", 1500, 300, list(range(2, 13)), 6, 30, 40)
 
 def sparse_case():
     n, m = 6000, 700

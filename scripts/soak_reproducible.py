@@ -20,12 +20,13 @@ def case(name, n, m, ks, R, iters, reps, env=None):
     for k_ in (env or {}): del os.environ[k_]
     print(f"{name:34s} {n}x{m} R={R} iters={iters}: {bad} of {reps - 1} repetitions differ  ({time.time() - t0:.0f} s)  {info}", flush=True)
 ks = [2, 3, 5, 6, 8, 13, 16, 20]
-case("8 restarts: MFMA group + per-rank", 700, 130, ks, 8, 40, 200)
+case("8 restarts: MFMA group + merged VALU", 700, 130, ks, 8, 40, 200)
 case("4 restarts: all on the MFMA group", 700, 130, ks, 4, 40, 200)
-case("8 restarts: MFMA group + per-rank", 8192, 512, list(range(2, 17)), 8, 30, 40)
+case("8 restarts: MFMA group + merged VALU", 8192, 512, list(range(2, 17)), 8, 30, 40)
 case("4 restarts: all on the MFMA group", 8192, 512, list(range(2, 17)), 4, 30, 40)
 case("two-phase sweep", 2048, 512, list(range(2, 17)), 16, 30, 40)
 case("two-phase sweep (bench shape)", 8192, 512, list(range(2, 17)), 32, 20, 12)
 case("8 restarts, 400 repetitions", 700, 130, ks, 8, 40, 400)
-case("old request for the merged kernel (not built: per-rank)", 700, 130, ks, 8, 40, 100, {"NMFK_HYB": "1", "NMFK_HYB_MINK": "6", "NMFK_MERGE": "1"})
+case("merged kernel on request, side by side", 700, 130, ks, 8, 40, 100, {"NMFK_HYB": "1", "NMFK_HYB_MINK": "6", "NMFK_MERGE": "1"})
+case("merged kernel for ALL ranks <= 16", 700, 130, ks, 8, 40, 100, {"NMFK_HYB": "0", "NMFK_MERGE": "2"})
 case("packed-VALU only", 700, 130, ks, 8, 40, 100, {"NMFK_HYB": "0"})

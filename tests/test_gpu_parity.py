@@ -317,8 +317,8 @@ def test_mfma_group_monitored_objective(NMFk, ctx, oracle):
 @pytest.mark.parametrize("R", [4, 8])
 def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle, R):
     """Sweeps with <= 8 restarts per rank (a rank's share at 4-8 GPUs): by default the ranks kmin..16 run as ONE mixed-rank
-    launch group on the split-operand MFMA half-step (kmin = 2 up to 4 restarts, 6 above), smaller ranks beside it on
-    their per-rank packed-VALU kernels, wider ranks on their own kernels.  Against the oracle (same tolerance as
+    launch group on the split-operand MFMA half-step (kmin = 2 up to 4 restarts, 6 above), smaller ranks beside it as ONE
+    mixed-rank packed-VALU launch group, wider ranks on their own kernels.  Against the oracle (same tolerance as
     everywhere) and against the all-VALU grouping (NMFK_HYB=0)."""
     n, m = 700, 130
     X = (0.05 + oracle.uniform_fill(33, 0, n * m)).reshape(n, m).astype(np.float32)
@@ -329,7 +329,7 @@ def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle, R):
     a = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
     info = ctx.last_sweep_info()
     assert info["mfma_group_units"] == R * sum(kmin <= k <= 16 for k in ks), info
-    assert info["phases"] == 1 and info["merged_valu_groups"] == 0, info  # (the merged fp32 kernel is opt-in: Known hazard)
+    assert info["phases"] == 1 and info["merged_valu_groups"] == (0 if R <= 4 else 1), info
     os.environ["NMFK_HYB"] = "0"
     try:
         b = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
@@ -372,9 +372,7 @@ def test_up_to_four_restarts_all_ranks_on_the_mfma_group(NMFk, ctx, oracle):
 @pytest.mark.parametrize("compute", ["f32", "f64"])
 def test_merged_launch_groups_bitwise_equal(NMFk, ctx, oracle, compute):
     """Mixed-rank launches of the packed-VALU kernel (step_kernel_multi, NMFK_MERGE groups): same arithmetic per unit =>
-    results identical to per-rank launches bit for bit, for every grouping; missing data included.  The kernel serves
-    fp64 compute; its fp32 instantiation is not built (NMFK_WITH_MERGED_F32 = 0: DESIGN.md, Known hazard), so in fp32 the
-    request only regroups the matrix-pipe launches and must leave the results alone just the same."""
+    results identical to per-rank launches bit for bit, for every grouping; missing data included."""
     n, m = 700, 130
     X = (0.05 + oracle.uniform_fill(33, 0, n * m)).reshape(n, m).astype(np.float32)
     for nan in (False, True):
@@ -390,7 +388,7 @@ def test_merged_launch_groups_bitwise_equal(NMFk, ctx, oracle, compute):
             os.environ["NMFK_MERGE"] = mg
             try:
                 out[mg] = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=40, compute=cm)
-                assert ctx.last_sweep_info()["merged_valu_groups"] == (int(mg) if compute == "f64" else 0)
+                assert ctx.last_sweep_info()["merged_valu_groups"] == int(mg)
             finally:
                 del os.environ["NMFK_MERGE"]
         for mg in ("1", "2", "5"):
@@ -993,14 +991,14 @@ def test_robustkmeans_rows_of_W_at_bench_size(NMFk, ctx, oracle):
 
 @pytest.mark.parametrize("forced_merged_kernel", [False, True])
 def test_merged_sweep_is_bitwise_reproducible_run_to_run(NMFk, oracle, forced_merged_kernel):
-    """A sweep with few restarts per rank -- a split-operand MFMA group, a k > 16 group and the small ranks -- repeated:
-    every repetition must reproduce the first bit for bit.  Regression test for the hazard met in round 2 (DESIGN.md,
-    "Known hazard"): packed fp32 instructions with op_sel[1] = 1 on a VGPR src1 return wrong low halves in the lanes
-    48-63 while a wave on the same CU issues gfx950's 128-bit-operand matrix instructions (our MFMA group, or any bf16
-    GEMM of another process); first seen in the fp32 mixed-rank packed-VALU kernel.  The generated code no longer
-    contains that form (tests/test_isa_lint.py) and the mixed-rank fp32 kernel is not built by default: the small ranks
-    run on their per-rank launches beside the group, one phase -- also when the old request for it is made
-    (NMFK_HYB=1 NMFK_MERGE=1).  scripts/dbg_*.sh, scratch/burner.hip and scratch/pk_victim.hip keep the reproducers."""
+    """A sweep with few restarts per rank -- a split-operand MFMA group, a k > 16 group and the small ranks on the
+    mixed-rank packed-VALU kernel, all side by side -- repeated: every repetition must reproduce the first bit for bit.
+    Regression test for the hazard met in round 2 ("Known hazard"): packed fp32 instructions with
+    op_sel[1] = 1 on a VGPR src1 return wrong low halves in the lanes 48-63 while a wave on the same CU issues gfx950's
+    128-bit-operand matrix instructions (our MFMA group, or any bf16 GEMM of another process); this very combination
+    differed in 299 of 299 repetitions.  The generated code no longer contains that form (tests/test_isa_lint.py).
+    Default schedule and the explicit request (NMFK_HYB=1 NMFK_MERGE=1); scripts/dbg_*.sh, scratch/burner.hip and
+    scratch/pk_victim.hip keep the reproducers."""
     n, m = 700, 130
     X = (0.05 + oracle.uniform_fill(33, 0, n * m)).reshape(n, m).astype(np.float32)
     ctx = NMFk.Context(0)
@@ -1015,9 +1013,7 @@ def test_merged_sweep_is_bitwise_reproducible_run_to_run(NMFk, oracle, forced_me
             res = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=20, **NOSTOP)
             info = ctx.last_sweep_info()
             assert info["mfma_group_units"] == 4 * R, info
-            assert info["phases"] == 1 and info["merged_valu_groups"] == 0, info
-            if not forced_merged_kernel:
-                assert info["launch_groups"] == 5, info
+            assert info["phases"] == 1 and info["merged_valu_groups"] == 1 and info["launch_groups"] == 3, info
             if ref is None:
                 ref = res
                 continue

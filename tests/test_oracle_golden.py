@@ -108,7 +108,12 @@ def test_bss_notebook_known_answers(oracle, bss_X):
     assert obj2[0] >= 13.9385 and obj2[-1] <= 13.9392  # 'OF: min ... max ...' line, :221
     aic_notebook_convention = 2 * (15 * 2 + 2 * 5) + 75 * math.log(sse2 / 75)
     assert abs(aic_notebook_convention - (-46.21209)) < 5e-3  # X is only printed to 6 s.f.
-    assert abs(rob[1] - 0.9940184) < 5e-3  # k=2 silhouette, :258
+    # k=2 silhouette, :258.  What limits the agreement is NOT the 6-s.f. print of X (perturbing X within it moves the value
+    # by 7e-9) but the ten random restarts, whose Julia RNG stream cannot be reproduced here: other seeds of our generator
+    # give 0.9867..0.9911.  With seed 2021 the restatement lands 5.8e-6 from the notebook's value; pinned to that.
+    assert abs(rob[1] - 0.9940184) < 2e-5
+    for s in (1, 2, 3):
+        assert abs(oracle.execute(X, range(2, 3), 10, seed=s)[3][1] - 0.9940184) < 1e-2
     assert rob[2] > 0.5 and rob[4] < 0  # k=3 robust, k=5 not (:259-261; examples/bss.jl:20-21 criterion)
     # every run stops by the stagnation rule well before maxiter on this toy (240-730 iterations)
     for nk in range(2, 6):

@@ -2,6 +2,7 @@
 # Known hazard: the fp32 merged packed-VALU kernel (checker process: must reproduce its first result bit for
 # bit) beside SYNTHETIC neighbours that keep one hardware unit busy each (scratch/burner.hip).
 cd $(dirname $0)/..
+for b in burner pk_victim cu_map uniform_vload; do [ -x scratch/$b ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scratch/$b.hip -o scratch/$b 2>/dev/null; done
 # (to see the hazard again: build the library from a commit before the broadcast-first operand rule, or with the rule reverted)
 for spec in "burner 0" "burner_vf 0" "burner 1" "burner_vf 1" "burner 2" "burner 3" "burner 4" "burner 5"; do
   set -- $spec

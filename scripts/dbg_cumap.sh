@@ -1,6 +1,7 @@
 #!/bin/bash
 # Which CUs do the masks of scripts/dbg_cumask.sh select?  (scratch/cu_map.hip)
 cd $(dirname $0)/..
+for b in burner pk_victim cu_map uniform_vload; do [ -x scratch/$b ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scratch/$b.hip -o scratch/$b 2>/dev/null; done
 echo "== no mask"; ./scratch/cu_map
 echo "== 0:0-127"; HSA_CU_MASK=0:0-127 ./scratch/cu_map
 echo "== 0:128-255"; HSA_CU_MASK=0:128-255 ./scratch/cu_map

@@ -8,6 +8,7 @@
 #             scalar caches)                        (mask bit i: XCD i%8, shader engine (i/8)%4, CU i/32 -- scripts/dbg_cumap.sh)
 #   nows      no masks, checker without the loop split over the waves of a workgroup (NMFK_MAX_WSPLIT=1)
 cd $(dirname $0)/..
+for b in burner pk_victim cu_map uniform_vload; do [ -x scratch/$b ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scratch/$b.hip -o scratch/$b 2>/dev/null; done
 # (to see the hazard again: build the library from a commit before the broadcast-first operand rule, or with the rule reverted)
 mode=${1:-none}
 case $mode in

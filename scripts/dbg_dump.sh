@@ -1,5 +1,6 @@
 #!/bin/bash
 cd $(dirname $0)/..
+for b in burner pk_victim cu_map uniform_vload; do [ -x scratch/$b ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scratch/$b.hip -o scratch/$b 2>/dev/null; done
 hs=/tmp/nmfk_hs_$$; rm -f $hs.ref $hs.go
 NMFK_HIP_LIB=$PWD/nmfk.jl_amd/libnmfk_hip_dbg.so NMFK_HYB=0 NMFK_MERGE=1 HANDSHAKE=$hs timeout -k 5 150 python scripts/dbg_dump.py ${REPS:-40} > $hs.out 2>&1 &
 CHK=$!

@@ -2,6 +2,7 @@
 # usage: dbg_first_diff.sh <burner mode> <label> [ENV=... for the checker]   (checker: scripts/dbg_first_diff.py)
 # The checker computes its reference alone, then the burner starts (another process) and the repetitions begin.
 cd $(dirname $0)/..
+for b in burner pk_victim cu_map uniform_vload; do [ -x scratch/$b ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scratch/$b.hip -o scratch/$b 2>/dev/null; done
 # (to see the hazard again: build the library from a commit before the broadcast-first operand rule, or with the rule reverted)
 mode=$1; label=$2; shift 2
 echo "== $label  (burner mode $mode; $*)"

@@ -1,6 +1,7 @@
 #!/bin/bash
 # scratch/pk_victim.hip beside scratch/burner.hip mode 0 (bf16 MFMA 16x16x32 in registers, another process), then alone
 cd $(dirname $0)/..
+for b in burner pk_victim cu_map uniform_vload; do [ -x scratch/$b ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scratch/$b.hip -o scratch/$b 2>/dev/null; done
 echo "== beside the bf16 MFMA burner"
 timeout -k 5 170 ./scratch/burner 0 ${SECS:-100} &
 BURN=$!

@@ -29,16 +29,49 @@ PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 
 
+TRAFFIC_FILES = ("profiles/r03/traffic.json", "profiles/r02/traffic.json")
+
+
 def _pmc_traffic():
-    """HBM bytes per launch of the dominant kernel (hyb_step_kernel<16,2,8,false>, 256 factorizations per launch):
-    FETCH_SIZE x 2 + WRITE_SIZE, collected in separate rocprofv3 --pmc runs of this command (scripts/profile_bench.sh,
-    scripts/make_traffic.py -> profiles/r02/traffic.json); None if absent."""
+    """HBM bytes per launch of the dominant kernel: FETCH_SIZE x 2 + WRITE_SIZE from separate `rocprofv3 --pmc` passes of
+    this command (scripts/profile_bench.sh, scripts/make_traffic.py).  PMC passes cannot run inside the timed bench, so
+    this is a STATIC figure read from the newest committed file -- the line says which (`traffic_source`).
+    -> (bytes or None, source string)"""
+    for rel in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, rel)) as fh:
+                t = json.load(fh)
+            return float(t["hbm_bytes_per_launch"]), f"{rel} (static: rocprofv3 --pmc passes of an earlier run of this command" + \
+                (f", kernel {t['kernel']}" if "kernel" in t else "") + ")"
+        except Exception:
+            continue
+    return None, "absent"
+
+
+def julia_reference_baseline(n, m, ks, nruns):
+    """the reference itself, if the box has `julia` and an importable NMFk.  Bounded: a
+    fixed-budget sweep (maxbaditers=10^9, maxiter=20) of 2 restarts at k = min, max.  Returns a dict for the bench line
+    ("julia": "absent" on this image -- SURVEY.md probe table)."""
+    import shutil
+    import subprocess
+
+    exe = shutil.which("julia")
+    if exe is None:
+        return {"julia": "absent"}
+    prog = (f"import Random; import NMFk; X = rand(Float32, {n}, {m}); "
+            f"NMFk.execute(rand(Float32, 15, 5), 2:3, 2; method=:simple, load=false, save=false, quiet=true); "  # JIT warm-up
+            f"t = @elapsed for k in ({ks[0]}, {ks[-1]}); NMFk.execute(X, k, 2; method=:simple, load=false, save=false, quiet=true, "
+            f"maxiter=20, maxbaditers=10^9); end; println(\"NMFK_REF_SECONDS=\", t)")
     try:
-        with open(os.path.join(ROOT, "profiles", "r02", "traffic.json")) as fh:
-            t = json.load(fh)
-        return float(t["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+        r = subprocess.run([exe, "-e", prog], capture_output=True, text=True, timeout=600, cwd=os.environ.get("TMPDIR", "/tmp"))
+    except Exception as e:  # noqa: BLE001
+        return {"julia": exe, "error": repr(e)}
+    for ln in r.stdout.splitlines():
+        if ln.startswith("NMFK_REF_SECONDS="):
+            sec = float(ln.split("=")[1])
+            return {"julia": exe, "kind": "reference", "seconds_for_4_factorizations_of_20_iterations": sec,
+                    "sec_per_iteration_mean_of_kmin_kmax": sec / 80.0}
+    return {"julia": exe, "error": "NMFk.jl is not importable on this box: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200]}
 
 
 def cpu_baseline(X, ks, nruns, iters_by_k, threads):
@@ -204,7 +237,7 @@ def main():
                     "kernel": "hyb_step_kernel<16,2,8,false> (nmfk_step_hyb.hip): H and W half-step launches of the mixed-rank group "
                               "(ranks 9..16 x 32 restarts = 256 factorizations per launch), alone on the GPU in phase 1 of the sweep",
                     "bound": "mfma", "achieved": tfd, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tfd / PEAK_FP32_TFLOPS,
-                    "traffic": _pmc_traffic(),
+                    "traffic": _pmc_traffic()[0], "traffic_source": _pmc_traffic()[1],
                     "avg_launch_ms": {"h_step": h["ms"] / h["launches"], "w_step": w["ms"] / w["launches"]},
                     "sampled_launches": h["launches"] + w["launches"],
                     "whole_mu_loop": whole, "per_rank_kernel": per_kp,
@@ -223,7 +256,7 @@ def main():
                 line["roofline"] = {
                     "kernel": "step_kernel<KP> (half-step numerators + fused finish; all ranks, concurrent streams)",
                     "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
-                    "traffic": _pmc_traffic(), "mu_loop_gpu_ms": loop["ms"], "dominant_rank_kernel": dom, "per_rank_kernel": per_kp,
+                    "traffic": _pmc_traffic()[0], "traffic_source": _pmc_traffic()[1], "mu_loop_gpu_ms": loop["ms"], "dominant_rank_kernel": dom, "per_rank_kernel": per_kp,
                     "note": "flops = 4*n*m*k per half-step per ACTIVE restart (W*H and the product with the ratio; SURVEY 8d: "
                             "8*n*m*k per iteration). fp32 vector and fp32 MFMA share the 157.3 TFLOP/s peak on gfx950; the "
                             "kernels issue packed fp32 FMAs (v_pk_fma_f32) or, for the mixed-rank group of few-restart sweeps, "
@@ -253,6 +286,7 @@ def main():
         if not args.no_cpu_baseline:
             threads = min(32, len(os.sched_getaffinity(0)))
             line["cpu_baseline"] = cpu_baseline(X, ks, args.nruns, iters_by_k, threads)
+            line["cpu_baseline"]["reference_julia"] = julia_reference_baseline(args.n, args.m, ks, args.nruns)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -188,6 +188,8 @@ enum { NMFK_UNIQUE_ID_BYTES = 128 };
 /* restarts of one rank k that shard `rank` of `nranks` runs: *count real ones, padded to *padded = ceil(nruns/nranks)
  * (short lists repeat their last restart; the padding results are dropped).  Pure host arithmetic. */
 int nmfk_shard_plan(int nruns, int nranks, int rank, int32_t *count, int32_t *padded);
+/* the inverse: restart r (0-based) of every rank k is run by shard *rank as its local restart *slot (r = rank + slot * nranks). */
+int nmfk_shard_owner(int nruns, int nranks, int r, int32_t *rank, int32_t *slot);
 /* ncclGetUniqueId: called by ONE rank, the host layer hands the 128 bytes to the others (Julia: Distributed / a file;
  * bench.py: torch.distributed).  nmfk_comm_create is collective over the nranks contexts (ncclCommInitRank). */
 int nmfk_comm_unique_id(void *id128);
@@ -207,12 +209,30 @@ int nmfk_mu_sweep_sharded(nmfk_ctx *ctx, nmfk_comm *comm, int nk, const int32_t 
                           const nmfk_mu_params *params, int need_W, float *const *W_out, float *const *H_out,
                           float *const *frob_out, double *const *sse_out, int32_t *const *iters_out,
                           int32_t *const *reason_out);
+/* Error behaviour of the collective calls: before every data collective the ranks agree on a status word, so when the
+ * local step of ONE rank fails (bad X on the root, out of memory, a NaN initial factor in its shard: NMFK_ERR_NAN_INIT, ...)
+ * EVERY rank returns that status -- the failing rank with its own message, the others naming the rank -- and no rank is
+ * left blocked in a collective (the reference's pmap rethrows a worker's exception on the caller, Exec:511-526). */
+
+/* Loopback transport -- a TEST HOOK that executes the N > 1 code of this section on a one-GPU box: `nranks` logical ranks
+ * = `nranks` contexts on ONE GPU driven by `nranks` host threads of one process; the collectives are a host barrier plus
+ * device-to-device copies instead of RCCL, everything else (shard plan, padding, contribution layout, strided delivery,
+ * status agreement, thread fan-out of nmfk_multi_*) is the code the RCCL transport runs. */
+typedef struct nmfk_loop_group nmfk_loop_group;
+int nmfk_loopback_group_create(int nranks, nmfk_loop_group **out);
+int nmfk_loopback_group_destroy(nmfk_loop_group *group);
+int nmfk_comm_create_loopback(nmfk_ctx *ctx, nmfk_loop_group *group, int rank, nmfk_comm **out);
+
 /* One process, several GPUs (what `NMFkHIP.execute(...; ngpus = 8)` calls): GPUs 0..ngpus-1, one context, communicator
  * and host thread each; the results are delivered through GPU 0.  nmfk_multi_context gives GPU g's context (GPU 0:
  * clustering, silhouettes and fit re-checks after the sweep). */
 typedef struct nmfk_multi nmfk_multi;
 int nmfk_multi_create(int ngpus, nmfk_multi **out);
 int nmfk_multi_destroy(nmfk_multi *mh);
+/* the loopback form of nmfk_multi_create (test hook): nranks logical ranks on GPU `device` */
+int nmfk_multi_create_loopback(int nranks, int device, nmfk_multi **out);
+/* rank `gpu`'s communicator (not owned by the caller): per-rank calls of nmfk_mu_sweep_sharded from the caller's own threads */
+int nmfk_multi_comm(nmfk_multi *mh, int gpu, nmfk_comm **comm);
 int nmfk_multi_context(nmfk_multi *mh, int gpu, nmfk_ctx **ctx);
 int nmfk_multi_set_X(nmfk_multi *mh, const float *X, int64_t n, int64_t m, int64_t ldx, double lambda, int64_t *nan_count,
                      int64_t *zero_count);

@@ -3,15 +3,16 @@
 #     import NMFkHIP
 #     W, H, fitquality, robustness, aic, kopt = NMFkHIP.execute(X, 2:16, 32; ngpus=8)
 #
-# Same methods, keyword arguments, return shapes, result files and exception types as the reference path
+# Written to offer the same methods, keyword arguments, return shapes, result files and exception types as the reference path
 # (src/NMFkExecute.jl:15-65, 178-233, 236-329, 483-711, 729-807; src/NMFkMultiplicative.jl:24; citations below are
 # relative to the NMFk.jl source tree).  What differs is where the work happens: the reference's serial loops over k
 # (Exec:203) and over the restarts (Exec:535-541, or pmap Exec:511-526) become ONE flat (k, restart) work list that
 # libnmfk_hip runs on 1..8 MI355X (nmfk_mu_sweep / nmfk_multi_sweep), followed by the robustness step per k on GPU 0.
 #
 # STATUS: written against the C ABI and checked statically (tests/test_host_cpu.py: every ccall against the header and
-# the exported symbols; every keyword of the reference signatures present).  It has NOT run: the build container has no
-# `julia`.  The Python mirror nmfk.jl_amd/execute.py implements the same orchestration and is what the GPU tests run.
+# the exported symbols; every keyword of the reference signatures present; block structure balanced; the per-restart seed
+# rule and the order of the post-processing steps diffed against the Python mirror).  It has NOT run: the build container
+# has no `julia`.  The Python mirror nmfk.jl_amd/execute.py implements the same orchestration and is what the GPU tests run.
 module NMFkHIP
 
 import Random
@@ -295,13 +296,14 @@ end
 const MU_KEYS = (:tol, :tolOF, :lambda, :maxiter, :maxreattempts, :maxbaditers, :stopconv, :compute)
 
 "Initial factors of all restarts of rank nk, drawn with JULIA's RNG in the reference's order (restart ascending, W then H,
-Mult:38,48; `seed >= 0` re-seeds before every restart exactly as the serial branch forwards it, Exec:540 -> Mult:33-36),
-so that Random.seed!(s); execute(...) starts from the reference's points.  Given Winit / Hinit are used for every restart
-(Mult:40-41, 50-51)."
-function draw_inits(n::Int, m::Int, nk::Int, nNMF::Int; seed::Integer=-1, Winit=Matrix{Float32}(undef, 0, 0), Hinit=Matrix{Float32}(undef, 0, 0))
+Mult:38,48), so that Random.seed!(s); execute(...) starts from the reference's points.  With the keyword `seed` given
+(`seed === nothing`: not given), restart r is drawn after `Random.seed!(seed + r)` -- the reference forwards
+`seed=kwseed+i` to restart i (Exec:536, 540) and NMFmultiplicative re-seeds when that sum is >= 0 (Mult:33-35): every
+restart starts from DIFFERENT factors.  Given Winit / Hinit are used for every restart (Mult:40-41, 50-51)."
+function draw_inits(n::Int, m::Int, nk::Int, nNMF::Int; seed::Union{Nothing,Integer}=nothing, Winit=Matrix{Float32}(undef, 0, 0), Hinit=Matrix{Float32}(undef, 0, 0))
 	Wi = Array{Float32}(undef, n, nk, nNMF); Hi = Array{Float32}(undef, nk, m, nNMF)
 	for r in 1:nNMF
-		seed >= 0 && Random.seed!(seed)
+		!isnothing(seed) && seed + r >= 0 && Random.seed!(seed + r)                   # Exec:536,540 -> Mult:33-35
 		if sizeof(Winit) == 0
 			Wi[:, :, r] = rand(n, nk)
 		else
@@ -435,7 +437,7 @@ function run_restarts(c::Context, X::AbstractMatrix{T}, ks::Vector{Int}, nNMF::I
 		setX!(c, Xn; lambda=p.lambda)
 	end
 	setweight!(c, weight, n, m)
-	seed = get(kwd, :seed, -1)
+	seed = haskey(kwd, :seed) ? kwd[:seed] : nothing                                  # Exec:533 `haskey(kw, :seed)`
 	Winit = get(kwd, :Winit, Matrix{Float32}(undef, 0, 0)); Hinit = get(kwd, :Hinit, Matrix{Float32}(undef, 0, 0))
 	(sizeof(Winit) > 0 || sizeof(Hinit) > 0) && length(ks) > 1 && error("Winit / Hinit can only be given for a single number of signals")
 	Wi = Vector{Array{Float32,3}}(undef, length(ks)); Hi = Vector{Array{Float32,3}}(undef, length(ks))

@@ -88,6 +88,12 @@ def lib():
     L.nmfk_last_sweep_info.argtypes = [vp, C.POINTER(C.c_int32)]
     i32p = C.POINTER(C.c_int32)
     L.nmfk_shard_plan.argtypes = [C.c_int, C.c_int, C.c_int, i32p, i32p]
+    L.nmfk_shard_owner.argtypes = [C.c_int, C.c_int, C.c_int, i32p, i32p]
+    L.nmfk_loopback_group_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.nmfk_loopback_group_destroy.argtypes = [vp]
+    L.nmfk_comm_create_loopback.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.nmfk_multi_create_loopback.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.nmfk_multi_comm.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.nmfk_comm_unique_id.argtypes = [C.c_void_p]
     L.nmfk_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_void_p, C.POINTER(vp)]
     L.nmfk_comm_destroy.argtypes = [vp]
@@ -194,6 +200,13 @@ def shard_plan(nruns, nranks, rank):
     return cnt.value, pad.value
 
 
+def shard_owner(nruns, nranks, r):
+    """nmfk_shard_owner -> (rank that runs restart r, its local slot): r = rank + slot * nranks."""
+    g, j = C.c_int32(), C.c_int32()
+    _check(lib().nmfk_shard_owner(int(nruns), int(nranks), int(r), C.byref(g), C.byref(j)))
+    return g.value, j.value
+
+
 def _pin_rccl():
     """One copy of RCCL per process: inside a PyTorch process libnmfk_hip must use the librccl PyTorch ships and has
     loaded (two copies double-free at exit), so point the library's dlopen at it before its first RCCL call."""
@@ -228,9 +241,9 @@ class Comm:
         ctx._comms = getattr(ctx, "_comms", []) + [self]  # the context closes its communicators before itself
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
+        if getattr(self, "_h", None) is not None and self._h.value and getattr(self, "_owned", True):
             lib().nmfk_comm_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     __del__ = close
 
@@ -257,18 +270,37 @@ class Comm:
 
 
 class Multi:
-    """nmfk_multi: one process, GPUs 0..ngpus-1 (a context, a communicator and a host thread per GPU)."""
+    """nmfk_multi: one process, GPUs 0..ngpus-1 (a context, a communicator and a host thread per GPU).
+    loopback=True (test hook): `ngpus` LOGICAL ranks on the one GPU `device`, collectives emulated by device copies --
+    the N > 1 code of the C ABI on a one-GPU box (nmfk_multi_create_loopback)."""
 
-    def __init__(self, ngpus):
-        _pin_rccl()
+    def __init__(self, ngpus, loopback=False, device=0):
         self._h = C.c_void_p()
-        _check(lib().nmfk_multi_create(int(ngpus), C.byref(self._h)))
+        if loopback:
+            _check(lib().nmfk_multi_create_loopback(int(ngpus), int(device), C.byref(self._h)))
+        else:
+            _pin_rccl()
+            _check(lib().nmfk_multi_create(int(ngpus), C.byref(self._h)))
         self.ngpus = int(ngpus)
-        h0 = C.c_void_p()
-        _check(lib().nmfk_multi_context(self._h, 0, C.byref(h0)))
-        self.ctx0 = Context.__new__(Context)  # GPU 0's context (not owned): clustering, silhouettes, fit re-checks
-        self.ctx0._h, self.ctx0._owned = h0, False
-        self.ctx0.n = self.ctx0.m = self.ctx0.nan_count = self.ctx0.zero_count = 0
+        self.ctx0 = self.context(0)  # GPU 0's context (not owned): clustering, silhouettes, fit re-checks
+
+    def context(self, g):
+        h = C.c_void_p()
+        _check(lib().nmfk_multi_context(self._h, int(g), C.byref(h)))
+        ctx = Context.__new__(Context)
+        ctx._h, ctx._owned = h, False
+        ctx.n = ctx.m = ctx.nan_count = ctx.zero_count = 0
+        return ctx
+
+    def comm(self, g):
+        """rank g's communicator as a Comm (not owned): per-rank collective calls from the caller's own threads."""
+        h = C.c_void_p()
+        _check(lib().nmfk_multi_comm(self._h, int(g), C.byref(h)))
+        c = Comm.__new__(Comm)
+        c.ctx, c.nranks, c.rank = self.context(g), self.ngpus, int(g)
+        c.ctx.n, c.ctx.m = self.ctx0.n, self.ctx0.m
+        c._h, c._owned = h, False
+        return c
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -3,13 +3,15 @@
 
 Differences from the reference, all stated: the random draws come from the library's counter-based generator (Julia's
 stream is not reproducible), the silhouettes are only computed for the winning repeat (the reference computes them for
-every repeat and keeps the winner's: same result), and the cache payload is .npz instead of .jld."""
+every repeat and keeps the winner's: same result).  The cache is the reference's file: `<case>-<k>-<d>_<n>-<repeats>.jld` with
+"assignments" = the winning Clustering.KmeansResult (sorted) and "best_silhouettes" (Clus:173-199, 236-244), written and
+read by jldfile.py in the layout of the Julia-written fixtures under tests/golden/."""
 import os
 import warnings
 
 import numpy as np
 
-from . import _lib
+from . import _lib, resultio
 
 
 def _context(ctx, device):
@@ -60,27 +62,34 @@ def robustkmeans(X, krange, repeats=1000, *, best_method="worst_cliff", maxiter=
 
 
 def _robust_k(X, k, repeats, maxiter, tol, resultdir, casefilename, load, save, sil_flag, seed, ctx):
-    fn = os.path.join(resultdir, f"{casefilename}-{k}-{'_'.join(str(v) for v in X.shape)}-{repeats}.npz")  # Clus:174,237
+    fn = os.path.join(resultdir, f"{casefilename}-{k}-{'_'.join(str(v) for v in X.shape)}-{repeats}.jld")  # Clus:174,237
     if load and casefilename != "":
-        if os.path.isfile(fn):
-            with np.load(fn) as z:
-                if "assignments" in z and (not sil_flag or "best_silhouettes" in z):
-                    res = {key: z[key] for key in z.files if key != "best_silhouettes"}
-                    for key in ("totalcost", "iterations", "best_repeat", "nclusters"):
-                        if key in res:
-                            res[key] = res[key].item()
-                    return (res, z["best_silhouettes"]) if sil_flag else res
+        if os.path.isfile(fn):  # Clus:175-196
+            f = resultio.load(fn)
+            sc = f.get("assignments")
+            if isinstance(sc, dict) and "assignments_" in sc and (not sil_flag or "best_silhouettes" in f):
+                a = np.asarray(sc["assignments_"], dtype=np.int32)
+                res = dict(assignments=a, centers=np.asarray(sc["centers_"], dtype=np.float32),
+                           costs=np.asarray(sc["costs_"], dtype=np.float32), counts=np.asarray(sc["counts_"], dtype=np.int32),
+                           totalcost=float(sc["totalcost_"]), iterations=int(sc["iterations_"]), converged=bool(sc["converged_"]),
+                           nclusters=int(len(np.unique(a))), best_repeat=None, all_costs=None)
+                return (res, np.asarray(f["best_silhouettes"], dtype=np.float32)) if sil_flag else res
             warnings.warn(f"Failed to load robust k-means results from '{fn}'; Robust k-means analysis will be executed ...")
     out = ctx.robustkmeans(X, k, repeats, maxiter=maxiter, tol=tol, seed=seed, compute_silhouettes_flag=sil_flag)
     res, sil = out if sil_flag else (out, None)
     if res["nclusters"] < k:  # Clus:232-234
         warnings.warn(f"Robust k-means analysis could not find {k} clusters! Only {res['nclusters']} clusters were found.")
-    if save and casefilename != "":
+    if save and casefilename != "":  # Clus:236-244: JLD.save(filename, "assignments", sc[, "best_silhouettes", ...])
         os.makedirs(resultdir, exist_ok=True)
-        payload = dict(res)
+        kf = res["nclusters"]
+        sc = dict(centers_=np.asarray(res["centers"], np.float64), assignments_=np.asarray(res["assignments"], np.int64),
+                  costs_=np.asarray(res["costs"], np.float64), counts_=np.asarray(res["counts"][:kf], np.int64),
+                  wcounts_=np.asarray(res["counts"][:kf], np.int64), totalcost_=float(res["totalcost"]),
+                  iterations_=int(res["iterations"]), converged_=int(res["iterations"] < maxiter))
+        payload = {"assignments": sc}
         if sil_flag:
-            payload["best_silhouettes"] = sil
-        np.savez(fn, **payload)
+            payload["best_silhouettes"] = np.asarray(sil, np.float64)
+        resultio.save(fn, **payload)
     return (res, sil) if sil_flag else res
 
 

@@ -10,11 +10,21 @@
 // librccl is loaded at run time (dlopen): a single-GPU user needs no RCCL, and inside a PyTorch process the copy that
 // is already loaded is the one used.  One rank = one nmfk_ctx = one GPU; ranks may be processes (unique id passed by
 // the host layer) or threads of one process (nmfk_multi_*).
+//
+// No rank ever enters a data collective alone: before each one the ranks AGREE on a status word (a 4-byte all-gather of
+// the local return code), so a rank whose local step failed (bad X on the root, out of memory, a NaN initial factor in
+// its shard, ...) makes EVERY rank return an error instead of leaving the others blocked in the collective.
+//
+// Transport: RCCL, or -- a test hook -- a LOOPBACK group: N logical ranks as N host threads with N contexts on ONE GPU,
+// collectives emulated by a host barrier plus device-to-device copies (nmfk_multi_create_loopback).  Everything above
+// the three collective primitives (shard plan, padding, contribution layout, strided delivery, thread fan-out, status
+// agreement) is the same code either way, which is how the N > 1 path is executed on a one-GPU test box.
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -69,11 +79,34 @@ Rccl &rccl() {
 
 }  // namespace
 
+// loopback group: a reusable host barrier and the per-rank buffer addresses of the collective in flight
+struct nmfk_loop_group {
+  int n = 1;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t gen = 0;
+  std::vector<const void *> ptr;  // [n] source buffer of each rank
+  std::vector<int32_t> word;      // [n] status words
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const uint64_t g = gen;
+    if (++arrived == n) {
+      arrived = 0;
+      ++gen;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return gen != g; });
+    }
+  }
+};
+
 struct nmfk_comm {
   nmfk_ctx *ctx = nullptr;
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;        // RCCL transport ...
+  nmfk_loop_group *loop = nullptr;  // ... or the loopback group (not owned)
   int nranks = 1, rank = 0;
-  DevBuf send, recv, xbuf;
+  DevBuf send, recv, xbuf, stat;
 };
 
 namespace {
@@ -89,6 +122,76 @@ int rccl_fail(const nmfk_comm *c, const char *what, int rc) {
     const int _r = (expr);                         \
     if (_r != ncclSuccess) return rccl_fail(c, what, _r); \
   } while (0)
+
+// ---- the three collective primitives (device buffers, the context's stream) ---------------------------------------
+// broadcast `bytes` of `buf` from `root` (in place)
+int coll_bcast(nmfk_comm *c, void *buf, size_t bytes, int root, const char *what) {
+  hipStream_t st = c->ctx->stream;
+  if (!c->loop) {
+    RCCLCHECK(c, what, rccl().Broadcast(buf, buf, bytes, ncclChar, root, c->comm, st));
+    return NMFK_OK;
+  }
+  nmfk_loop_group *G = c->loop;
+  HIPCHECK(hipStreamSynchronize(st));  // the root's buffer is complete
+  G->ptr[c->rank] = buf;
+  G->barrier();
+  hipError_t e = hipSuccess;
+  if (c->rank != root) {
+    e = hipMemcpyAsync(buf, G->ptr[root], bytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  G->barrier();  // nobody touches the root's buffer before every rank has its copy
+  HIPCHECK(e);
+  return NMFK_OK;
+}
+// all-gather: `bytes` from every rank's `send` into recv[h * bytes], h = rank of origin
+int coll_allgather(nmfk_comm *c, const void *send, void *recv, size_t bytes, const char *what) {
+  hipStream_t st = c->ctx->stream;
+  if (!c->loop) {
+    RCCLCHECK(c, what, rccl().AllGather(send, recv, bytes, ncclChar, c->comm, st));
+    return NMFK_OK;
+  }
+  nmfk_loop_group *G = c->loop;
+  HIPCHECK(hipStreamSynchronize(st));
+  G->ptr[c->rank] = send;
+  G->barrier();
+  hipError_t e = hipSuccess;
+  for (int h = 0; h < c->nranks && e == hipSuccess; ++h)
+    e = hipMemcpyAsync((char *)recv + (size_t)h * bytes, G->ptr[h], bytes, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  G->barrier();
+  HIPCHECK(e);
+  return NMFK_OK;
+}
+// Status agreement: every rank contributes the return code of its local step; all ranks get NMFK_OK, or the first
+// failing rank's code.  A rank that failed itself keeps its own message (nmfk_last_error); the others name the rank.
+int agree(nmfk_comm *c, int my_rc, const char *step) {
+  std::vector<int32_t> all((size_t)c->nranks, NMFK_OK);
+  if (c->loop) {
+    nmfk_loop_group *G = c->loop;
+    G->word[c->rank] = my_rc;
+    G->barrier();
+    for (int h = 0; h < c->nranks; ++h) all[h] = G->word[h];
+    G->barrier();
+  } else {
+    hipStream_t st = c->ctx->stream;
+    int32_t *d = (int32_t *)c->stat.p;  // [0]: mine, [64 ...]: everybody's (allocated by nmfk_comm_create)
+    const int32_t mine = my_rc;
+    HIPCHECK(hipMemcpyAsync(d, &mine, sizeof(mine), hipMemcpyHostToDevice, st));
+    RCCLCHECK(c, "ncclAllGather(status)", rccl().AllGather(d, d + 64, sizeof(int32_t), ncclChar, c->comm, st));
+    HIPCHECK(hipMemcpyAsync(all.data(), d + 64, sizeof(int32_t) * c->nranks, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+  }
+  if (my_rc != NMFK_OK) return my_rc;  // (message of the local failure stays)
+  for (int h = 0; h < c->nranks; ++h)
+    if (all[h] != NMFK_OK) {
+      char b[256];
+      snprintf(b, sizeof(b), "rank %d of %d failed with status %d in %s (this is rank %d; see that rank's nmfk_last_error)", h,
+               c->nranks, (int)all[h], step, c->rank);
+      return fail(all[h], b);
+    }
+  return NMFK_OK;
+}
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -114,6 +217,21 @@ NMFK_EXPORT int nmfk_comm_unique_id(void *id128) {
   return NMFK_OK;
 }
 
+namespace {
+int comm_new(nmfk_ctx *ctx, int nranks, int rank, nmfk_comm **out) {
+  nmfk_comm *c = new nmfk_comm();
+  c->ctx = ctx;
+  c->nranks = nranks;
+  c->rank = rank;
+  if (c->stat.ensure(sizeof(int32_t) * (64 + (size_t)nranks))) {  // status words of agree(): never allocated on a failure path
+    delete c;
+    return fail(NMFK_ERR_HIP, "out of device memory (communicator)");
+  }
+  *out = c;
+  return NMFK_OK;
+}
+}  // namespace
+
 NMFK_EXPORT int nmfk_comm_create(nmfk_ctx *ctx, int nranks, int rank, const void *id128, nmfk_comm **out) {
   if (!ctx || !id128 || !out) return fail(NMFK_ERR_BAD_ARG, "null argument");
   *out = nullptr;
@@ -121,18 +239,46 @@ NMFK_EXPORT int nmfk_comm_create(nmfk_ctx *ctx, int nranks, int rank, const void
   Rccl &R = rccl();
   if (!R.err.empty()) return fail(NMFK_ERR_RCCL, R.err);
   HIPCHECK(hipSetDevice(ctx->device));
-  nmfk_comm *c = new nmfk_comm();
-  c->ctx = ctx;
-  c->nranks = nranks;
-  c->rank = rank;
+  nmfk_comm *c = nullptr;
+  const int rc0 = comm_new(ctx, nranks, rank, &c);
+  if (rc0 != NMFK_OK) return rc0;
   ncclUniqueId id;
   memcpy(&id, id128, NMFK_UNIQUE_ID_BYTES);
   const int rc = R.CommInitRank(&c->comm, nranks, id, rank);
   if (rc != ncclSuccess) {
     const int e = rccl_fail(c, "ncclCommInitRank", rc);
+    c->stat.release();
     delete c;
     return e;
   }
+  *out = c;
+  return NMFK_OK;
+}
+
+// Loopback transport (test hook, see the head of this file): the `nranks` communicators of one group belong to `nranks`
+// contexts on ONE GPU and are driven by `nranks` host threads of one process.
+NMFK_EXPORT int nmfk_loopback_group_create(int nranks, nmfk_loop_group **out) {
+  if (!out || nranks < 1) return fail(NMFK_ERR_BAD_ARG, "bad argument");
+  nmfk_loop_group *G = new nmfk_loop_group();
+  G->n = nranks;
+  G->ptr.assign((size_t)nranks, nullptr);
+  G->word.assign((size_t)nranks, 0);
+  *out = G;
+  return NMFK_OK;
+}
+NMFK_EXPORT int nmfk_loopback_group_destroy(nmfk_loop_group *G) {
+  delete G;
+  return NMFK_OK;
+}
+NMFK_EXPORT int nmfk_comm_create_loopback(nmfk_ctx *ctx, nmfk_loop_group *group, int rank, nmfk_comm **out) {
+  if (!ctx || !group || !out) return fail(NMFK_ERR_BAD_ARG, "null argument");
+  *out = nullptr;
+  if (rank < 0 || rank >= group->n) return fail(NMFK_ERR_BAD_ARG, "bad rank");
+  HIPCHECK(hipSetDevice(ctx->device));
+  nmfk_comm *c = nullptr;
+  const int rc0 = comm_new(ctx, group->n, rank, &c);
+  if (rc0 != NMFK_OK) return rc0;
+  c->loop = group;
   *out = c;
   return NMFK_OK;
 }
@@ -145,6 +291,7 @@ NMFK_EXPORT int nmfk_comm_destroy(nmfk_comm *c) {
   c->send.release();
   c->recv.release();
   c->xbuf.release();
+  c->stat.release();
   delete c;
   return NMFK_OK;
 }
@@ -159,35 +306,53 @@ NMFK_EXPORT int nmfk_comm_info(nmfk_comm *c, int *rank, int *nranks) {
 NMFK_EXPORT int nmfk_comm_bcast_X(nmfk_comm *c, int root, const float *X, int64_t n, int64_t m, int64_t ldx, double lambda,
                                   int64_t *n_out, int64_t *m_out, int64_t *nan_count, int64_t *zero_count) {
   if (!c) return fail(NMFK_ERR_BAD_ARG, "comm is null");
-  if (root < 0 || root >= c->nranks) return fail(NMFK_ERR_BAD_ARG, "bad root");
   nmfk_ctx *ctx = c->ctx;
   HIPCHECK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  // header: the size of X, known on the root only
-  if (c->xbuf.ensure(256)) return fail(NMFK_ERR_HIP, "out of device memory");
-  int64_t hdr[2] = {0, 0};
-  if (c->rank == root) {
-    if (!X || n <= 0 || m <= 0 || ldx < n) return fail(NMFK_ERR_BAD_ARG, "root: bad X");
-    hdr[0] = n;
-    hdr[1] = m;
-  }
+  // step 1 (local): arguments; the size of X is known on the root only
+  auto local_args = [&]() -> int {
+    if (root < 0 || root >= c->nranks) return fail(NMFK_ERR_BAD_ARG, "bad root");
+    if (c->rank == root && (!X || n <= 0 || m <= 0 || ldx < n))
+      return fail(NMFK_ERR_BAD_ARG, n <= 0 || m <= 0 ? "Input array has a zero dimension!" : "root: bad X");
+    if (c->xbuf.ensure(256)) return fail(NMFK_ERR_HIP, "out of device memory");
+    return NMFK_OK;
+  };
+  int rc = agree(c, local_args(), "nmfk_comm_bcast_X (arguments)");
+  if (rc != NMFK_OK) return rc;
+  int64_t hdr[2] = {c->rank == root ? n : 0, c->rank == root ? m : 0};
   HIPCHECK(hipMemcpyAsync(c->xbuf.p, hdr, sizeof(hdr), hipMemcpyHostToDevice, st));
-  RCCLCHECK(c, "ncclBroadcast(size of X)", rccl().Broadcast(c->xbuf.p, c->xbuf.p, sizeof(hdr), ncclChar, root, c->comm, st));
+  rc = coll_bcast(c, c->xbuf.p, sizeof(hdr), root, "ncclBroadcast(size of X)");
+  if (rc != NMFK_OK) return rc;
   HIPCHECK(hipMemcpyAsync(hdr, c->xbuf.p, sizeof(hdr), hipMemcpyDeviceToHost, st));
   HIPCHECK(hipStreamSynchronize(st));
   n = hdr[0];
   m = hdr[1];
-  if (n <= 0 || m <= 0) return fail(NMFK_ERR_BAD_ARG, "Input array has a zero dimension!");
+  // step 2 (local): the broadcast buffer and, on the root, the dense n x m image of the caller's (host or device) array
   const size_t bytes = (size_t)n * (size_t)m * sizeof(float);
-  if (c->xbuf.ensure(bytes)) return fail(NMFK_ERR_HIP, "out of device memory (X broadcast buffer)");
-  if (c->rank == root)  // dense n x m image of the caller's (host or device) array
-    HIPCHECK(hipMemcpy2DAsync(c->xbuf.p, (size_t)n * 4, X, (size_t)ldx * 4, (size_t)n * 4, (size_t)m, hipMemcpyDefault, st));
-  RCCLCHECK(c, "ncclBroadcast(X)", rccl().Broadcast(c->xbuf.p, c->xbuf.p, (size_t)n * m, ncclFloat32, root, c->comm, st));
+  auto local_stage = [&]() -> int {
+    if (n <= 0 || m <= 0) return fail(NMFK_ERR_BAD_ARG, "Input array has a zero dimension!");
+    if (c->xbuf.ensure(bytes)) return fail(NMFK_ERR_HIP, "out of device memory (X broadcast buffer)");
+    if (c->rank == root)
+      HIPCHECK(hipMemcpy2DAsync(c->xbuf.p, (size_t)n * 4, X, (size_t)ldx * 4, (size_t)n * 4, (size_t)m, hipMemcpyDefault, st));
+    return NMFK_OK;
+  };
+  rc = agree(c, local_stage(), "nmfk_comm_bcast_X (staging)");
+  if (rc != NMFK_OK) return rc;
+  rc = coll_bcast(c, c->xbuf.p, bytes, root, "ncclBroadcast(X)");
+  if (rc != NMFK_OK) return rc;
   HIPCHECK(hipStreamSynchronize(st));
-  const int rc = nmfk_set_X(ctx, (const float *)c->xbuf.p, n, m, n, lambda, nan_count, zero_count);  // NMFpreprocessing! on every rank
+  // step 3 (local): NMFpreprocessing! on every rank; a rank that fails here (negative entries fail on all) fails them all
+  rc = agree(c, nmfk_set_X(ctx, (const float *)c->xbuf.p, n, m, n, lambda, nan_count, zero_count), "nmfk_set_X");
   if (n_out) *n_out = n;
   if (m_out) *m_out = m;
   return rc;
+}
+
+NMFK_EXPORT int nmfk_shard_owner(int nruns, int nranks, int r, int32_t *rank, int32_t *slot) {
+  if (nruns <= 0 || nranks <= 0 || r < 0 || r >= nruns) return fail(NMFK_ERR_BAD_ARG, "bad shard arguments");
+  if (rank) *rank = r % nranks;  // restart r = rank + slot * nranks
+  if (slot) *slot = r / nranks;
+  return NMFK_OK;
 }
 
 NMFK_EXPORT int nmfk_mu_sweep_sharded(nmfk_ctx *ctx, nmfk_comm *c, int nk, const int32_t *ks, int nruns,
@@ -195,59 +360,68 @@ NMFK_EXPORT int nmfk_mu_sweep_sharded(nmfk_ctx *ctx, nmfk_comm *c, int nk, const
                                       const nmfk_mu_params *params, int need_W, float *const *W_out, float *const *H_out,
                                       float *const *frob_out, double *const *sse_out, int32_t *const *iters_out,
                                       int32_t *const *reason_out) {
-  if (!ctx || !c || c->ctx != ctx || !ks || !params) return fail(NMFK_ERR_BAD_ARG, "null argument");
-  if (nk <= 0 || nruns <= 0) return fail(NMFK_ERR_BAD_ARG, "nk and nruns must be positive");
-  if (!ctx->Xc && !ctx->sparse) return fail(NMFK_ERR_NO_X, "nmfk_set_X / nmfk_comm_bcast_X has not been called");
+  if (!ctx || !c || c->ctx != ctx) return fail(NMFK_ERR_BAD_ARG, "null argument / communicator of another context");
   HIPCHECK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int N = c->nranks, g = c->rank;
   const int64_t n = ctx->n, m = ctx->m;
   int32_t mine = 0, cpad = 0;
-  (void)nmfk_shard_plan(nruns, N, g, &mine, &cpad);
   const bool withW = need_W != 0;
   // layout of a rank's contribution: per rank k (in the caller's order) cpad restarts of W, H, frob, iters, reason, sse
-  std::vector<size_t> oW(nk), oH(nk), oF(nk), oI(nk), oR(nk), oS(nk);
+  std::vector<size_t> oW, oH, oF, oI, oR, oS, oWl, oWi, oHi;
   size_t tot = 0;
-  for (int q = 0; q < nk; ++q) {
-    if (ks[q] < 1 || ks[q] > NMFK_MAX_K) return fail(NMFK_ERR_UNSUPPORTED, "k out of range");
-    const size_t k = (size_t)ks[q];
-    oW[q] = tot;
-    tot += align256(withW ? sizeof(float) * cpad * k * n : 0);
-    oH[q] = tot;
-    tot += align256(sizeof(float) * cpad * k * m);
-    oF[q] = tot;
-    tot += align256(sizeof(float) * cpad);
-    oI[q] = tot;
-    tot += align256(sizeof(int32_t) * cpad);
-    oR[q] = tot;
-    tot += align256(sizeof(int32_t) * cpad);
-    oS[q] = tot;
-    tot += align256(sizeof(double) * cpad);
-  }
-  // local scratch behind the contribution: W of the local restarts when it is not exchanged, local inits
-  std::vector<size_t> oWl(nk, 0), oWi(nk, 0), oHi(nk, 0);
-  size_t loc = tot;
-  for (int q = 0; q < nk; ++q) {
-    const size_t k = (size_t)ks[q];
-    if (!withW) {
-      oWl[q] = loc;
-      loc += align256(sizeof(float) * cpad * k * n);
+  // step 1 (local): arguments and buffers.  Every way out of a local step leads to agree(): no rank is left alone in a collective.
+  auto local_plan = [&]() -> int {
+    if (!ks || !params) return fail(NMFK_ERR_BAD_ARG, "null argument");
+    if (nk <= 0 || nruns <= 0) return fail(NMFK_ERR_BAD_ARG, "nk and nruns must be positive");
+    if (!ctx->Xc && !ctx->sparse) return fail(NMFK_ERR_NO_X, "nmfk_set_X / nmfk_comm_bcast_X has not been called");
+    (void)nmfk_shard_plan(nruns, N, g, &mine, &cpad);
+    oW.assign(nk, 0), oH.assign(nk, 0), oF.assign(nk, 0), oI.assign(nk, 0), oR.assign(nk, 0), oS.assign(nk, 0);
+    oWl.assign(nk, 0), oWi.assign(nk, 0), oHi.assign(nk, 0);
+    for (int q = 0; q < nk; ++q) {
+      if (ks[q] < 1 || ks[q] > NMFK_MAX_K) return fail(NMFK_ERR_UNSUPPORTED, "k out of range");
+      const size_t k = (size_t)ks[q];
+      oW[q] = tot;
+      tot += align256(withW ? sizeof(float) * cpad * k * n : 0);
+      oH[q] = tot;
+      tot += align256(sizeof(float) * cpad * k * m);
+      oF[q] = tot;
+      tot += align256(sizeof(float) * cpad);
+      oI[q] = tot;
+      tot += align256(sizeof(int32_t) * cpad);
+      oR[q] = tot;
+      tot += align256(sizeof(int32_t) * cpad);
+      oS[q] = tot;
+      tot += align256(sizeof(double) * cpad);
     }
-    if (Winit && Winit[q]) {
-      oWi[q] = loc;
-      loc += align256(sizeof(float) * cpad * k * n);
+    // local scratch behind the contribution: W of the local restarts when it is not exchanged, local inits
+    size_t loc = tot;
+    for (int q = 0; q < nk; ++q) {
+      const size_t k = (size_t)ks[q];
+      if (!withW) {
+        oWl[q] = loc;
+        loc += align256(sizeof(float) * cpad * k * n);
+      }
+      if (Winit && Winit[q]) {
+        oWi[q] = loc;
+        loc += align256(sizeof(float) * cpad * k * n);
+      }
+      if (Hinit && Hinit[q]) {
+        oHi[q] = loc;
+        loc += align256(sizeof(float) * cpad * k * m);
+      }
     }
-    if (Hinit && Hinit[q]) {
-      oHi[q] = loc;
-      loc += align256(sizeof(float) * cpad * k * m);
-    }
-  }
-  if (c->send.ensure(loc)) return fail(NMFK_ERR_HIP, "out of device memory (shard buffers)");
-  if (c->recv.ensure(tot * (size_t)N)) return fail(NMFK_ERR_HIP, "out of device memory (gather buffer)");
+    if (c->send.ensure(loc)) return fail(NMFK_ERR_HIP, "out of device memory (shard buffers)");
+    if (c->recv.ensure(tot * (size_t)N)) return fail(NMFK_ERR_HIP, "out of device memory (gather buffer)");
+    return NMFK_OK;
+  };
+  int rc = agree(c, local_plan(), "nmfk_mu_sweep_sharded (arguments, buffers)");
+  if (rc != NMFK_OK) return rc;
   char *S = c->send.p;
 
-  if (mine > 0) {
-    // this rank's restarts r = g + j*N (j < mine), padded to cpad by repeating the last one
+  // step 2 (local): this rank's restarts r = g + j*N (j < mine), padded to cpad by repeating the last one
+  auto local_sweep = [&]() -> int {
+    if (mine <= 0) return NMFK_OK;
     std::vector<uint64_t> lseeds((size_t)nk * cpad, 0);
     std::vector<const float *> wi(nk, nullptr), hi(nk, nullptr);
     std::vector<float *> wo(nk), ho(nk), fo(nk);
@@ -276,11 +450,13 @@ NMFK_EXPORT int nmfk_mu_sweep_sharded(nmfk_ctx *ctx, nmfk_comm *c, int nk, const
     }
     HIPCHECK(hipStreamSynchronize(st));
     // the local sweep writes straight into the contribution (device pointers on the boundary)
-    const int rc = nmfk_mu_sweep(ctx, nk, ks, cpad, wi.data(), hi.data(), seeds ? lseeds.data() : nullptr, params, wo.data(),
-                                 ho.data(), fo.data(), so.data(), io.data(), ro.data());
-    if (rc != NMFK_OK) return rc;  // (the other ranks then fail in the collective: the host layer tears the job down)
-  }
-  RCCLCHECK(c, "ncclAllGather(results)", rccl().AllGather(S, c->recv.p, tot, ncclChar, c->comm, st));
+    return nmfk_mu_sweep(ctx, nk, ks, cpad, wi.data(), hi.data(), seeds ? lseeds.data() : nullptr, params, wo.data(), ho.data(),
+                         fo.data(), so.data(), io.data(), ro.data());
+  };
+  rc = agree(c, local_sweep(), "its local sweep");
+  if (rc != NMFK_OK) return rc;
+  rc = coll_allgather(c, S, c->recv.p, tot, "ncclAllGather(results)");
+  if (rc != NMFK_OK) return rc;
 
   // deliver: restart r = h + j*N of rank k comes from rank h, slot j
   if (H_out) {
@@ -321,6 +497,7 @@ NMFK_EXPORT int nmfk_mu_sweep_sharded(nmfk_ctx *ctx, nmfk_comm *c, int nk, const
 struct nmfk_multi {
   std::vector<nmfk_ctx *> ctx;
   std::vector<nmfk_comm *> comm;
+  nmfk_loop_group *loop = nullptr;  // loopback form: N logical ranks on one GPU (owned)
 };
 
 namespace {
@@ -336,8 +513,11 @@ int on_all(nmfk_multi *mh, F f) {
       if (rc[g] != NMFK_OK) msg[g] = nmfk_last_error();
     });
   for (auto &t : th) t.join();
-  for (int g = 0; g < N; ++g)
-    if (rc[g] != NMFK_OK) return fail(rc[g], "GPU " + std::to_string(g) + ": " + msg[g]);
+  // report the rank whose own step failed (the others only say "rank h failed", see agree())
+  for (int pass = 0; pass < 2; ++pass)
+    for (int g = 0; g < N; ++g)
+      if (rc[g] != NMFK_OK && (pass == 1 || msg[g].find("see that rank's nmfk_last_error") == std::string::npos))
+        return fail(rc[g], "GPU " + std::to_string(g) + ": " + msg[g]);
   return NMFK_OK;
 }
 }  // namespace
@@ -346,6 +526,7 @@ NMFK_EXPORT int nmfk_multi_destroy(nmfk_multi *mh) {
   if (!mh) return NMFK_OK;
   for (auto *c : mh->comm) (void)nmfk_comm_destroy(c);
   for (auto *x : mh->ctx) (void)nmfk_destroy(x);
+  delete mh->loop;
   delete mh;
   return NMFK_OK;
 }
@@ -369,6 +550,31 @@ NMFK_EXPORT int nmfk_multi_create(int ngpus, nmfk_multi **out) {
     return fail(rc, keep);
   }
   *out = mh;
+  return NMFK_OK;
+}
+
+// test hook: `nranks` logical ranks (contexts, communicators, host threads) on the ONE GPU `device`, loopback transport
+NMFK_EXPORT int nmfk_multi_create_loopback(int nranks, int device, nmfk_multi **out) {
+  if (!out || nranks < 1) return fail(NMFK_ERR_BAD_ARG, "bad argument");
+  *out = nullptr;
+  nmfk_multi *mh = new nmfk_multi();
+  mh->ctx.assign(nranks, nullptr);
+  mh->comm.assign(nranks, nullptr);
+  int rc = nmfk_loopback_group_create(nranks, &mh->loop);
+  for (int g = 0; g < nranks && rc == NMFK_OK; ++g) rc = nmfk_create(device, &mh->ctx[g]);
+  for (int g = 0; g < nranks && rc == NMFK_OK; ++g) rc = nmfk_comm_create_loopback(mh->ctx[g], mh->loop, g, &mh->comm[g]);
+  if (rc != NMFK_OK) {
+    const std::string keep = nmfk_last_error();
+    (void)nmfk_multi_destroy(mh);
+    return fail(rc, keep);
+  }
+  *out = mh;
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_multi_comm(nmfk_multi *mh, int gpu, nmfk_comm **comm) {
+  if (!mh || !comm || gpu < 0 || gpu >= (int)mh->comm.size()) return fail(NMFK_ERR_BAD_ARG, "bad argument");
+  *comm = mh->comm[gpu];
   return NMFK_OK;
 }
 

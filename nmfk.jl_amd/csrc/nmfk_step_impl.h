@@ -349,7 +349,7 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
       T2 pp[1] = {splat2((T)0)};
 #pragma unroll
       for (int c = 0; c < KP; ++c) {
-#ifdef NMFK_UNSAFE_OPERAND_ORDER  // (scripts/build_hazard_lib.sh: the order that makes hipcc emit the unsafe select)
+#ifdef NMFK_UNSAFE_OPERAND_ORDER  // (tools/hazard/build_hazard_lib.sh: the order that makes hipcc emit the unsafe select)
         pp[0] = fma2(ae[EP ? c : 0], splat2(bv[c]), pp[0]);
 #else
         pp[0] = fma2(splat2(bv[c]), ae[EP ? c : 0], pp[0]);

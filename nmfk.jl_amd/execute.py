@@ -66,7 +66,7 @@ _first_warning = True  # NMFk's module-level `first_warning` (Mult:8-15): the tw
 
 
 def _zero_line_warnings(X):
-    """Mult:8-15: a row / column whose entries sum to 0 (NaN sums compare false, as in Julia)."""
+    """Mult:8-15: minimum(sum(X; dims=...)) == 0, once per session."""
     global _first_warning
     if not _first_warning:
         return
@@ -76,9 +76,11 @@ def _zero_line_warnings(X):
     else:
         Xa = np.asarray(X)
         rs, cs = Xa.sum(axis=1), Xa.sum(axis=0)
-    if rs.size and np.nanmin(np.where(np.isnan(rs), np.inf, rs)) == 0:
+    # Julia's minimum() propagates NaN and `NaN == 0` is false: with a missing entry anywhere in X the reference stays
+    # silent even when another row / column is all zero.  numpy's min() propagates NaN the same way.
+    if rs.size and rs.min() == 0:
         warnings.warn("All matrix entries in a row should not be 0!")
-    if cs.size and np.nanmin(np.where(np.isnan(cs), np.inf, cs)) == 0:
+    if cs.size and cs.min() == 0:
         warnings.warn("All matrix entries in a column should not be 0!")
 
 
@@ -235,6 +237,9 @@ def _sweep(ctx, X, ks, nNMF, kw, need_all_W=True):
             res[k]["W"] = np.ascontiguousarray(res[k]["W"] * v[None, :, None])
             res[k]["objvalue"] = np.array([ctx.frobenius(res[k]["W"][r], res[k]["H"][r]) for r in range(nNMF)],
                                           dtype=np.float32)
+            # the library's sse belongs to the row-normalised X of the loop; the reference's "OF is very different" check
+            # (Exec:602-607) works on the restored X with the rescaled W, i.e. on what objvalue now holds: nothing to compare
+            res[k]["sse"] = None
     return res, params
 
 

@@ -45,6 +45,12 @@ class _Reader:
         if sb[13] != 8 or sb[14] != 8:
             raise ValueError("only 8-byte offsets / lengths are supported")
         self.base = struct.unpack_from("<Q", sb, 24)[0]
+        # end-of-file address: ABSOLUTE (user block included), as libhdf5 writes it -- both Julia-written fixtures store
+        # their full file size with base = 512.  libhdf5 refuses addresses beyond (eof - base), so a wrong value makes a
+        # file unreadable for JLD.jl although every object in it is intact: reject it here too.
+        self.eof = struct.unpack_from("<Q", sb, 40)[0]
+        if self.eof != len(buf):
+            raise ValueError(f"HDF5 end-of-file address {self.eof} differs from the file size {len(buf)} (truncated or mis-written file)")
         self.root_header = struct.unpack_from("<Q", sb, 56 + 8)[0]
 
     def at(self, addr):
@@ -313,6 +319,9 @@ def load(path, *names):
         v = node["value"]
         if node["type"] and not isinstance(node["type"], np.dtype) and node["type"][0] == "ref":
             v = [byhdr[h]["value"] for h in v]
+        elif node["type"] and not isinstance(node["type"], np.dtype) and node["type"][0] == "compound" and isinstance(v, dict):
+            # a Julia struct (e.g. Clustering.KmeansResult): array fields are references into /_refs
+            v = {f: (byhdr[v[f][0]]["value"] if ft == ("ref",) else v[f]) for f, _off, ft in node["type"][2]}
         out[name] = v
     return out
 
@@ -341,6 +350,31 @@ def _dt_msg(dt):
 
 
 _REF_DT = struct.pack("<BBBBI", 0x17, 0, 0, 0, 8)  # object reference
+
+
+_BOOL_DT = struct.pack("<BBBBI", 0x14, 0, 0, 0, 1) + struct.pack("<HH", 0, 8)  # bit field, 1 byte: how JLD stores Bool
+
+
+def _compound_msg(size, members):
+    """version-1 compound datatype message, the form libhdf5 writes for JLD's struct types: per member the name (NUL
+    terminated, padded to a multiple of 8), byte offset, 28 bytes of (unused) array information, the member's type.
+    members: [(name, offset, datatype message bytes)]"""
+    out = struct.pack("<BBBBI", 0x16, len(members) & 255, len(members) >> 8, 0, size)
+    for name, off, tmsg in members:
+        out += _pad8(name.encode() + b"\0") + struct.pack("<I28x", off) + tmsg
+    return out
+
+
+# Clustering.KmeansResult{Matrix{Float64},Float64,Int64} as JLD.jl 0.13 commits it (packed, no alignment): the layout of
+# tests/golden/julia_written_Hmatrix-2-2_10-1000.jld, reproduced byte for byte (tests/test_jldfile.py)
+KMEANS_JULIA_TYPE = "Clustering.KmeansResult{Core.Array{Core.Float64,2},Core.Float64,Core.Int64}"
+_KMEANS_FIELDS = [("centers_", 0, "ref"), ("assignments_", 8, "ref"), ("costs_", 16, "ref"), ("counts_", 24, "ref"),
+                  ("wcounts_", 32, "ref"), ("totalcost_", 40, "f8"), ("iterations_", 48, "i8"), ("converged_", 56, "bool")]
+
+
+def kmeans_result_datatype():
+    kinds = {"ref": _REF_DT, "f8": _dt_msg("f8"), "i8": _dt_msg("i8"), "bool": _BOOL_DT}
+    return _compound_msg(57, [(nm, off, kinds[kd]) for nm, off, kd in _KMEANS_FIELDS])
 
 
 def _ds_msg(shape):
@@ -402,6 +436,22 @@ class _Writer:
         msgs += [_msg(0x000C, _attr_msg(k, v)) for k, v in attrs]
         return self.alloc(_header(msgs))
 
+    def committed_type(self, tmsg, julia_type, users=1):
+        """a named datatype (member of /_types): datatype message + the "julia type" attribute; reference count = its
+        link + the datasets that share it"""
+        msgs = [_msg(0x0003, tmsg, flags=1), _msg(0x000C, _attr_msg("julia type", julia_type))]
+        body = b"".join(msgs)
+        return self.alloc(struct.pack("<BBHII4x", 1, 0, len(msgs), 1 + users, len(body)) + body)
+
+    def struct_dataset(self, raw, type_hdr):
+        """scalar dataset of a committed compound type: shared datatype message (version 2, type 2 = object header
+        address of the committed type), compact layout"""
+        shared = struct.pack("<BBQ", 2, 2, type_hdr)
+        layout = struct.pack("<BBH", 3, 0, len(raw)) + raw
+        msgs = [_msg(0x0001, _ds_msg(None)), _msg(0x0003, shared, flags=3), _msg(0x0005, _FILL, flags=1), _msg(0x0008, layout),
+                _msg(0x0012, _MTIME)]
+        return self.alloc(_header(msgs))
+
     def group(self, entries):
         """group as libhdf5 writes it for JLD: link-info + group-info messages and one hard-link message per member in
         the (version-1) object header"""
@@ -415,7 +465,8 @@ class _Writer:
 
     def finish(self, root_hdr):
         sb = SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, 4, 16, 0)
-        sb += struct.pack("<QQQQ", USERBLOCK, UNDEF, len(self.buf), UNDEF)
+        # base address, free-space info, END-OF-FILE address (absolute: user block + HDF5 image), driver info
+        sb += struct.pack("<QQQQ", USERBLOCK, UNDEF, USERBLOCK + len(self.buf), UNDEF)
         sb += struct.pack("<QQII16x", 0, root_hdr, 0, 0)  # root symbol-table entry: nothing cached
         self.buf[:96] = sb
         return MAGIC + b"\0" * (USERBLOCK - len(MAGIC)) + bytes(self.buf)
@@ -430,9 +481,24 @@ def save(path, variables):
     """JLD.save(path, name1, value1, ...).  values: numpy arrays / numpy scalars / Python floats and ints, or lists of
     arrays (Vector{Matrix{T}}: reference datasets into /_refs)."""
     W = _Writer()
-    top, refs = [], []
+    top, refs, types = [], [], []
     for name, v in variables.items():
-        if isinstance(v, (list, tuple)):
+        if isinstance(v, dict):  # a Clustering.KmeansResult (the robustkmeans cache, src/NMFkCluster.jl:236-244)
+            if set(v) != {nm for nm, _o, _k in _KMEANS_FIELDS}:
+                raise TypeError(f"{name}: only the fields of Clustering.KmeansResult can be written as a struct")
+            if not types:
+                types.append(("%08d" % 1, W.committed_type(kmeans_result_datatype(), KMEANS_JULIA_TYPE)))
+            raw = b""
+            for nm, _off, kd in _KMEANS_FIELDS:
+                if kd == "ref":
+                    dt = np.float64 if nm in ("centers_", "costs_") else np.int64
+                    h = W.dataset(np.asarray(v[nm], dtype=dt))
+                    refs.append(("%08d" % (len(refs) + 1), h))
+                    raw += struct.pack("<Q", h)
+                else:
+                    raw += struct.pack({"f8": "<d", "i8": "<q", "bool": "<B"}[kd], v[nm])
+            top.append((name, W.struct_dataset(raw, types[0][1])))
+        elif isinstance(v, (list, tuple)):
             hdrs = []
             for a in v:
                 a = np.asarray(a)
@@ -447,7 +513,7 @@ def save(path, variables):
                        ("WORD_SIZE", W.dataset(np.int64(64))), ("JULIA_MINOR", W.dataset(np.uint32(11))),
                        ("ENDIAN_BOM", W.dataset(np.uint32(0x04030201)))])
     top.append(("_creator", creator))
-    top.append(("_types", W.group([])))
+    top.append(("_types", W.group(types)))
     if refs:
         top.append(("_refs", W.group(refs)))
     data = W.finish(W.group(top))

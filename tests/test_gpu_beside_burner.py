@@ -1,7 +1,7 @@
 """Opt-in soak (NMFK_TEST_BURNER=1): every shipped path repeated while ANOTHER process keeps gfx950's 128-bit-operand
 matrix instructions busy on every CU -- the neighbour that exposed the packed-fp32 hazard of DESIGN.md ("Known hazard").
 Each repetition must reproduce, bit for bit, a reference computed with the GPU to ourselves.  Skipped by default: it
-starts a second GPU process (scratch/burner, built with hipcc on the spot) and runs for about a minute; the generated-code
+starts a second GPU process (tools/hazard/burner, built with hipcc on the spot) and runs for about a minute; the generated-code
 lint of tests/test_isa_lint.py is the always-on guard.  profiles/r02/soak_beside_burner.txt has the full-length run."""
 import os
 import subprocess

@@ -98,3 +98,124 @@ def test_comm_errors_are_loud(NMFk):
         comm.mu_sweep([2], 2, seeds=np.zeros((1, 2), np.uint64))
     comm.close()
     ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 through the C ABI on ONE GPU: the loopback transport (include/nmfk_hip.h, "Loopback transport").  N logical ranks
+# = N contexts + N host threads; everything above the three collective primitives -- shard plan, padding by repeating the
+# last restart, contribution layout, strided delivery (pitch elem * N), the need_W = 0 local-W copy, the status agreement
+# and the thread fan-out of nmfk_multi_* -- is the code the RCCL transport runs.  Reference seam: Distributed.pmap over the
+# restarts, src/NMFkExecute.jl:511-526.
+# ---------------------------------------------------------------------------------------------------------------------
+def _ranks_in_threads(mh, fn):
+    """fn(g, comm) on one Python thread per logical rank (ctypes releases the GIL, the collectives meet inside the library)."""
+    import threading
+
+    out, err = [None] * mh.ngpus, [None] * mh.ngpus
+
+    def work(g):
+        try:
+            out[g] = fn(g, mh.comm(g))
+        except Exception as e:  # noqa: BLE001 -- handed to the asserting thread
+            err[g] = e
+
+    th = [threading.Thread(target=work, args=(g,)) for g in range(mh.ngpus)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "a rank is still blocked in a collective"
+    return out, err
+
+
+@pytest.mark.parametrize("N,R", [(2, 5), (3, 7), (8, 5), (8, 11), (3, 2)])
+def test_loopback_sharded_sweep_is_bit_identical(NMFk, oracle, N, R):
+    """nruns not divisible by N, more ranks than restarts (idle ranks), mixed rank widths incl. the all-MFMA kernel."""
+    from nmfk_jl_amd import _lib
+
+    X = _case(oracle, 200, 48)
+    ks = [2, 5, 12, 20]
+    seeds = np.array([[NMFk.run_seed(11, k, r) for r in range(R)] for k in ks], dtype=np.uint64)
+    ref_ctx = NMFk.Context(0)
+    ref_ctx.set_X(X)
+    ref = ref_ctx.mu_sweep(ks, R, seeds=seeds, maxiter=30, **NOSTOP)
+    mh = _lib.Multi(N, loopback=True)
+    mh.set_X(X)  # loopback broadcast of X from rank 0 + NMFpreprocessing! on every rank
+    res = mh.mu_sweep(ks, R, seeds=seeds, maxiter=30, **NOSTOP)  # nmfk_multi_sweep: N threads inside the library
+    for k in ks:
+        for key in ("W", "H", "objvalue", "iters", "reason", "sse"):
+            assert (res[k][key] == ref[k][key]).all(), (k, key)
+
+    # per-rank calls of nmfk_mu_sweep_sharded: every rank receives every restart; need_W = 0: W of the own restarts only
+    for need_W in (True, False):
+        out, err = _ranks_in_threads(mh, lambda g, comm: comm.mu_sweep(ks, R, seeds=seeds, maxiter=30, need_W=need_W, **NOSTOP))
+        assert err == [None] * N, err
+        for g in range(N):
+            own = [r for r in range(R) if _lib.shard_owner(R, N, r)[0] == g]
+            assert own == list(range(g, R, N))
+            for k in ks:
+                for key in ("H", "objvalue", "iters", "reason", "sse"):
+                    assert (out[g][k][key] == ref[k][key]).all(), (g, k, key, need_W)
+                if need_W:
+                    assert (out[g][k]["W"] == ref[k]["W"]).all()
+                else:
+                    assert (out[g][k]["W"][own] == ref[k]["W"][own]).all()
+                    other = [r for r in range(R) if r not in own]
+                    assert np.isnan(out[g][k]["W"][other]).all()  # (the binding pre-fills W with NaN)
+    mh.close()
+    ref_ctx.close()
+
+
+def test_loopback_given_inits_travel_through_the_shard_buffers(NMFk, oracle):
+    from nmfk_jl_amd import _lib
+
+    X = _case(oracle, 120, 40)
+    N, R, k = 3, 7, 4
+    seeds = [NMFk.run_seed(2, k, r) for r in range(R)]
+    W0 = np.stack([oracle.init_factors(int(s), *X.shape, k)[0] for s in seeds])
+    H0 = np.stack([oracle.init_factors(int(s), *X.shape, k)[1] for s in seeds])
+    ref_ctx = NMFk.Context(0)
+    ref_ctx.set_X(X)
+    b = ref_ctx.mu_sweep([k], R, Winit={k: W0}, Hinit={k: H0}, maxiter=25, **NOSTOP)[k]
+    mh = _lib.Multi(N, loopback=True)
+    mh.set_X(X)
+    a = mh.mu_sweep([k], R, Winit={k: W0}, Hinit={k: H0}, maxiter=25, **NOSTOP)[k]
+    assert (a["W"] == b["W"]).all() and (a["H"] == b["H"]).all() and (a["objvalue"] == b["objvalue"]).all()
+    # only H given: W drawn from the seeds (the mixed form of Mult:38-55)
+    sd = np.array([seeds], dtype=np.uint64)
+    a = mh.mu_sweep([k], R, seeds=sd, Hinit={k: H0}, maxiter=25, **NOSTOP)[k]
+    b = ref_ctx.mu_sweep([k], R, seeds=sd, Hinit={k: H0}, maxiter=25, **NOSTOP)[k]
+    assert (a["W"] == b["W"]).all() and (a["H"] == b["H"]).all()
+    mh.close()
+    ref_ctx.close()
+
+
+def test_loopback_failing_rank_fails_every_rank_without_a_hang(NMFk, oracle):
+    """A NaN initial factor in ONE shard (restart 1 -> rank 1 of 3): that rank's local sweep returns NMFK_ERR_NAN_INIT; the
+    status agreement makes every rank (and nmfk_multi_sweep) return it instead of blocking in the all-gather."""
+    from nmfk_jl_amd import _lib
+
+    X = _case(oracle, 120, 40)
+    N, R, k = 3, 6, 3
+    seeds = [NMFk.run_seed(4, k, r) for r in range(R)]
+    W0 = np.stack([oracle.init_factors(int(s), *X.shape, k)[0] for s in seeds])
+    H0 = np.stack([oracle.init_factors(int(s), *X.shape, k)[1] for s in seeds])
+    W0[1, 5, 1] = np.nan
+    mh = _lib.Multi(N, loopback=True)
+    mh.set_X(X)
+    with pytest.raises(NMFk.NMFkError, match="GPU 1: Initial values") as ei:
+        mh.mu_sweep([k], R, Winit={k: W0}, Hinit={k: H0}, maxiter=10, **NOSTOP)
+    assert ei.value.code == _lib.ERR_NAN_INIT
+    out, err = _ranks_in_threads(mh, lambda g, comm: comm.mu_sweep([k], R, Winit={k: W0}, Hinit={k: H0}, maxiter=10, **NOSTOP))
+    assert all(isinstance(e, NMFk.NMFkError) and e.code == _lib.ERR_NAN_INIT for e in err), err
+    assert "Initial values" in str(err[1]) and "rank 1 of 3 failed" in str(err[0]) and "rank 1 of 3 failed" in str(err[2])
+    # the communicators are still usable afterwards
+    W0[1, 5, 1] = 0.5
+    a = mh.mu_sweep([k], R, Winit={k: W0}, Hinit={k: H0}, maxiter=10, **NOSTOP)[k]
+    assert np.isfinite(a["objvalue"]).all()
+    # X with a negative entry: the root's NMFpreprocessing! fails on every rank alike -> one error, no hang
+    Xbad = X.copy()
+    Xbad[3, 3] = -1.0
+    with pytest.raises(NMFk.NMFkError, match="nonnegative"):
+        mh.set_X(Xbad)
+    mh.close()

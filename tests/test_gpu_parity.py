@@ -966,13 +966,14 @@ def test_robustkmeans_krange_and_cache(NMFk, ctx, oracle, tmp_path):
     assert got["k"] == kbest and np.array_equal(got["assignments"], best["assignments"])
     assert abs(got["worst_silhouette"] - best["worst_silhouette"]) < 1e-6
     assert NMFk.robustkmeans(X[:, :2], [2, 3], 5, ctx=ctx) is None
-    # result cache (Clus:173-199, 236-244; .npz payload: the reference stores a KmeansResult struct, which is not written here)
+    # result cache (Clus:173-199, 236-244): the reference's .jld with the KmeansResult struct and the silhouettes
     r1, s1 = NMFk.robustkmeans(X, 3, 10, ctx=ctx, save=True, resultdir=str(tmp_path), casefilename="Hmatrix",
                                compute_silhouettes_flag=True)
-    assert os.path.isfile(tmp_path / "Hmatrix-3-5_60-10.npz")
+    assert os.path.isfile(tmp_path / "Hmatrix-3-5_60-10.jld")
     r2, s2 = NMFk.robustkmeans(X, 3, 10, ctx=ctx, load=True, seed=999, resultdir=str(tmp_path), casefilename="Hmatrix",
                                compute_silhouettes_flag=True)
     assert np.array_equal(r1["assignments"], r2["assignments"]) and np.array_equal(s1, s2) and r2["totalcost"] == r1["totalcost"]
+    assert np.array_equal(r1["centers"], r2["centers"]) and np.array_equal(r1["costs"], r2["costs"]) and r2["iterations"] == r1["iterations"]
 
 
 def test_robustkmeans_rows_of_W_at_bench_size(NMFk, ctx, oracle):
@@ -997,8 +998,8 @@ def test_merged_sweep_is_bitwise_reproducible_run_to_run(NMFk, oracle, forced_me
     op_sel[1] = 1 on a VGPR src1 return wrong low halves in the lanes 48-63 while a wave on the same CU issues gfx950's
     128-bit-operand matrix instructions (our MFMA group, or any bf16 GEMM of another process); this very combination
     differed in 299 of 299 repetitions.  The generated code no longer contains that form (tests/test_isa_lint.py).
-    Default schedule and the explicit request (NMFK_HYB=1 NMFK_MERGE=1); scripts/dbg_*.sh, scratch/burner.hip and
-    scratch/pk_victim.hip keep the reproducers."""
+    Default schedule and the explicit request (NMFK_HYB=1 NMFK_MERGE=1); scripts/dbg_*.sh, tools/hazard/burner.hip and
+    tools/hazard/pk_victim.hip keep the reproducers."""
     n, m = 700, 130
     X = (0.05 + oracle.uniform_fill(33, 0, n * m)).reshape(n, m).astype(np.float32)
     ctx = NMFk.Context(0)

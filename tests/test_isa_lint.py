@@ -47,8 +47,35 @@ def test_no_kernel_contains_the_unsafe_packed_form():
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
 def test_the_lint_finds_the_form_when_the_operand_rule_is_dropped():
     """The same sources with the broadcast operand second again (-DNMFK_UNSAFE_OPERAND_ORDER, what
-    scripts/build_hazard_lib.sh builds): hipcc emits the unsafe select in the mixed-rank kernels and the lint must say so."""
+    tools/hazard/build_hazard_lib.sh builds): hipcc emits the unsafe select in the mixed-rank kernels and the lint must say so."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "isa_lint_pk_opsel.py"), "--tu", "nmfk_step_f32.hip",
                         "-DNMFK_UNSAFE_OPERAND_ORDER=1"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 1, r.stdout + r.stderr
     assert "step_kernel_multi" in r.stdout and "op_sel:[0,1,0]" in r.stdout, r.stdout
+
+
+def test_the_built_library_is_linted_as_shipped():
+    """the operand-order rule is only as good as the code hipcc generated for THIS build, so the check
+    runs on the library that ships: the Makefile's link step calls the lint with --so (gfx950 code objects unbundled from
+    .hip_fatbin, llvm-objdump -d) and removes the library on a hit.  Here: the Makefile has that step, the built library
+    passes it, and the disassembly scanner recognises the unsafe form in llvm-objdump's syntax."""
+    m = _lint()
+    mk = open(os.path.join(ROOT, "nmfk.jl_amd", "csrc", "Makefile")).read()
+    assert "isa_lint_pk_opsel.py" in mk and "--so $@" in mk and "rm -f $@" in mk
+    text = """
+0000000000001900 <_Z4goodv>:
+\tv_pk_fma_f32 v[46:47], v[52:53], v[48:49], v[46:47] op_sel:[1,0,0]                  // 000000001904: D3B0082E 1CBA6134
+0000000000002a00 <_Z3badv>:
+\tv_pk_fma_f32 v[62:63], v[24:25], v[52:53], v[62:63] op_sel:[0,1,0]     // 000000002A04: D3B0103E 1CFA6918
+\tv_pk_mul_f32 v[2:3], v[4:5], s[6:7] op_sel:[0,1]     // 000000002A0C: D3B11002 18000D04
+"""
+    hits = m.scan_disassembly(text)
+    assert list(hits) == ["_Z3badv"] and len(hits["_Z3badv"]) == 1
+    so = os.path.join(ROOT, "nmfk.jl_amd", "libnmfk_hip.so")
+    if not (os.path.exists(so) and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump")):
+        pytest.skip("needs the built library and llvm-objdump")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "isa_lint_pk_opsel.py"), "--so", so], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and " 0 unsafe packed instruction(s) among " in r.stdout, r.stdout + r.stderr
+    npk = int(r.stdout.split(" among ")[1].split()[0])
+    assert npk > 1000, r.stdout  # the scan saw the packed-VALU kernels (it is not vacuous)

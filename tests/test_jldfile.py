@@ -97,3 +97,77 @@ def test_all_payload_roundtrip(tmp_path):
     assert len(root["children"]["_refs"]["children"]) == 2 * R
     w, h, f = resultio.load(fn, "W", "H", "fit").values()  # JLD.load(filename, "W", "H", "fit") of Exec:503
     assert len(w) == R and f.shape == (R,)
+
+
+def test_superblock_fields_match_the_julia_written_files(tmp_path):
+    """the superblock's end-of-file address is ABSOLUTE.  libhdf5 limits addresses to eof - base, so a
+    file that stores (size - 512) puts its last 512 bytes -- where the root group header sits -- out of reach and
+    JLD.load fails with an address overflow although our own reader (which ignored the field) was happy.  Pin base and EOF
+    of a written file to what both Julia-written fixtures hold: base = 512, EOF = file size; and the reader now rejects a
+    file whose EOF differs from its size."""
+    import struct
+
+    from nmfk_jl_amd import jldfile
+
+    def fields(path):
+        b = open(path, "rb").read()
+        at = b.find(jldfile.SIG)
+        base, _, eof, _ = struct.unpack_from("<QQQQ", b, at + 24)
+        return at, base, eof, len(b)
+
+    for name in ("julia_written_Hmatrix-2-2_10-1000.jld", "julia_written_Wmatrix-4-4_100-1000.jld"):
+        at, base, eof, size = fields(os.path.join(GOLD, name))
+        assert (at, base, eof) == (512, 512, size)
+    fn = str(tmp_path / "w.jld")
+    jldfile.save(fn, {"W": [np.ones((3, 2), np.float32)] * 2, "fit": np.arange(4, dtype=np.float32), "big": np.zeros((64, 64))})
+    at, base, eof, size = fields(fn)
+    assert (at, base, eof) == (512, 512, size) == (512, 512, os.path.getsize(fn))
+    assert set(jldfile.load(fn)) >= {"W", "fit", "big"}
+    raw = bytearray(open(fn, "rb").read())
+    struct.pack_into("<Q", raw, 512 + 40, size - 512)  # the round-2 defect
+    open(fn, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="end-of-file"):
+        jldfile.load(fn)
+
+
+def test_kmeans_result_struct_is_written_like_julia(tmp_path):
+    """The robustkmeans cache of the reference (src/NMFkCluster.jl:236-244: JLD.save(filename, "assignments", sc,
+    "best_silhouettes", ...)) holds a Clustering.KmeansResult struct.  The writer's committed compound datatype must be,
+    byte for byte, the datatype message of the Julia-written fixture; a written file reads back like the fixture does."""
+    import struct
+
+    from nmfk_jl_amd import jldfile
+
+    gold = os.path.join(GOLD, "julia_written_Hmatrix-2-2_10-1000.jld")
+    root, R = jldfile.read_structure(gold)
+    tnode = root["children"]["_types"]["children"]["00000001"]
+    assert tnode["attrs"]["julia type"] == jldfile.KMEANS_JULIA_TYPE
+    gold_msg = next(bytes(b) for t, b in R.messages(tnode["header"]) if t == 0x0003)
+    mine = jldfile.kmeans_result_datatype()
+    assert gold_msg[:len(mine)] == mine and not any(gold_msg[len(mine):])  # (the stored message is padded to 8 bytes)
+    g = jldfile.load(gold)
+    assert g["assignments"]["assignments_"].tolist() == [1, 2, 1, 1, 1, 1, 2, 1, 1, 1] and g["assignments"]["counts_"].tolist() == [8, 2]
+    assert g["assignments"]["centers_"].shape == (2, 2) and g["assignments"]["converged_"] == 1
+    # write the same content, read it back, and compare the object-level structure with the fixture's
+    fn = str(tmp_path / "Hmatrix-2-2_10-1000.jld")
+    jldfile.save(fn, {"assignments": g["assignments"], "best_silhouettes": g["best_silhouettes"]})
+    z = jldfile.load(fn)
+    for key, val in g["assignments"].items():
+        assert np.array_equal(np.asarray(z["assignments"][key]), np.asarray(val)), key
+    assert np.array_equal(z["best_silhouettes"], g["best_silhouettes"])
+    r2, R2 = jldfile.read_structure(fn)
+    a, b = root["children"], r2["children"]
+    assert a["assignments"]["type"] == b["assignments"]["type"] and a["assignments"]["shape"] == b["assignments"]["shape"]
+    assert b["_types"]["children"]["00000001"]["attrs"] == tnode["attrs"]
+    assert {k: (v["type"], v["shape"]) for k, v in a["_refs"]["children"].items()} == \
+           {k: (v["type"], v["shape"]) for k, v in b["_refs"]["children"].items()}
+    # the dataset's datatype message is the SHARED form pointing at the committed type, as in the fixture
+    for Rx, node, types in ((R, a["assignments"], a["_types"]), (R2, b["assignments"], b["_types"])):
+        o = Rx.at(node["header"])
+        p = o + 16
+        for _ in range(struct.unpack_from("<H", Rx.buf, o + 2)[0]):
+            mtype, msize, flags = struct.unpack_from("<HHB", Rx.buf, p)
+            if mtype == 3:
+                assert flags == 3 and Rx.buf[p + 8:p + 10] == b"\x02\x02"
+                assert struct.unpack_from("<Q", Rx.buf, p + 10)[0] == types["children"]["00000001"]["header"]
+            p += 8 + msize

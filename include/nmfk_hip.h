@@ -254,6 +254,11 @@ int nmfk_set_profiling(nmfk_ctx *ctx, int enabled);
  * packed-VALU ranks afterwards), info[1] = units on the split-operand MFMA half-step, info[2] = mixed-rank packed-VALU
  * launch groups, info[3] = launch groups in all, info[4] = units on the all-MFMA half-step (k > 16), info[5..7] reserved. */
 int nmfk_last_sweep_info(nmfk_ctx *ctx, int32_t info[8]);
+/* The objective the stop rule monitors -- sum((((X - W*H) .* weight)[.!inan]).^2) every 10th iteration (Mult:73-74) -- as
+ * the device computed it, for every check of every restart of the NEXT sweeps (parity tests compare it with the oracle's
+ * trace check by check).  nmfk_get_objective_trace: restart `restart` of rank ks[kidx] of the last sweep; *count = checks made. */
+int nmfk_set_objective_trace(nmfk_ctx *ctx, int enabled);
+int nmfk_get_objective_trace(nmfk_ctx *ctx, int kidx, int restart, double *out, int cap, int *count);
 int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *total_ms, int64_t *launches,
                      double *flops, int *count);
 

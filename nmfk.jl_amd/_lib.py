@@ -85,6 +85,8 @@ def lib():
                                     ip, C.POINTER(C.c_double), ip, ip, ip, C.c_void_p, C.c_void_p]
     L.nmfk_frobenius.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_double)]
     L.nmfk_set_profiling.argtypes = [vp, C.c_int]
+    L.nmfk_set_objective_trace.argtypes = [vp, C.c_int]
+    L.nmfk_get_objective_trace.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
     L.nmfk_last_sweep_info.argtypes = [vp, C.POINTER(C.c_int32)]
     i32p = C.POINTER(C.c_int32)
     L.nmfk_shard_plan.argtypes = [C.c_int, C.c_int, C.c_int, i32p, i32p]
@@ -486,6 +488,17 @@ class Context:
         _check(lib().nmfk_last_sweep_info(self._h, info))
         return dict(phases=info[0], mfma_group_units=info[1], merged_valu_groups=info[2], launch_groups=info[3],
                     wide_mfma_units=info[4])
+
+    def set_objective_trace(self, on=True):
+        """nmfk_set_objective_trace: record the monitored objective (Mult:74) at every check of the next sweeps."""
+        _check(lib().nmfk_set_objective_trace(self._h, int(on)))
+
+    def objective_trace(self, kidx, restart, cap=100000):
+        """nmfk_get_objective_trace: the checks of restart `restart` of the kidx-th rank of the last mu_sweep."""
+        out = (C.c_double * cap)()
+        n = C.c_int()
+        _check(lib().nmfk_get_objective_trace(self._h, int(kidx), int(restart), out, cap, C.byref(n)))
+        return np.array(out[:min(n.value, cap)], dtype=np.float64)
 
     def set_profiling(self, on=True):
         _check(lib().nmfk_set_profiling(self._h, int(on)))

@@ -104,9 +104,13 @@ struct Sampler {
 //   NMFK_MFMA_SSE, NMFK_HYB_SSE   0: monitored objective of the MFMA groups on the packed-VALU objective kernel
 //   NMFK_STREAMS      concurrent rank-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1 prints the host's share of the loop
 //   NMFK_MERGE_PHASED 1: merged sweeps run their matrix-pipe groups first and the packed-VALU group behind them (default: side by side)
+//   NMFK_HYB_RES      0: no resident form of the split-operand MFMA half-step (short loop dimension: the loop factor in LDS)
+//   NMFK_HYB_RES_TPW  pairs of lane tiles a wave of the resident form should walk (4)
+//   NMFK_HYB_SMALL    0: ranks <= 8 keep the round-2 forms (packed-VALU / 16-signal MFMA) -- A/B switch for the 4x4x1 variants
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, hyb_groups = 1, merge = -1, phases = -1, max_wsplit = 8;
-  int wide_sse = 1, hyb_sse = 1, streams = -1, host_timing = 0, merge_phased = 0;
+  int wide_sse = 1, hyb_sse = 1, streams = -1, host_timing = 0, merge_phased = 0, hyb_small = 1;
+  int hyb_res = 1, hyb_res_tpw = 4;
 };
 Tuning read_tuning() {
   Tuning t;
@@ -130,6 +134,10 @@ Tuning read_tuning() {
   if (t.streams >= 0) t.streams = std::max(1, std::min(64, t.streams));
   geti("NMFK_HOST_TIMING", t.host_timing);
   geti("NMFK_MERGE_PHASED", t.merge_phased);
+  geti("NMFK_HYB_SMALL", t.hyb_small);
+  geti("NMFK_HYB_RES", t.hyb_res);
+  geti("NMFK_HYB_RES_TPW", t.hyb_res_tpw);
+  t.hyb_res_tpw = std::max(1, t.hyb_res_tpw);
   return t;
 }
 
@@ -462,6 +470,28 @@ NMFK_EXPORT int nmfk_set_profiling(nmfk_ctx *ctx, int enabled) {
   return NMFK_OK;
 }
 
+NMFK_EXPORT int nmfk_set_objective_trace(nmfk_ctx *ctx, int enabled) {
+  if (!ctx) return fail(NMFK_ERR_BAD_ARG, "ctx is null");
+  ctx->trace_objective = enabled != 0;
+  ctx->obj_trace.clear();
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_get_objective_trace(nmfk_ctx *ctx, int kidx, int restart, double *out, int cap, int *count) {
+  if (!ctx || !count || cap < 0 || (cap > 0 && !out)) return fail(NMFK_ERR_BAD_ARG, "bad argument");
+  *count = 0;
+  if (ctx->obj_trace.empty()) return fail(NMFK_ERR_BAD_ARG, "no objective trace: nmfk_set_objective_trace before the sweep");
+  const size_t idx = (size_t)kidx * ctx->obj_trace_nruns + restart;
+  if (kidx < 0 || restart < 0 || restart >= ctx->obj_trace_nruns || idx >= ctx->obj_trace_unit.size() || ctx->obj_trace_unit[idx] < 0)
+    return fail(NMFK_ERR_BAD_ARG, "no such unit in the last sweep");
+  const double *t = ctx->obj_trace.data() + (size_t)ctx->obj_trace_unit[idx] * ctx->obj_trace_stride;
+  int n = 0;
+  while (n < ctx->obj_trace_stride && t[n] == t[n]) ++n;  // (slots of checks that never happened hold NaN bits)
+  for (int i = 0; i < n && i < cap; ++i) out[i] = t[i];
+  *count = n;
+  return NMFK_OK;
+}
+
 NMFK_EXPORT int nmfk_last_sweep_info(nmfk_ctx *ctx, int32_t info[8]) {
   if (!ctx || !info) return fail(NMFK_ERR_BAD_ARG, "bad argument");
   memcpy(info, ctx->sweep_info, sizeof(ctx->sweep_info));
@@ -557,14 +587,16 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   if (hyb_on < 0) {  // automatic (an explicit NMFK_MERGE keeps the packed-VALU groups)
     const double Erel = (double)n * m / (8192.0 * 512.0);
     const double wg_ns = 8.5 * ((double)n + m) / 256.0;              // per-workgroup overhead of a unit of the group
-    const double k0 = 8.8 + (wg_ns / Erel - 8.5 * 34.0) / 324.0;     // break-even rank (8.8 at 8192 x 512)
-    // first rank of the group: the break-even (9 at the reference shape, also with 16 restarts per rank: 206 vs 216 ms
-    // per 200 iterations; 2048 x 2048: 180 vs 294), 6 in merged sweeps
-    // (<= 4 restarts per rank, a rank's share at 8 GPUs: ALL ranks 2..16 on the group, one phase and no packed-VALU
-    // launches at all -- 124 vs 140 ms per 400 iterations at k = 2:16; with 8 restarts the two are level, 230 vs 226)
-    const int mk = hyb_mink >= 0 ? hyb_mink : (nruns <= 4 ? 2 : nruns <= 8 ? 6 : std::min(16, (int)ceil(k0)));
+    const double k0 = 8.8 + (wg_ns / Erel - 8.5 * 34.0) / 324.0;     // round 2's break-even rank against the 16-signal form
+    // Round 3: the matrix-pipe kernel no longer pads a rank to 16 signals (nmfk_step_hyb.hip: one bf16 MFMA and 4x4x1
+    // numerator blocks for k <= 4, two and eight for k <= 8), which puts EVERY rank <= 16 below its packed-VALU cost
+    // (k = 2: ~1.5 vs 2.1 us per factorization and iteration at the reference shape, k = 8: ~2.2 vs 4.0): first rank 2.
+    // NMFK_HYB_SMALL=0 restores round 2's rule (first rank = break-even against the 16-signal form; 2 / 6 in merged sweeps).
+    const int mk = hyb_mink >= 0 ? hyb_mink
+                   : T.hyb_small ? 2
+                                 : (nruns <= 4 ? 2 : nruns <= 8 ? 6 : std::min(16, (int)ceil(k0)));
     int hyb_units = 0;
-    double hyb_score = 0;  // what the group saves, in rank-restarts (a packed-VALU unit costs ~k, a unit of the group ~k0)
+    double hyb_score = 0;  // what the group saves, in rank-restarts (round 2's model: a packed-VALU unit costs ~k, a unit of the group ~k0)
     for (int q = 0; q < nk; ++q)
       if (hyb_fits && ks[q] <= 16 && ks[q] >= mk) {
         hyb_units += nruns;
@@ -576,9 +608,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if ((merge > 0 && !merge_env) || few) {  // few restarts per rank: merged sweep
       hyb_on = 1;
       if (hyb_units > 0) merge = 1;  // the few small ranks left: one packed-VALU group (126 vs 130 ms per 400 iterations)
-    } else if (merge == 0 && !merge_env && nruns >= 16 && launch_ns >= 50e3 && 2 * h_wgs >= cus && hyb_score >= 300) {
+    } else if (merge == 0 && !merge_env && nruns >= 16 && launch_ns >= 50e3 && 2 * h_wgs >= cus && (T.hyb_small || hyb_score >= 300)) {
       hyb_on = 1;
-      hyb_phases = true;
+      hyb_phases = true;  // (only matters when packed-VALU ranks are left: they run behind the matrix-pipe groups)
     } else {
       hyb_on = 0;
     }
@@ -591,6 +623,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // "Known hazard"; its generated code is free of the unsafe instruction form now and checked by tests/test_isa_lint.py.)
   const bool valu_merged = merge > 0 && (f64 || NMFK_WITH_MERGED_F32 != 0);
   auto use_hyb_k = [&](int k) { return hyb_on && hyb_fits && k <= 16 && k >= hyb_mink; };
+  // kernel variant of a rank on the split-operand MFMA half-step (nmfk_hyb_variant: 4 / 8 / 12 / 16)
+  auto hyb_variant_of = [&](int k) { return T.hyb_small ? nmfk_hyb_variant(k) : 16; };
+  int hyb_vmax = 4;  // widest variant among the units of the matrix-pipe groups (sizes their LDS)
+  for (int q = 0; q < nk; ++q)
+    if (use_hyb_k(ks[q])) hyb_vmax = std::max(hyb_vmax, hyb_variant_of(ks[q]));
   // lane elements per workgroup (= per sum-table slot) of the half-step kernel a rank runs
   auto lane_tile = [&](int k, int ws) {
     if (ctx->sparse) return NMFK_TILE;
@@ -598,6 +635,27 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if (use_hyb_k(k)) return nmfk_hyb_lane_tile(ws);
     if (valu_merged && k <= NMFK_MULTI_MAXK && !use_hyb_k(k)) return (ws > 1 ? 64 : NMFK_TILE) * NMFK_MULTI_LB;
     return (ws > 1 ? 64 : NMFK_TILE) * NMFK_LB_OF(nmfk_padded_k(k));
+  };
+  // Resident form of the split-operand MFMA half-step (nmfk_step_hyb.hip, hyb_res_kernel): when the loop dimension is
+  // short enough for the whole loop factor to sit in LDS (the W half-step of a tall X), the units of the matrix-pipe
+  // groups run it with res_wgs[which] workgroups of 16 waves per unit, each wave walking several pairs of lane tiles.
+  int res_wgs[2] = {0, 0};  // [0] H half-step (L = m, D = n), [1] W half-step (L = n, D = m)
+  if (hyb_on && T.hyb_res) {
+    int hyb_units = 0;
+    for (int q = 0; q < nk; ++q) hyb_units += use_hyb_k(ks[q]) ? nruns : 0;
+    for (int which = 0; which < 2 && hyb_units > 0; ++which) {
+      const int L = which == 0 ? m : n, D = which == 0 ? n : m;
+      if (nmfk_hyb_resident_lds(hyb_vmax, D) == 0) continue;
+      const int ntp = (L + 31) / 32;                                     // pairs of 16-lane tiles
+      const int fill = (4 * cus + hyb_units - 1) / hyb_units;            // workgroups per unit that fill the chip a few times
+      const int rw = nmfk_hyb_resident_waves();
+      res_wgs[which] = std::max(1, std::min(std::max(1, ntp / rw), std::max(std::max(1, ntp / (rw * T.hyb_res_tpw)), fill)));
+    }
+  }
+  // workgroups (= lane tiles = sum-table slots) of one unit of rank k in the half-step `which`
+  auto tiles_of = [&](int k, int which, int L, int ws) {
+    if (use_hyb_k(k) && res_wgs[which] > 0) return res_wgs[which];
+    return (L + lane_tile(k, ws) - 1) / lane_tile(k, ws);
   };
   const int max_ws = T.max_wsplit;
   // phases of a two-phase sweep run one after the other, so each gets the geometry that fills the chip with ITS units
@@ -607,12 +665,12 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   for (int q = 0; q < nk; ++q) any_hyb_k = any_hyb_k || use_hyb_k(ks[q]);
   const bool phased = hyb_phases || (valu_merged && any_hyb_k && T.merge_phased);
   auto phase_of_k = [&](int k) { return phased && !use_hyb_k(k) && !(merge > 0 && use_wide_k(k)) ? 1 : 0; };
-  auto geometry = [&](int L, int D, int phase) {
+  auto geometry = [&](int L, int D, int phase, int which) {
     Geo g;
     auto wgs = [&](int ws) {  // workgroups of one half-step over all units of the phase
       int64_t t = 0;
       for (int q = 0; q < nk; ++q)
-        if (phase_of_k(ks[q]) == phase) t += (int64_t)((L + lane_tile(ks[q], ws) - 1) / lane_tile(ks[q], ws)) * nruns;
+        if (phase_of_k(ks[q]) == phase) t += (int64_t)tiles_of(ks[q], which, L, ws) * nruns;
       return std::max<int64_t>(t, 1);
     };
     g.wsplit = 1;
@@ -630,11 +688,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     g.slots = 1;  // slots of the sum tables = the most lane tiles any rank's kernel uses
     for (int q = 0; q < nk; ++q)
       if (phase_of_k(ks[q]) == phase)
-        g.slots = std::max(g.slots, (L + lane_tile(ks[q], g.wsplit) - 1) / lane_tile(ks[q], g.wsplit));
+        g.slots = std::max(g.slots, tiles_of(ks[q], which, L, g.wsplit));
     return g;
   };
-  Geo ghp[2] = {geometry(m, n, 0), geometry(m, n, phased ? 1 : 0)};
-  Geo gwp[2] = {geometry(n, m, 0), geometry(n, m, phased ? 1 : 0)};
+  Geo ghp[2] = {geometry(m, n, 0, 0), geometry(m, n, phased ? 1 : 0, 0)};
+  Geo gwp[2] = {geometry(n, m, 0, 1), geometry(n, m, phased ? 1 : 0, 1)};
   if (ctx->sparse) {  // gather kernels, always finished in-kernel; the H half-step's slots are per pass (see NmfkSparseArgs)
     int slots_h = 1;
     for (int q = 0; q < nk; ++q) {
@@ -656,6 +714,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   const size_t o_flag = B.take(256);
   const size_t o_args = B.take(4 * sizeof(NmfkStepArgs));
   const size_t o_ptrs = B.take(sizeof(void *) * 7 * nk);
+  const int trace_stride = ctx->trace_objective ? (int)std::max<int64_t>(1, P.maxiter / 10) : 0;
+  const size_t o_trace = ctx->trace_objective ? B.take(sizeof(double) * (size_t)nunits * trace_stride) : 0;
   std::vector<NmfkRun> runs(nunits);
   std::vector<size_t> o_Wi(nk, 0), o_Hi(nk, 0), o_Wo(nk), o_Ho(nk), o_frob(nk), o_iters(nk), o_reason(nk);
   struct Group {
@@ -680,15 +740,16 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       groups.back().kp = std::max(groups.back().kp, nmfk_padded_k(k));
       groups.back().count += nruns;
     } else {
-      groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns, use_hyb_k(k) ? (k <= 8 ? 8 : 16) : 0, phase_of_k(k)});
+      groups.push_back({k, nmfk_padded_k(k), (int)ulist.size(), nruns, use_hyb_k(k) ? hyb_vmax : 0, phase_of_k(k)});
     }
     for (int r = 0; r < nruns; ++r) ulist.push_back({q, r});
   }
   // merged sweeps: the ranks of the split-operand MFMA kernel (its cost does not depend on the rank, one instantiation
   // serves them all at split width 16) form mixed-rank groups of their own, the other ranks <= 16 the VALU ones
   const int hg = (merge > 0 || hyb_phases) ? std::min(hyb_groups, nruns) : 0;
+  // (ONE launch group whatever the kernel variants of its units are: the kernels switch per workgroup, NmfkRun::hyb)
   for (int g = 0; g < hg; ++g) {
-    Group G{0, 0, (int)ulist.size(), 0, 16, 0};
+    Group G{0, 0, (int)ulist.size(), 0, hyb_vmax, 0};
     for (int oi = 0; oi < nk; ++oi) {
       const int q = order[oi];
       if (ks[q] > NMFK_MULTI_MAXK || !use_hyb_k(ks[q])) continue;
@@ -727,11 +788,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         rd.seed = seeds ? seeds[(size_t)q * nruns + r] : 0;
         // slots the unit's kernels write: the fused half-step one per lane tile, the grid-parallel helpers any count
         const Geo &gh = ghp[phase_of_k(k)], &gw = gwp[phase_of_k(k)];
-        rd.nsH = gh.fused ? (m + lane_tile(k, gh.wsplit) - 1) / lane_tile(k, gh.wsplit) : PH;
+        rd.nsH = (gh.fused || (use_hyb_k(k) && res_wgs[0] > 0)) ? tiles_of(k, 0, m, gh.wsplit) : PH;
         if (ctx->sparse) rd.nsH = (m + nmfk_sp_slot(kp, 1) - 1) / nmfk_sp_slot(kp, 1);
-        rd.nsW = gw.fused ? (n + lane_tile(k, gw.wsplit) - 1) / lane_tile(k, gw.wsplit) : PW;
+        rd.nsW = (gw.fused || (use_hyb_k(k) && res_wgs[1] > 0)) ? tiles_of(k, 1, n, gw.wsplit) : PW;
         rd.hyb = rd.pad0 = 0;
-        if (use_hyb_k(k)) rd.hyb = (merge > 0 || hyb_phases || k > 8) ? 16 : 8;
+        if (use_hyb_k(k)) rd.hyb = hyb_variant_of(k);
       }
     }
   }
@@ -763,6 +824,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   HIPCHECK(hipMemcpyAsync(A + o_runs, runs.data(), sizeof(NmfkRun) * nunits, hipMemcpyHostToDevice, st));
   HIPCHECK(hipMemcpyAsync(A + o_ptrs, ptrs.data(), sizeof(void *) * ptrs.size(), hipMemcpyHostToDevice, st));
   HIPCHECK(hipMemsetAsync(A + o_flag, 0, 256, st));
+  if (trace_stride) HIPCHECK(hipMemsetAsync(A + o_trace, 0xff, sizeof(double) * (size_t)nunits * trace_stride, st));  // NaN = no check
   for (int q = 0; q < nk; ++q) {
     const size_t k = (size_t)ks[q];
     if (Winit && Winit[q])
@@ -836,7 +898,10 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   hs.state = d_state;
   hs.nunits = nunits;
   hs.force = 0;
+  hs.res_wgs = res_wgs[0];
+  hs.pad1 = 0;
   NmfkStepArgs ws = hs;
+  ws.res_wgs = res_wgs[1];
   ws.X = ctx->Xc;
   ws.Xalt = ctx->Xr;
   ws.Xtile = any_hyb ? (const float *)ctx->xtile.p + tile_h : nullptr;
@@ -899,6 +964,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ca.runs = d_runs;
   ca.state = d_state;
   ca.nunits = nunits;
+  ca.trace = trace_stride ? (double *)(A + o_trace) : nullptr;
+  ca.trace_stride = trace_stride;
 
   NmfkSparseArgs sph, spw;  // CSC view (H half-step), CSR view (W half-step, objective)
   sph.arena = A;
@@ -1032,7 +1099,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         else
           nmfk_launch_step_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         if (timed) prof.end(e0, PK_HSTEP, j, it, gs);
-        if (!hs.fused) {
+        if (!hs.fused && !(use_hyb(G) && hs.res_wgs > 0)) {  // (the resident form always finishes itself)
           if (f64)
             nmfk_launch_reduce_f64(hs, G.begin, G.count, gs);
           else
@@ -1061,7 +1128,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         else
           nmfk_launch_step_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         if (timed) prof.end(e0, PK_WSTEP, j, it, gs);
-        if (!ws.fused) {
+        if (!ws.fused && !(use_hyb(G) && ws.res_wgs > 0)) {
           if (f64)
             nmfk_launch_reduce_f64(ws, G.begin, G.count, gs);
           else
@@ -1199,6 +1266,16 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     HIPCHECK(hipMemcpyAsync(h_iters[q].data(), A + o_iters[q], sizeof(int32_t) * nruns, hipMemcpyDeviceToHost, st));
   }
   HIPCHECK(hipStreamSynchronize(st));
+
+  ctx->obj_trace.clear();
+  if (trace_stride) {
+    ctx->obj_trace.resize((size_t)nunits * trace_stride);
+    HIPCHECK(hipMemcpy(ctx->obj_trace.data(), A + o_trace, sizeof(double) * ctx->obj_trace.size(), hipMemcpyDeviceToHost));
+    ctx->obj_trace_stride = trace_stride;
+    ctx->obj_trace_nruns = nruns;
+    ctx->obj_trace_unit.assign((size_t)nk * nruns, -1);
+    for (int u = 0; u < nunits; ++u) ctx->obj_trace_unit[(size_t)runs[u].kidx * nruns + runs[u].ridx] = u;
+  }
 
   // sse_out (Mult:125); it may be device memory: stage through a host vector.  Unweighted: normnan(X - W*H)^2.
   if (sse_out) {

@@ -77,6 +77,9 @@ struct NmfkStepArgs {
   NmfkState *state;
   int32_t nunits;
   int32_t force;    // ignore the active flags
+  int32_t res_wgs;  // > 0: the split-operand MFMA units run the RESIDENT form of this half-step (nmfk_step_hyb.hip) with
+                    // this many workgroups per unit (= sum-table slots they write); 0: the streaming form
+  int32_t pad1;
 };
 
 struct NmfkSseArgs {
@@ -122,6 +125,8 @@ struct NmfkCheckArgs {
   const NmfkRun *runs;
   NmfkState *state;
   int32_t nunits;
+  double *trace;         // optional (nmfk_set_objective_trace): monitored objective of unit u at check c -> trace[u * trace_stride + c]
+  int32_t trace_stride;
 };
 
 struct NmfkFinishArgs {
@@ -250,6 +255,9 @@ void nmfk_launch_step_mfma_wide_f32(const NmfkStepArgs &a, const NmfkStepArgs *d
                                     hipStream_t s);
 int nmfk_mfma_wide_lane_tile(int wsplit);
 int nmfk_hyb_lane_tile(int wsplit);
+int nmfk_hyb_resident_waves();  // waves per workgroup of the resident form
+size_t nmfk_hyb_resident_lds(int variant, int D);  // LDS bytes of the resident form for a loop dimension D, 0 = not applicable
+int nmfk_hyb_variant(int k);  // kernel variant of rank k on the split-operand MFMA half-step: 4 / 8 / 12 / 16
 void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int ks, int u0, int cnt, hipStream_t s);
 void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double weight, int hsel, int ks, int u0, int cnt,
                          hipStream_t s);

@@ -88,5 +88,10 @@ struct nmfk_ctx {
   };
   std::map<std::string, ProfEntry> prof;
   int32_t sweep_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // nmfk_last_sweep_info
+  // nmfk_set_objective_trace: the monitored objective (Mult:74) of every unit at every check of the last sweep
+  bool trace_objective = false;
+  std::vector<double> obj_trace;  // [unit][check]
+  std::vector<int32_t> obj_trace_unit;  // (kidx * nruns + restart) -> unit
+  int32_t obj_trace_stride = 0, obj_trace_nruns = 0;
 };
 

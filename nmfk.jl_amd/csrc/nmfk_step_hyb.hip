@@ -11,6 +11,15 @@
 //     term blocks at once -> 3 or 2 MFMAs of 16 cycles per 16 x 16 tile of P;
 //   * Q = X ./ P on the VALU (v_rcp_f32 + mul), it comes out of the MFMA in B-operand layout;
 //   * N += B' Q on the matrix pipe in plain fp32 (v_mfma_f32_16x16x4_f32, 4 per tile), no rounding of Q.
+// Round 3: the rank is no longer padded to 16 on the matrix pipe.
+//   * first product: the six term blocks need 6k contraction slots, v_mfma_f32_16x16x32_bf16 has 32: ONE instruction for
+//     k <= 4 (KS = 4), two for k <= 8 (KS = 8), three for k <= 16 (KS = 16);
+//   * second product: v_mfma_f32_4x4x1_16B_f32 -- sixteen independent 4 x 4 outer products per instruction, here "four
+//     signals x four lane elements x one loop step" -- costs 8 cycles per four signals and 64 elements, i.e. 32 * ceil(k/4)
+//     matrix cycles per 16 x 16 tile against 128 for the 16-signal form: NS = ceil(k/4) sets of accumulators (NS = 0
+//     keeps v_mfma_f32_16x16x4_f32, which is the same work for k = 13..16).  A lane's accumulators then hold the sums
+//     over ITS four loop steps of a chunk (d = 4g + r) only; the four k-lane groups are added once, after the loop.
+//   scratch/small_mfma_rate.hip measures the forms with operands in registers (profiles/r03/small_mfma_rate.txt).
 // A factor lives in HBM in ONE form, its fp32 rows [L][k].  The operand forms of the two products -- bf16 split rows for
 // the first, a transposed fp32 block for the second -- exist only in LDS: the waves of a workgroup read 64 loop rows
 // of the loop factor once, split them on the fly and lay them out for the matrix pipe (HybStage); the lane factor's
@@ -21,6 +30,13 @@
 #include <algorithm>
 #include <type_traits>
 
+// Timing ablations for scripts/r3_ablate.sh (WRONG results; never set in the product build): 1 = X entries loaded once, not
+// per chunk; 2 = the loop factor staged once (first block only); 4 = no reciprocal; 8 = no second product; 16 = no barriers;
+// resident form: 32 = no chunk loop (a tile pair's prologue and finish only), 64 = no prologue / finish work (constant operand
+// blocks, nothing loaded or stored per tile pair), 128 = no X loads inside the chunk loop
+#ifndef NMFK_HYB_ABLATE
+#define NMFK_HYB_ABLATE 0
+#endif
 #ifndef NMFK_HYB_CPB
 #define NMFK_HYB_CPB 4  // chunks of 16 loop steps per staged block of a workgroup (one barrier per block)
 #endif
@@ -33,13 +49,20 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
+#if NMFK_HYB_ABLATE & 16
+#define HYB_BARRIER() ((void)0)
+#else
 #define HYB_BARRIER() __syncthreads()
+#endif
 __device__ __forceinline__ float hyb_div(float x, float p) { return x * __builtin_amdgcn_rcpf(p); }
 
 // term blocks of the first product: MFMA j, k-lane group g -> split index (0 = h, 1 = m, 2 = l) of the loop factor
 // (A operand) and of the lane factor (B operand; -1 = zero block)
+// (KS = 4: ONE MFMA holds all six blocks, two per k-lane group -- A terms (h|h), (m|m), (h|l), B terms (h|m), (h|m), (l|h),
+//  group 3 is a zero block; its A planes are laid out as those pairs, see HybStage, so hyb_sa is the plane index)
 template <int KS>
 __device__ __forceinline__ int hyb_sa(int j, int g) {
+  if (KS == 4) return g < 2 ? g : 2;
   if (KS == 16) return j == 0 ? 0 : j == 1 ? 1 : (g < 2 ? 2 : 0);
   return j == 0 ? (g < 3 ? 0 : 1) : (g == 0 ? 1 : g == 1 ? 2 : 0);
 }
@@ -117,10 +140,18 @@ __global__ __launch_bounds__(NMFK_TILE) void hyb_tile_kernel(const float *__rest
 // Rows at or beyond the factor's last row are staged as zeros; the caller masks the ratios of the loop steps beyond
 // its own range.
 // ------------------------------------------------------------------------------------------------------
-template <int KS, int CPB, int GT, bool WITH_T>
+// TM: layout of the second product's operand block: 0 = none (objective), 1 = for v_mfma_f32_16x16x4_f32 (planes of 256 B),
+// 2 = for v_mfma_f32_4x4x1_16B_f32: the same planes (loop steps [4g, 4g + 4) of signal c at c*16) with a plane stride of
+// 320 B -- a lane reads signal 4s + (c16 & 3) of its plane g, so the 16 lanes of a read group (8 of plane g, 8 of plane
+// g + 1) touch 64 B per plane, and the 64-byte skew puts the two windows on different banks.
+// KS = 4: a chunk's split planes are the three operand PAIRS (h|h), (m|m), (h|l) of the single first-product MFMA: row r
+// of a plane = 16 B = two blocks of four bf16 signals.
+template <int KS, int CPB, int GT, int TM>
 struct HybStage {
-  static constexpr int NH = KS / 8;              // halves of 8 signals
-  static constexpr int CHP = 3 * NH * 256, CHT = 4 * 256;  // bytes of a chunk's split planes / transposed planes
+  static constexpr bool WITH_T = TM != 0;
+  static constexpr int NH = KS == 4 ? 1 : KS / 8;  // halves of 8 signals (KS = 4: one pair plane per term slot)
+  static constexpr int TPS = TM == 2 ? 320 : 256;  // plane stride of the transposed block
+  static constexpr int CHP = 3 * NH * 256, CHT = 4 * TPS;  // bytes of a chunk's split planes / transposed planes
   static constexpr int BFB = CPB * CHP, STB = BFB + (WITH_T ? CPB * CHT : 0);
   static constexpr int PPR = KS / 2;                   // signal pairs per row
   static constexpr int NITEM = 16 * CPB * PPR, NI = (NITEM + GT - 1) / GT;
@@ -144,8 +175,11 @@ struct HybStage {
       voff[i] = (uint32_t)((r * k + 2 * cp) * 4);
       c0[i] = 2 * cp < k;
       c1[i] = 2 * cp + 1 < k;
-      lsp[i] = (uint32_t)((r >> 4) * CHP + (cp >> 2) * 256 + (r & 15) * 16 + (cp & 3) * 4);  // term t: + t * NH * 256
-      ltr[i] = (uint32_t)(BFB + (r >> 4) * CHT + ((r & 15) >> 2) * 256 + 2 * cp * 16 + (r & 3) * 4);
+      if (KS == 4)
+        lsp[i] = (uint32_t)((r >> 4) * CHP + (r & 15) * 16 + cp * 4);  // pair plane p: + p * 256, second block of the pair: + 8
+      else
+        lsp[i] = (uint32_t)((r >> 4) * CHP + (cp >> 2) * 256 + (r & 15) * 16 + (cp & 3) * 4);  // term t: + t * NH * 256
+      ltr[i] = (uint32_t)(BFB + (r >> 4) * CHT + ((r & 15) >> 2) * TPS + 2 * cp * 16 + (r & 3) * 4);
     }
   }
   // fetch the block that starts at loop row `row0` (a block reads at most 64 rows = 4 KB past the end of the array,
@@ -168,9 +202,18 @@ struct HybStage {
       const float v[1][2] = {{(ok && c0[i]) ? vin[i][0] : 0.0f, (ok && c1[i]) ? vin[i][1] : 0.0f}};
       uint32_t h, m, l;
       split3_pair(v[0][0], v[0][1], h, m, l);
-      *(uint32_t *)(dst + lsp[i]) = h;
-      *(uint32_t *)(dst + lsp[i] + NH * 256) = m;
-      *(uint32_t *)(dst + lsp[i] + 2 * NH * 256) = l;
+      if (KS == 4) {
+        *(uint32_t *)(dst + lsp[i]) = h;            // (h|h)
+        *(uint32_t *)(dst + lsp[i] + 8) = h;
+        *(uint32_t *)(dst + lsp[i] + 256) = m;      // (m|m)
+        *(uint32_t *)(dst + lsp[i] + 256 + 8) = m;
+        *(uint32_t *)(dst + lsp[i] + 512) = h;      // (h|l)
+        *(uint32_t *)(dst + lsp[i] + 512 + 8) = l;
+      } else {
+        *(uint32_t *)(dst + lsp[i]) = h;
+        *(uint32_t *)(dst + lsp[i] + NH * 256) = m;
+        *(uint32_t *)(dst + lsp[i] + 2 * NH * 256) = l;
+      }
       if (WITH_T) {
         *(float *)(dst + ltr[i]) = v[0][0];
         *(float *)(dst + ltr[i] + 16) = v[0][1];
@@ -181,9 +224,39 @@ struct HybStage {
 
 // split blocks of the lane factor (B operand of the first product): 8 signals [8 * (g & SUBMASK), +8) of row `l` of
 // the fp32 rows A (row stride k), term hyb_sb(j, g) for MFMA j; rows that do not exist give zero blocks
+// The row's signals come with one or two 16-byte loads (dword aligned: a row starts at l*k floats) whatever k is -- a row
+// shorter than the split width reads into the following rows, inside the arena, and is masked -- instead of one guarded
+// load per signal (sixteen branches per pair of lane tiles: a third of the W half-step's instructions outside its loop).
+struct HybRows {
+  f32x4_t r0, r1;  // signals [s0, s0 + 4), [s0 + 4, s0 + 8) of a lane factor row (KS = 4: r0 only)
+};
+template <int KS>
+__device__ __forceinline__ HybRows hyb_lane_rows(const float *__restrict__ A, int k, int l, int g) {
+  constexpr int SUBMASK = KS == 16 ? 1 : 0;
+  const float *rp = A + (int64_t)l * k + 8 * (g & SUBMASK);
+  HybRows R;
+  R.r0 = *(const f32x4_u *)rp;
+  R.r1 = KS == 4 ? R.r0 : (f32x4_t)(*(const f32x4_u *)(rp + 4));
+  return R;
+}
+// `full`: wave-uniform promise that every lane's row exists and has KS signals (k = KS): no masking at all.
 template <int KS, int NM>
-__device__ __forceinline__ void hyb_lane_blocks(const float *__restrict__ A, int k, int l, bool valid, int g,
-                                                bf16x8_t (&bop)[NM]) {
+__device__ __forceinline__ void hyb_lane_blocks_from(const HybRows &R, int k, bool valid, int g, bf16x8_t (&bop)[NM], bool full = false) {
+  if (KS == 4) {  // one MFMA: the lane factor's term PAIR of k-lane group g: (h|m), (h|m), (l|h), zero
+    uint32_t hh[2], mm[2], ll[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) v[e] = (full || (valid && 2 * i + e < k)) ? R.r0[2 * i + e] : 0.0f;
+      split3_pair(v[0], v[1], hh[i], mm[i], ll[i]);
+    }
+    u32x4_t w = {0u, 0u, 0u, 0u};
+    if (g < 2) w = (u32x4_t){hh[0], hh[1], mm[0], mm[1]};
+    if (g == 2) w = (u32x4_t){ll[0], ll[1], hh[0], hh[1]};
+    bop[0] = __builtin_bit_cast(bf16x8_t, w);
+    return;
+  }
   constexpr int SUBMASK = KS == 16 ? 1 : 0;
   const int s0 = 8 * (g & SUBMASK);
   uint32_t hh[4], mm[4], ll[4];
@@ -192,10 +265,25 @@ __device__ __forceinline__ void hyb_lane_blocks(const float *__restrict__ A, int
     float v[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const int c = s0 + 2 * i + e;
-      v[e] = (valid && c < k) ? A[c + (int64_t)l * k] : 0.0f;
+      const int c = 2 * i + e;
+      v[e] = (full || (valid && s0 + c < k)) ? (c < 4 ? R.r0[c & 3] : R.r1[c & 3]) : 0.0f;
     }
     split3_pair(v[0], v[1], hh[i], mm[i], ll[i]);
+  }
+  if (KS == 16) {
+    // hyb_sb<16>: MFMA 0 and 1 take the same block (h for the k-lane groups 0, 1; m for 2, 3), MFMA 2 takes (h; l):
+    // two selects per word instead of a chain per MFMA
+    const bool lo = g < 2;
+    u32x4_t w01, w2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w01[i] = lo ? hh[i] : mm[i];
+      w2[i] = lo ? hh[i] : ll[i];
+    }
+    bop[0] = __builtin_bit_cast(bf16x8_t, w01);
+    bop[1 % NM] = bop[0];
+    bop[2 % NM] = __builtin_bit_cast(bf16x8_t, w2);
+    return;
   }
 #pragma unroll
   for (int j = 0; j < NM; ++j) {
@@ -205,6 +293,11 @@ __device__ __forceinline__ void hyb_lane_blocks(const float *__restrict__ A, int
     for (int i = 0; i < 4; ++i) w[i] = sb == 0 ? hh[i] : sb == 1 ? mm[i] : sb == 2 ? ll[i] : 0u;
     bop[j] = __builtin_bit_cast(bf16x8_t, w);
   }
+}
+template <int KS, int NM>
+__device__ __forceinline__ void hyb_lane_blocks(const float *__restrict__ A, int k, int l, bool valid, int g,
+                                                bf16x8_t (&bop)[NM]) {
+  hyb_lane_blocks_from<KS, NM>(hyb_lane_rows<KS>(A, k, l, g), k, valid, g, bop);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -216,14 +309,15 @@ __device__ __forceinline__ void hyb_lane_blocks(const float *__restrict__ A, int
 // W*H from the same three-term bf16 products (fp32-accurate), residuals squared and accumulated in fp64; W orientation
 // (gp = the W half-step's arguments, lanes = rows of X), whole loop range per workgroup, H of iteration parity `it`;
 // one partial per workgroup in ossepart[] like sse_kernel (256 rows per workgroup = its tile).
-template <int KS, int NT, int NW, bool OBJ>  // NW: waves per workgroup when wsplit = 1 (4 or 8)
-__global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena, const float *__restrict__ Xa,
-                                                       const float *__restrict__ Xt,
-                                                       const NmfkRun *__restrict__ runs,
-                                                       const NmfkState *__restrict__ state,
-                                                       const NmfkStepArgs *__restrict__ gp, int it, int u0, double weight) {
-  extern __shared__ double lds[];  // den[16], red[8*16], staging buffers / cross-wave scratch
-  constexpr int NM = KS == 16 ? 3 : 2;       // bf16 MFMAs of the first product
+// NS: sets of four signals whose numerators run as v_mfma_f32_4x4x1_16B_f32 (ceil(k / 4)); 0 = v_mfma_f32_16x16x4_f32
+template <int KS, int NS, int NT, int NW, bool OBJ>  // NW: waves per workgroup when wsplit = 1 (4 or 8)
+__device__ __forceinline__ void hyb_step_body(char *arena, const float *__restrict__ Xa, const float *__restrict__ Xt,
+                                              const NmfkRun *__restrict__ runs, const NmfkState *__restrict__ state,
+                                              const NmfkStepArgs *__restrict__ gp, int it, int u0, double weight,
+                                              double *lds) {  // lds: den[16], red[16*16], staging buffers / cross-wave scratch
+  constexpr int NM = KS == 16 ? 3 : KS == 8 ? 2 : 1;  // bf16 MFMAs of the first product
+  constexpr int NSA = NS > 0 ? NS : 1;       // accumulator tiles per lane tile
+  constexpr int TM = OBJ ? 0 : (NS > 0 ? 2 : 1);  // layout of the second product's operand block (HybStage)
   constexpr int SUBMASK = KS == 16 ? 1 : 0;  // signal sub-block of a k-lane group: 8 * (g & SUBMASK)
   const int u = u0 + blockIdx.y, bx = blockIdx.x;
   if (!(gp->force && !OBJ) && !state[u].active) return;
@@ -261,9 +355,11 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
     lt[t] = lv[t] ? l : 0;
     hyb_lane_blocks<KS, NM>(A, k, lt[t], lv[t], g, bop[t]);
   }
-  f32x4_t acc[NT];
+  f32x4_t accs[NT][NSA];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int sn = 0; sn < NSA; ++sn) accs[t][sn] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   double ssum = 0.0;
 
   // X comes from the tiled copy Xt (hyb_tile_kernel): the 16 x 16 block (lane tile, chunk) is 1 KB in lane order, so
@@ -274,6 +370,9 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
   for (int t = 0; t < NT; ++t) xoff[t] = (uint32_t)(((int64_t)min((l0 >> 4) + t, nL16 - 1) * nD16 * 256 + lane * 4) * 4);
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)Xt, 0, -1, 0x00020000);
   auto xload = [&](int dch, f32x4_t (&xv)[NT]) __attribute__((always_inline)) {
+#if NMFK_HYB_ABLATE & 1
+    if (dch > d0 + 16) return;
+#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       xv[t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, xoff[t], dch * 64, 0));
@@ -291,17 +390,30 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
         p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[j]), bop[t][j], p[t], 0, 0, 0);
   };
   // ratios and second product (or the objective's residuals)
-  auto chunk_n = [&](int dch, const f32x4_t (&xcur)[NT], const f32x4_t (&p)[NT], const f32x4_t &bn, bool mask)
+  auto chunk_n = [&](int dch, const f32x4_t (&xcur)[NT], const f32x4_t (&p)[NT], const f32x4_t (&bn)[NSA], bool mask)
                      __attribute__((always_inline)) {
     if (OBJ) {
+      // The squares of a lane's 4 * NT residuals of the chunk are added in fp32 (packed), the chunk's partial then enters
+      // the fp64 sum: a partial of 8 squares carries <= 5e-7 of relative rounding noise, unbiased -- over the 8192
+      // partials a lane group of a 8192 x 512 X contributes that is ~1e-8 of the objective, the stop rule's tolOF = 1e-3
+      // on ~3.5e5 is 3e-9 .. per-element fp64 (round 2) cost three fp64 instructions per element: the objective launch
+      // of the bench sweep took as long as a half-step (702 us per check, profiles/r03/trace_micro_before.txt).
+      float part = 0.0f;
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t) {
+        f32x2_t s2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = xcur[t][r] - p[t][r];
-          const double e2 = (double)e * (double)e;
-          ssum += (lv[t] && (!mask || dch + 4 * g + r < d1)) ? e2 : 0.0;
+        for (int r = 0; r < 4; r += 2) {
+          f32x2_t e2 = (f32x2_t){xcur[t][r], xcur[t][r + 1]} - (f32x2_t){p[t][r], p[t][r + 1]};
+          if (mask) {
+            e2.x = dch + 4 * g + r < d1 ? e2.x : 0.0f;
+            e2.y = dch + 4 * g + r + 1 < d1 ? e2.y : 0.0f;
+          }
+          s2 = __builtin_elementwise_fma(e2, e2, s2);
         }
+        part += lv[t] ? s2.x + s2.y : 0.0f;
+      }
+      ssum += (double)part;
       return;
     }
     f32x4_t q[NT];
@@ -309,7 +421,11 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; r += 2) {  // (pairs: one v_pk_mul_f32 for two ratios)
+#if NMFK_HYB_ABLATE & 4
+        const f32x2_t rc = {p[t][r], p[t][r + 1]};
+#else
         const f32x2_t rc = {__builtin_amdgcn_rcpf(p[t][r]), __builtin_amdgcn_rcpf(p[t][r + 1])};
+#endif
         const f32x2_t q2 = (f32x2_t){xcur[t][r], xcur[t][r + 1]} * rc;
         q[t][r] = q2.x;
         q[t][r + 1] = q2.y;
@@ -318,10 +434,26 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
           q[t][r + 1] = (dch + 4 * g + r + 1 < d1) ? q[t][r + 1] : 0.0f;
         }
       }
+#if NMFK_HYB_ABLATE & 8
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int t = 0; t < NT; ++t) accs[t][0] += q[t];
+    return;
+#endif
+    if (NS > 0) {
+      // block (g, c16 >> 2) of the instruction: signals 4 sn + (lane & 3) of loop step 4g + r (A operand) x the ratios of
+      // the block's four lane elements (B operand) -> accs[t][sn][i] += b[4g + r][4 sn + i] * q[4g + r][lane element]
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[r], q[t][r], acc[t], 0, 0, 0);
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int sn = 0; sn < NSA; ++sn)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) accs[t][sn] = __builtin_amdgcn_mfma_f32_4x4x1f32(bn[sn][r], q[t][r], accs[t][sn], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) accs[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[0][r], q[t][r], accs[t][0], 0, 0, 0);
+    }
   };
   // inputs of the fused finish, fetched before the loop so that the finish does not wait for memory: the other
   // factor's sums (denominators of Mult:67 / Mult:70) and this lane's old factor values
@@ -329,14 +461,7 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
   double *den = lds;
   const bool vec4 = (k & 3) == 0;  // fp32 rows are 16-byte aligned: one load / store per lane instead of four
   f32x4_t aold[NT];
-  if (fused) {
-    const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
-    const int PB = which == 0 ? gp->PW : gp->PH;
-    if (tid < k) {
-      double sd = 0;
-      for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * k + tid];
-      den[tid] = sd;
-    }
+  auto load_aold = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       aold[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -348,8 +473,19 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
           if (4 * g + r < k) aold[t][r] = A[4 * g + r + (int64_t)lt[t] * k];
       }
     }
+  };
+  constexpr bool AOLD_EARLY = NS == 0;  // (the 4x4x1 forms carry more accumulators: their old values are fetched behind the loop)
+  if (fused) {
+    const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
+    const int PB = which == 0 ? gp->PW : gp->PH;
+    if (tid < k) {
+      double sd = 0;
+      for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * k + tid];
+      den[tid] = sd;
+    }
+    if (AOLD_EARLY) load_aold();
   }
-  char *sbase = (char *)(lds + 9 * 16);  // staging buffers, later the cross-wave scratch (wsplit > 1)
+  char *sbase = (char *)(lds + 17 * 16);  // staging buffers, later the cross-wave scratch (wsplit > 1)
   const int nchunks = (d1 - d0 + 15) >> 4;
 
   // The loop.  TRIP chunks per trip of the (unrolled) body so that the LDS buffer of a block and the register set of
@@ -363,7 +499,8 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
     int fofs[NM];
 #pragma unroll
     for (int j = 0; j < NM; ++j) fofs[j] = (hyb_sa<KS>(j, g) * ST::NH + (g & SUBMASK)) * 256 + c16 * 16;
-    const int nofs = ST::BFB + g * 256 + min(c16, KS - 1) * 16;
+    // second product's operand: 16x16x4 form: signal c16 of plane g; 4x4x1 form: signal 4 sn + (c16 & 3) (sn: + 64 B)
+    const int nofs = ST::BFB + g * ST::TPS + (NS > 0 ? (c16 & 3) : min(c16, KS - 1)) * 16;
     if (nchunks <= 0) return;
     // staging registers of TWO blocks: the rows of block b + 2 are requested at the start of block b and written to LDS
     // during block b + 1 -- a whole block of latency even when a block is a single chunk (per-wave staging), where a
@@ -399,19 +536,23 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
         const bool more2 = FULLT || (c - ch + 2 * CPB < nchunks);  // and one after that
         xload(FULLT ? dch + 32 : min(dch + 32, dlast), xr[(ci + 2) & 3]);
         // (vmcnt retires in order: the staging requests go out AFTER this chunk's X prefetch)
-        if (ch == 0 && more2) stage.load(dch + 32 * CPB, sv[buf], svrow[buf]);
+        if (ch == 0 && more2 && !(NMFK_HYB_ABLATE & 2)) stage.load(dch + 32 * CPB, sv[buf], svrow[buf]);
         // the next block (requested a block ago) goes to the free LDS buffer BEFORE this block's last chunk: conversion
         // and LDS writes overlap with that chunk's matrix work instead of sitting in front of the barrier
         const bool last_of_block = ch == CPB - 1 || (!FULLT && c == nchunks - 1);
-        if (last_of_block && more) stage.write(sb + (buf ^ 1) * ST::STB, sv[buf ^ 1], svrow[buf ^ 1]);
+        if (last_of_block && more && !(NMFK_HYB_ABLATE & 2)) stage.write(sb + (buf ^ 1) * ST::STB, sv[buf ^ 1], svrow[buf ^ 1]);
         __builtin_amdgcn_sched_barrier(0);  // loads stay in front of the arithmetic they overlap with
         // The block's barrier sits HERE, in front of its last chunk's arithmetic: every wave has written its part of
         // the next block and has fetched its last operands of this one (the second product's block below; the first
         // product's came with the previous chunk), so this buffer is free for the block after next and the last chunk
         // can already fetch the next block's first operands behind its first product.
         const char *b = sb + buf * ST::STB;
-        f32x4_t bn = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (!OBJ) bn = *(const f32x4_t *)(b + nofs + ch * ST::CHT);
+        f32x4_t bn[NSA];
+#pragma unroll
+        for (int sn = 0; sn < NSA; ++sn) {
+          bn[sn] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          if (!OBJ) bn[sn] = *(const f32x4_t *)(b + nofs + sn * 64 + ch * ST::CHT);
+        }
         if (last_of_block) barrier();
         {
           u32x4_t av[NM];
@@ -437,7 +578,7 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
     for (; c0 < nchunks; c0 += TRIP) trip(c0, std::false_type());
   };
   if (OBJ) {
-    HybStage<KS, NMFK_HYB_CPB, 64 * NW, false> stage;
+    HybStage<KS, NMFK_HYB_CPB, 64 * NW, 0> stage;
     stage.init(B, k, D, tid);
     run(stage, sbase, [] { HYB_BARRIER(); });
     // workgroup sum in wave order (fixed order => reproducible), one partial per workgroup
@@ -454,14 +595,34 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
     return;
   }
   if (ws == 1) {
-    HybStage<KS, NMFK_HYB_CPB, 64 * NW, true> stage;
+    HybStage<KS, NMFK_HYB_CPB, 64 * NW, TM> stage;
     stage.init(B, k, D, tid);
     run(stage, sbase, [] { HYB_BARRIER(); });
   } else {
-    HybStage<KS, 1, 64, true> stage;
+    HybStage<KS, 1, 64, TM> stage;
     stage.init(B, k, D, lane);
-    run(stage, sbase + wave * 2 * HybStage<KS, 1, 64, true>::STB, [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); });
+    run(stage, sbase + wave * 2 * HybStage<KS, 1, 64, TM>::STB, [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); });
     __syncthreads();  // the cross-wave scratch below overlays the staging buffers
+  }
+  // 4x4x1 form: a lane holds the sums over its own loop steps (d = 4g + r of every chunk) of ALL 4 NS signals: add the
+  // four k-lane groups (lanes c16, c16 + 16, + 32, + 48: every lane gets the same bits), then lane group g keeps set g
+  f32x4_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (NS > 0) {
+      acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sn = 0; sn < NSA; ++sn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = accs[t][sn][r];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (g == sn) acc[t][r] = v;
+        }
+    } else {
+      acc[t] = accs[t][0];
+    }
   }
   // acc[t][r] = numerator of signal c = 4g + r at lane element l0 + 16t + c16
 
@@ -501,10 +662,11 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
     return;
   }
 
+  if (!AOLD_EARLY) load_aold();
   __syncthreads();  // den[] is visible
   float *__restrict__ Anew = which == 0 ? (float *)(arena + NMFK_HOFF(*rdp, it + 1)) : (float *)(arena + rdp->oWt);
   double *sumA = (double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)) + (int64_t)tile * k;
-  double *red = den + 16;  // [8][16]
+  double *red = den + 16;  // [16][16]
   float vs[4] = {0.f, 0.f, 0.f, 0.f};
   if (owner) {
 #pragma unroll
@@ -541,6 +703,373 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// RESIDENT form of the half-step (round 3): for a short loop dimension (the W half-step of a tall X: D = m = 512 at the
+// BASELINE shape) the WHOLE loop factor, in both operand forms, fits in the LDS of a CU (D / 16 chunks of 2 - 2.8 KB).  The
+// streaming kernel above pays, per workgroup of 8 waves and ONE pair of lane tiles per wave: the split of all D rows (at
+// n = 8192 thirty-two workgroups of a unit each convert the same 512 rows), a barrier per 64 loop steps, the workgroup's
+// prologue (denominators, first block) and an epilogue as long as the loop itself (PMC, profiles/r03: half of the W
+// half-step's vector instructions sat outside the loop).  Here a workgroup of 16 waves stages the factor ONCE, and then
+// every wave walks SEVERAL pairs of lane tiles on its own -- no barrier, no staging, operands straight from LDS, X two
+// chunks ahead across tile boundaries -- with a slim per-tile epilogue (reciprocal denominators, sums kept per lane and
+// reduced once per workgroup).  One sum-table slot per workgroup.  Needs D % 64 == 0 (the host checks; else streaming).
+// ------------------------------------------------------------------------------------------------------
+#ifndef NMFK_HYB_RW
+#define NMFK_HYB_RW 16  // waves per workgroup of the resident form
+#endif
+// OBJ: the monitored objective (Mult:74) of the units instead of a half-step, like the streaming kernel's OBJ mode: gp = the
+// W half-step's arguments, `it` = parity of the H buffer that holds the current H, first product only, one partial per
+// workgroup in ossepart[b] (the entries b >= gridDim.x up to ntile are zeroed: check_a_kernel adds ntile of them).
+template <int KS, int NS, int NT, bool OBJ>
+__device__ __forceinline__ void hyb_res_body(char *arena, const float *__restrict__ Xt, const NmfkRun *__restrict__ runs,
+                                             const NmfkState *__restrict__ state, const NmfkStepArgs *__restrict__ gp, int it, int u0,
+                                             double weight, int ntile,
+                                             double *lds) {  // lds: den[16], red[16*16], rden, then the factor: split planes [nch][CHP], transposed blocks [nch][CHT]
+  constexpr int NM = KS == 16 ? 3 : KS == 8 ? 2 : 1;
+  constexpr int NSA = NS > 0 ? NS : 1;
+  constexpr int TM = OBJ ? 0 : (NS > 0 ? 2 : 1);
+  constexpr int SUBMASK = KS == 16 ? 1 : 0;
+  constexpr int RW = NMFK_HYB_RW;
+  typedef HybStage<KS, 1, 64 * RW, TM> ST;  // (layout constants only)
+  const int u = u0 + blockIdx.y, b = blockIdx.x, G = gridDim.x;
+  if (!(gp->force && !OBJ) && !state[u].active) return;
+  const NmfkRun *__restrict__ rdp = runs + u;
+  const int k = rdp->k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int which = gp->which, L = gp->L, D = gp->D;
+  const int nch = D >> 4;
+  const float *__restrict__ A = (const float *)(arena + (which == 0 ? NMFK_HOFF(*rdp, it) : rdp->oWt));          // lane factor
+  const float *__restrict__ B = (const float *)(arena + (which == 0 ? rdp->oWt : NMFK_HOFF(*rdp, OBJ ? it : it + 1)));  // loop factor
+  char *sb = (char *)(lds + 18 * 16);  // den[16], red[16][16], rden[16] (+ padding)
+  const int BFB = nch * ST::CHP;
+
+  // ---- the whole loop factor -> LDS, once per workgroup: item = (row, pair of adjacent signals)
+  for (int q = tid; q < D * ST::PPR; q += 64 * RW) {
+    const int r = q / ST::PPR, cp = q - r * ST::PPR;
+    const float v0 = 2 * cp < k ? B[(int64_t)r * k + 2 * cp] : 0.0f, v1 = 2 * cp + 1 < k ? B[(int64_t)r * k + 2 * cp + 1] : 0.0f;
+    uint32_t h, m, l;
+    split3_pair(v0, v1, h, m, l);
+    const int ch = r >> 4, rr = r & 15;
+    if (KS == 4) {
+      char *d = sb + ch * ST::CHP + rr * 16 + cp * 4;
+      *(uint32_t *)(d) = h;  // (h|h)
+      *(uint32_t *)(d + 8) = h;
+      *(uint32_t *)(d + 256) = m;  // (m|m)
+      *(uint32_t *)(d + 256 + 8) = m;
+      *(uint32_t *)(d + 512) = h;  // (h|l)
+      *(uint32_t *)(d + 512 + 8) = l;
+    } else {
+      char *d = sb + ch * ST::CHP + (cp >> 2) * 256 + rr * 16 + (cp & 3) * 4;
+      *(uint32_t *)(d) = h;
+      *(uint32_t *)(d + ST::NH * 256) = m;
+      *(uint32_t *)(d + 2 * ST::NH * 256) = l;
+    }
+    if (!OBJ) {
+      char *t = sb + BFB + ch * ST::CHT + (rr >> 2) * ST::TPS + 2 * cp * 16 + (rr & 3) * 4;
+      *(float *)(t) = v0;
+      *(float *)(t + 16) = v1;
+    }
+  }
+  double *den = lds;
+  double ssum = 0.0;
+  if (!OBJ) {
+    const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
+    const int PB = which == 0 ? gp->PW : gp->PH;
+    if (tid < k) {
+      double sd = 0;
+      for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * k + tid];
+      den[tid] = sd;
+    }
+  }
+  __syncthreads();
+  // 1 / sum(B) as fp32, once per workgroup (den[] is re-used for it: the finish of every tile pair reads it from LDS
+  // instead of keeping four registers per lane alive across the loop)
+  float *rden = (float *)(den + 16) + 16 * 32;  // behind red[16][16]
+  if (!OBJ) {
+    if (tid < 16) rden[tid] = tid < k ? 1.0f / (float)den[tid] : 0.0f;
+    __syncthreads();
+  }
+
+  const int ntp = (L + 16 * NT - 1) / (16 * NT);  // pairs (NT-tuples) of 16-lane tiles
+  const int stride = RW * G;
+  const int nD16 = nch, nL16 = (L + 15) >> 4;
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)Xt, 0, -1, 0x00020000);
+  int fofs[NM];
+#pragma unroll
+  for (int j = 0; j < NM; ++j) fofs[j] = (hyb_sa<KS>(j, g) * ST::NH + (g & SUBMASK)) * 256 + c16 * 16;
+  const int nofs = BFB + g * ST::TPS + (NS > 0 ? (c16 & 3) : min(c16, KS - 1)) * 16;
+  float *__restrict__ Anew = which == 0 ? (float *)(arena + NMFK_HOFF(*rdp, it + 1)) : (float *)(arena + rdp->oWt);
+  // sums of the new factor: fp32 per lane over this wave's tile pairs (<= a few dozen values), fp64 from there on
+  float vsf[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // X: the 16 x 16 block (16-lane tile, chunk) is 1 KB in lane order; byte offset = wave-uniform block offset (SGPR) + 16 * lane
+  const uint32_t xlane = (uint32_t)lane * 16u;
+  auto xoffs = [&](int tp, int (&xo)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xo[t] = __builtin_amdgcn_readfirstlane(min(tp * NT + t, nL16 - 1) * nD16 * 1024);
+  };
+  auto xload = [&](const int (&xo)[NT], int c, f32x4_t (&xv)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      xv[t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, xlane, xo[t] + c * 1024, 0));
+  };
+  f32x4_t xr[4][NT];
+  u32x4_t avn[NM];
+  int tp = b * RW + wave;
+  int xo[NT], xn[NT];
+  // Measured without gain (profiles/r03/resident_ablation.txt): the next pair's lane-factor rows and the current pair's old
+  // values requested a tile, or four chunks, ahead of the boundary (19 spilled registers at 128 per wave; with 12 waves
+  // per workgroup and 170 registers the kernel was slower as a whole), X three chunks ahead instead of two.
+  HybRows nrow[NT];
+  if (tp < ntp) {
+    xoffs(tp, xo);
+    xload(xo, 0, xr[0]);
+    xload(xo, 1, xr[1]);
+#pragma unroll
+    for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(sb + fofs[j]);
+  }
+  for (; tp < ntp; tp += stride) {
+    const int tnext = tp + stride < ntp ? tp + stride : tp;  // (the last pair prefetches itself again: dropped)
+    xoffs(tnext, xn);
+    bf16x8_t bop[NT][NM];
+    int lt[NT];
+    bool lv[NT];
+    f32x4_t aoldv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int l = (tp * NT + t) * 16 + c16;
+      lv[t] = l < L;
+      lt[t] = lv[t] ? l : L - 1;
+#if !(NMFK_HYB_ABLATE & 64)
+      nrow[t] = hyb_lane_rows<KS>(A, k, lt[t], g);
+#endif
+    }
+#if NMFK_HYB_ABLATE & 64
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < NM; ++j) bop[t][j] = __builtin_bit_cast(bf16x8_t, (u32x4_t){0x3f803f80u + (uint32_t)lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+    if (false) {
+#else
+    if (k == KS && (tp * NT + NT) * 16 <= L) {  // (wave-uniform) whole tiles of full-width rows: nothing to mask
+#endif
+#pragma unroll
+      for (int t = 0; t < NT; ++t) hyb_lane_blocks_from<KS, NM>(nrow[t], k, true, g, bop[t], true);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) hyb_lane_blocks_from<KS, NM>(nrow[t], k, lv[t], g, bop[t]);
+    }
+    // (aold: one dword-aligned 16-byte load: a lane whose four signals end beyond the row reads into the next row -- the
+    //  last row of the factor reads <= 12 bytes past it, inside the arena; those values are never used)
+    auto load_aold = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) aoldv[t] = *(const f32x4_u *)(A + min(4 * g, max(k - 1, 0)) + (int64_t)lt[t] * k);
+    };
+    f32x4_t accs[NT][NSA];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int sn = 0; sn < NSA; ++sn) accs[t][sn] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // four chunks per trip (X register sets and LDS offsets are compile-time); TAIL: the tile's last four chunks fetch
+    // the first X entries of the wave's NEXT tile pair and the first operands of chunk 0 again
+    auto trip = [&](int c0, auto tail_tag) __attribute__((always_inline)) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {
+        const int c = c0 + ci;
+#if !(NMFK_HYB_ABLATE & 128)
+        if (TAIL && ci >= 2)
+          xload(xn, ci - 2, xr[(ci + 2) & 3]);
+        else
+          xload(xo, c + 2, xr[(ci + 2) & 3]);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4_t bn[NSA];
+        if (!OBJ) {
+#pragma unroll
+          for (int sn = 0; sn < NSA; ++sn) bn[sn] = *(const f32x4_t *)(sb + nofs + sn * 64 + c * ST::CHT);
+        }
+        f32x4_t p[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NM; ++j)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, avn[j]), bop[t][j], p[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const char *nx = sb + ((TAIL && ci == 3) ? 0 : (c + 1) * ST::CHP);
+#pragma unroll
+          for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(nx + fofs[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (OBJ) {  // residuals: squares of a chunk in fp32 (packed), the chunk's partial into the fp64 sum (see the streaming form)
+          float part = 0.0f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            f32x2_t s2 = {0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+              const f32x2_t e2 = (f32x2_t){xr[ci][t][r], xr[ci][t][r + 1]} - (f32x2_t){p[t][r], p[t][r + 1]};
+              s2 = __builtin_elementwise_fma(e2, e2, s2);
+            }
+            part += lv[t] ? s2.x + s2.y : 0.0f;
+          }
+          ssum += (double)part;
+          __builtin_amdgcn_sched_barrier(0);
+          continue;
+        }
+        f32x4_t q[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const f32x2_t rc = {__builtin_amdgcn_rcpf(p[t][r]), __builtin_amdgcn_rcpf(p[t][r + 1])};
+            const f32x2_t q2 = (f32x2_t){xr[ci][t][r], xr[ci][t][r + 1]} * rc;
+            q[t][r] = q2.x;
+            q[t][r + 1] = q2.y;
+          }
+        if (NS > 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int sn = 0; sn < NSA; ++sn)
+#pragma unroll
+              for (int t = 0; t < NT; ++t) accs[t][sn] = __builtin_amdgcn_mfma_f32_4x4x1f32(bn[sn][r], q[t][r], accs[t][sn], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) accs[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[0][r], q[t][r], accs[t][0], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+#if !(NMFK_HYB_ABLATE & 32)
+    for (int c0 = 0; c0 + 4 < nch; c0 += 4) trip(c0, std::false_type());
+    trip(nch - 4, std::true_type());
+#endif
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xo[t] = xn[t];
+
+    if (OBJ) continue;
+    // ---- the tile pair's finish: A_new = A .* numerator ./ sum(B) (Mult:67 / Mult:70), sums of A_new per lane
+#if NMFK_HYB_ABLATE & 64
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int sn = 0; sn < NSA; ++sn) vsf[0] += accs[t][sn][0] + accs[t][sn][1] + accs[t][sn][2] + accs[t][sn][3];
+    continue;
+#endif
+    load_aold();
+    float vsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4_t acc;
+      if (NS > 0) {
+        acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sn = 0; sn < NSA; ++sn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = accs[t][sn][r];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == sn) acc[r] = v;
+          }
+      } else {
+        acc = accs[t][0];
+      }
+      if (lv[t] && 4 * g < k) {
+        const f32x4_t aold = aoldv[t];
+        const f32x4_t rd4 = *(const f32x4_t *)(rden + 4 * g);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = 4 * g + r < k ? (aold[r] * acc[r]) * rd4[r] : 0.0f;
+          vsum[r] += v[r];
+        }
+        float *dst = Anew + 4 * g + (int64_t)lt[t] * k;
+        if (4 * g + 3 < k) {
+          *(f32x4_u *)dst = (f32x4_t){v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            if (4 * g + r < k) dst[r] = v[r];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vsf[r] += vsum[r];
+  }
+
+  if (OBJ) {  // workgroup sum in wave order (fixed order => reproducible), one partial per workgroup
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ssum += __shfl_down(ssum, o, 64);
+    if (lane == 0) lds[wave] = ssum;
+    __syncthreads();
+    double *part = (double *)(arena + rdp->ossepart);
+    if (tid == 0) {
+      double t = 0;
+      for (int w = 0; w < RW; ++w) t += lds[w];
+      part[b] = t * weight * weight;
+    }
+    if (b == 0)
+      for (int t = G + tid; t < ntile; t += 64 * RW) part[t] = 0.0;
+    return;
+  }
+  // ---- sums of the new factor over the workgroup's lane elements -> slot b (fixed order: lanes, then waves)
+  double *red = den + 16;  // [RW][16]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = 4 * g + r;
+    double v = (double)vsf[r];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (c16 == 0 && c < k) red[wave * 16 + c] = v;
+  }
+  __syncthreads();
+  if (tid < k) {
+    double t = red[tid];
+    for (int w = 1; w < RW; ++w) t += red[w * 16 + tid];
+    ((double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)))[(int64_t)b * k + tid] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The kernels.  ONE launch serves units of different kernel variants (NmfkRun::hyb = 4 / 8 / 16, see nmfk_hyb_variant):
+// a workgroup belongs to one unit, so the switch is workgroup-uniform; registers and LDS are those of the widest variant
+// (the same 4 waves per SIMD for all).  With a launch per variant the 96 + 128 + 256 factorizations of the bench sweep
+// were three launches that each left CUs idle (H half-step: two workgroups per unit) and ended in their own tail;
+// together they fill the chip (profiles/r03/variants_one_launch.txt).
+// ------------------------------------------------------------------------------------------------------
+template <int NT, int NW, bool OBJ>
+__global__ __launch_bounds__(64 * (NW > 8 ? NW : 8), OBJ ? 2 : 4) void hyb_step_kernel(char *arena, const float *__restrict__ Xa,
+                                                       const float *__restrict__ Xt,
+                                                       const NmfkRun *__restrict__ runs,
+                                                       const NmfkState *__restrict__ state,
+                                                       const NmfkStepArgs *__restrict__ gp, int it, int u0, double weight) {
+  extern __shared__ double lds[];
+  switch (runs[u0 + blockIdx.y].hyb) {
+    case 4: hyb_step_body<4, OBJ ? 0 : 1, NT, NW, OBJ>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
+    case 8: hyb_step_body<8, OBJ ? 0 : 2, NT, NW, OBJ>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
+    default: hyb_step_body<16, 0, NT, NW, OBJ>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
+  }
+}
+
+template <int NT, bool OBJ>
+__global__ __launch_bounds__(64 * NMFK_HYB_RW) void hyb_res_kernel(char *arena, const float *__restrict__ Xt, const NmfkRun *__restrict__ runs,
+                                                      const NmfkState *__restrict__ state, const NmfkStepArgs *__restrict__ gp,
+                                                      int it, int u0, double weight, int ntile) {
+  extern __shared__ double lds[];
+  switch (runs[u0 + blockIdx.y].hyb) {
+    case 4: hyb_res_body<4, OBJ ? 0 : 1, NT, OBJ>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
+    case 8: hyb_res_body<8, OBJ ? 0 : 2, NT, OBJ>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
+    default: hyb_res_body<16, 0, NT, OBJ>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
+  }
+}
+
 }  // namespace
 
 #ifndef NMFK_HYB_NT
@@ -552,22 +1081,57 @@ __global__ __launch_bounds__(512, OBJ ? 2 : 4) void hyb_step_kernel(char *arena,
 
 int nmfk_hyb_lane_tile(int wsplit) { return 16 * NMFK_HYB_NT * (wsplit > 1 ? 1 : NMFK_HYB_NW); }
 
-// half-step of the `cnt` units [u0, u0 + cnt), all of split width ks (8: k <= 8, 16: k <= 16)
-void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int ks, int u0, int cnt, hipStream_t s) {
+// kernel variant of a rank (NmfkRun::hyb): 4 = (KS 4, NS 1) for k <= 4, 8 = (KS 8, NS 2) for k <= 8, 16 = (KS 16, 16-signal
+// numerators) for k <= 16.  (Three sets of 4x4x1 numerators for k = 9..12 were built and measured: at 128 registers per
+// wave they spill, and in the resident form, where they fit, a launch of 256 factorizations of k = 12 took 0.473 ms
+// against 0.470 ms with the 16-signal form -- that kernel is bound by instruction issue, not by the matrix pipe.)
+int nmfk_hyb_variant(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : 16; }
+
+namespace {
+// bytes of one staged chunk (split planes + transposed block) of the widest variant <= vmax
+size_t hyb_chunk_bytes(int vmax) {
+  size_t b = 0;
+  for (int v : {4, 8, 16}) {
+    if (v > vmax) continue;
+    const size_t planes = 3 * (size_t)(v == 4 ? 1 : v / 8) * 256;
+    b = std::max(b, planes + (v == 16 ? 4 * 256 : 4 * 320));
+  }
+  return b;
+}
+}  // namespace
+
+int nmfk_hyb_resident_waves() { return NMFK_HYB_RW; }
+// Resident form: bytes of LDS a workgroup needs for a loop dimension of D when the widest variant of the launch is vmax
+// (0: not applicable -- D % 64 != 0 or too long)
+size_t nmfk_hyb_resident_lds(int vmax, int D) {
+  if (D < 64 || (D & 63) != 0) return 0;
+  const size_t need = sizeof(double) * 18 * 16 + (size_t)(D >> 4) * hyb_chunk_bytes(vmax);
+  return need <= 160 * 1024 ? need : 0;
+}
+
+// half-step of the `cnt` units [u0, u0 + cnt) (any mix of variants; vmax = the widest among them)
+void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int vmax, int u0, int cnt, hipStream_t s) {
   constexpr int NT = NMFK_HYB_NT, NW = NMFK_HYB_NW;
+  if (a.res_wgs > 0) {  // resident form (the host has checked nmfk_hyb_resident_lds)
+    static bool once = false;  // more than 64 KB of dynamic LDS has to be allowed per kernel
+    if (!once) {
+      (void)hipFuncSetAttribute((const void *)hyb_res_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      once = true;
+    }
+    hipLaunchKernelGGL((hyb_res_kernel<NT, false>), dim3(a.res_wgs, cnt), dim3(64 * NMFK_HYB_RW), nmfk_hyb_resident_lds(vmax, a.D), s,
+                       a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0, 0);
+    return;
+  }
   const int ws = a.wsplit, nwaves = ws > 1 ? ws : NW;
   const int lpw = 16 * NT * (ws > 1 ? 1 : nwaves);
   const int ntile = (a.L + lpw - 1) / lpw;
   const dim3 grid(ntile * a.S, cnt), blk(64 * nwaves);
   const size_t cross = ws > 1 ? (size_t)(ws - 1) * NT * 4 * 64 * sizeof(float) : 0;
   // two staged blocks of NMFK_HYB_CPB chunks per workgroup (wsplit = 1) / of one chunk per wave (wsplit > 1): HybStage::STB
-  const size_t chunkb = 3 * (size_t)(ks / 8) * 256 + 4 * 256;
+  const size_t chunkb = hyb_chunk_bytes(vmax);
   const size_t stage = ws > 1 ? (size_t)ws * 2 * chunkb : 2 * NMFK_HYB_CPB * chunkb;
-  const size_t ldsb = sizeof(double) * 9 * 16 + std::max(cross, stage);
-  if (ks == 8)
-    hipLaunchKernelGGL((hyb_step_kernel<8, NT, NW, false>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
-  else
-    hipLaunchKernelGGL((hyb_step_kernel<16, NT, NW, false>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
+  const size_t ldsb = sizeof(double) * 17 * 16 + std::max(cross, stage);
+  hipLaunchKernelGGL((hyb_step_kernel<NT, NW, false>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
 }
 
 // tiled copy of X (element (l, d) at src[d + l*D]) for nmfk_launch_step_hyb_f32; out: roundup16(L) * roundup16(D) floats
@@ -580,14 +1144,22 @@ void nmfk_launch_hyb_tile(const float *src, int L, int D, float *out, hipStream_
 // monitored objective of the units [u0, u0 + cnt) of a group on the split-operand MFMA kernel (active units only):
 // the half-step kernel in its objective mode.  w: the W half-step's arguments (dw: their device copy); hsel: parity
 // of the H buffer that holds the current H
-void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double weight, int hsel, int ks, int u0, int cnt,
+void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double weight, int hsel, int vmax, int u0, int cnt,
                          hipStream_t s) {
-  constexpr int NT = NMFK_HYB_NT, NW = NMFK_HYB_NW;
+  constexpr int NT = NMFK_HYB_NT, NW = 8;
+  if (w.res_wgs > 0) {  // resident form (W orientation: the loop factor H sits in LDS), res_wgs partials per unit
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute((const void *)hyb_res_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      once = true;
+    }
+    const int ntile = (w.L + NMFK_TILE - 1) / NMFK_TILE;  // partials check_a_kernel adds (sse_kernel's count)
+    hipLaunchKernelGGL((hyb_res_kernel<NT, true>), dim3(std::min(w.res_wgs, ntile), cnt), dim3(64 * NMFK_HYB_RW),
+                       nmfk_hyb_resident_lds(vmax, w.D), s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight, ntile);
+    return;
+  }
   const int lpw = 16 * NT * NW;  // = NMFK_TILE: the partials line up with sse_kernel's
   const dim3 grid((w.L + lpw - 1) / lpw, cnt), blk(64 * NW);
-  const size_t ldsb = sizeof(double) * 9 * 16 + 2 * NMFK_HYB_CPB * 3 * (size_t)(ks / 8) * 256;  // two blocks of split planes
-  if (ks == 8)
-    hipLaunchKernelGGL((hyb_step_kernel<8, NT, NW, true>), grid, blk, ldsb, s, w.arena, w.Xalt, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
-  else
-    hipLaunchKernelGGL((hyb_step_kernel<16, NT, NW, true>), grid, blk, ldsb, s, w.arena, w.Xalt, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
+  const size_t ldsb = sizeof(double) * 17 * 16 + 2 * NMFK_HYB_CPB * 3 * (size_t)(vmax <= 8 ? 1 : 2) * 256;  // two blocks of split planes
+  hipLaunchKernelGGL((hyb_step_kernel<NT, NW, true>), grid, blk, ldsb, s, w.arena, w.Xalt, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
 }

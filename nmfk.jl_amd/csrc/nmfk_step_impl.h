@@ -1487,6 +1487,7 @@ __global__ void check_a_kernel(NmfkCheckArgs g, int u0, int cnt) {
   double obj = 0;
   for (int t = 0; t < g.ntile_n; ++t) obj += NMFK_PTR(const double, g, rd.ossepart)[t];
   st->last_obj = obj;
+  if (g.trace && (g.it + 1) / 10 - 1 < g.trace_stride) g.trace[(int64_t)u * g.trace_stride + (g.it + 1) / 10 - 1] = obj;
   if (obj < g.tol) {  // Mult:75-78: leaves the loop before the clamp
     st->active = 0;
     st->reason = NMFK_STOP_TOL;

@@ -128,6 +128,29 @@ def _ranks_in_threads(mh, fn):
     return out, err
 
 
+def _shard_reference(NMFk, ref_ctx, ks, R, N, seeds=None, Winit=None, Hinit=None, **kw):
+    """What the sharded sweep must deliver, bit for bit: rank g runs nmfk_mu_sweep on ITS restarts {g, g + N, ...} padded to
+    ceil(R / N) by repeating the last one (the launch schedule of a sweep depends on the number of restarts per rank, so
+    the comparison is against the same shard swept alone, not against the unsharded sweep -- that one is compared within
+    fp32 tolerance).  -> dict k -> dict key -> array over all R restarts"""
+    from nmfk_jl_amd import _lib
+
+    out = {k: {} for k in ks}
+    for g in range(N):
+        cnt, pad = _lib.shard_plan(R, N, g)
+        if cnt == 0:
+            continue
+        idx = [g + min(j, cnt - 1) * N for j in range(pad)]
+        part = ref_ctx.mu_sweep(ks, pad, seeds=None if seeds is None else seeds[:, idx],
+                                Winit=None if Winit is None else {k: v[idx] for k, v in Winit.items()},
+                                Hinit=None if Hinit is None else {k: v[idx] for k, v in Hinit.items()}, **kw)
+        for k in ks:
+            for key, val in part[k].items():
+                dst = out[k].setdefault(key, np.zeros((R,) + val.shape[1:], dtype=val.dtype))
+                dst[idx[:cnt]] = val[:cnt]
+    return out
+
+
 @pytest.mark.parametrize("N,R", [(2, 5), (3, 7), (8, 5), (8, 11), (3, 2)])
 def test_loopback_sharded_sweep_is_bit_identical(NMFk, oracle, N, R):
     """nruns not divisible by N, more ranks than restarts (idle ranks), mixed rank widths incl. the all-MFMA kernel."""
@@ -138,7 +161,12 @@ def test_loopback_sharded_sweep_is_bit_identical(NMFk, oracle, N, R):
     seeds = np.array([[NMFk.run_seed(11, k, r) for r in range(R)] for k in ks], dtype=np.uint64)
     ref_ctx = NMFk.Context(0)
     ref_ctx.set_X(X)
-    ref = ref_ctx.mu_sweep(ks, R, seeds=seeds, maxiter=30, **NOSTOP)
+    ref = _shard_reference(NMFk, ref_ctx, ks, R, N, seeds=seeds, maxiter=30, **NOSTOP)
+    whole = ref_ctx.mu_sweep(ks, R, seeds=seeds, maxiter=30, **NOSTOP)
+    for k in ks:  # the shards' results are the unsharded sweep's up to the schedule's summation order
+        for r in range(R):
+            err = np.linalg.norm(ref[k]["W"][r] @ ref[k]["H"][r] - whole[k]["W"][r] @ whole[k]["H"][r]) / np.linalg.norm(X)
+            assert err < 1e-5, (k, r, err)
     mh = _lib.Multi(N, loopback=True)
     mh.set_X(X)  # loopback broadcast of X from rank 0 + NMFpreprocessing! on every rank
     res = mh.mu_sweep(ks, R, seeds=seeds, maxiter=30, **NOSTOP)  # nmfk_multi_sweep: N threads inside the library
@@ -176,7 +204,7 @@ def test_loopback_given_inits_travel_through_the_shard_buffers(NMFk, oracle):
     H0 = np.stack([oracle.init_factors(int(s), *X.shape, k)[1] for s in seeds])
     ref_ctx = NMFk.Context(0)
     ref_ctx.set_X(X)
-    b = ref_ctx.mu_sweep([k], R, Winit={k: W0}, Hinit={k: H0}, maxiter=25, **NOSTOP)[k]
+    b = _shard_reference(NMFk, ref_ctx, [k], R, N, Winit={k: W0}, Hinit={k: H0}, maxiter=25, **NOSTOP)[k]
     mh = _lib.Multi(N, loopback=True)
     mh.set_X(X)
     a = mh.mu_sweep([k], R, Winit={k: W0}, Hinit={k: H0}, maxiter=25, **NOSTOP)[k]
@@ -184,7 +212,7 @@ def test_loopback_given_inits_travel_through_the_shard_buffers(NMFk, oracle):
     # only H given: W drawn from the seeds (the mixed form of Mult:38-55)
     sd = np.array([seeds], dtype=np.uint64)
     a = mh.mu_sweep([k], R, seeds=sd, Hinit={k: H0}, maxiter=25, **NOSTOP)[k]
-    b = ref_ctx.mu_sweep([k], R, seeds=sd, Hinit={k: H0}, maxiter=25, **NOSTOP)[k]
+    b = _shard_reference(NMFk, ref_ctx, [k], R, N, seeds=sd, Hinit={k: H0}, maxiter=25, **NOSTOP)[k]
     assert (a["W"] == b["W"]).all() and (a["H"] == b["H"]).all()
     mh.close()
     ref_ctx.close()

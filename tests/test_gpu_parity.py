@@ -316,20 +316,20 @@ def test_mfma_group_monitored_objective(NMFk, ctx, oracle):
 
 @pytest.mark.parametrize("R", [4, 8])
 def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle, R):
-    """Sweeps with <= 8 restarts per rank (a rank's share at 4-8 GPUs): by default the ranks kmin..16 run as ONE mixed-rank
-    launch group on the split-operand MFMA half-step (kmin = 2 up to 4 restarts, 6 above), smaller ranks beside it as ONE
-    mixed-rank packed-VALU launch group, wider ranks on their own kernels.  Against the oracle (same tolerance as
-    everywhere) and against the all-VALU grouping (NMFK_HYB=0)."""
+    """Sweeps with <= 8 restarts per rank (a rank's share at 4-8 GPUs): every rank 2..16 runs in ONE mixed-rank launch group
+    on the split-operand MFMA half-step (round 3: the kernel switches per workgroup between its variants -- one bf16 MFMA and
+    4x4x1 numerator blocks for k <= 4, two and two sets for k <= 8, the 16-signal form above), wider ranks on their own
+    kernels; no packed-VALU launch is left.  Against the oracle (same tolerance as everywhere) and against the all-VALU
+    grouping (NMFK_HYB=0)."""
     n, m = 700, 130
     X = (0.05 + oracle.uniform_fill(33, 0, n * m)).reshape(n, m).astype(np.float32)
     ctx.set_X(X)
     ks, iters = [2, 3, 5, 6, 8, 13, 16, 20], 40
-    kmin = 2 if R <= 4 else 6
     seeds = _seeds(NMFk, 11, ks, R)
     a = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
     info = ctx.last_sweep_info()
-    assert info["mfma_group_units"] == R * sum(kmin <= k <= 16 for k in ks), info
-    assert info["phases"] == 1 and info["merged_valu_groups"] == (0 if R <= 4 else 1), info
+    assert info["mfma_group_units"] == R * sum(2 <= k <= 16 for k in ks), info
+    assert info["phases"] == 1 and info["merged_valu_groups"] == 0, info
     os.environ["NMFK_HYB"] = "0"
     try:
         b = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
@@ -339,13 +339,50 @@ def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle, R):
         for r in range(R):
             e = _rel(a[k]["W"][r] @ a[k]["H"][r], b[k]["W"][r] @ b[k]["H"][r], X)
             assert e <= 5e-6, (k, r, e)
-            if k < kmin or k > 16:
+            if k > 16:
                 assert e == 0.0  # not on the MFMA group: the same kernels in both runs
         W0, H0 = oracle.init_factors(int(seeds[q, 0]), n, m, k)
         ref = oracle.singlerun(X, k, W0, H0, maxiter=iters, **NOSTOP)
         assert _rel(a[k]["W"][0] @ a[k]["H"][0], ref["W"] @ ref["H"], X) <= 1e-4
         assert abs(a[k]["objvalue"][0] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
-    assert max(_rel(a[13]["W"][r] @ a[13]["H"][r], b[13]["W"][r] @ b[13]["H"][r], X) for r in range(R)) > 0.0  # it did run
+    for k in (2, 5, 13):  # every kernel variant did run (the two arithmetics differ in the last bits)
+        assert max(_rel(a[k]["W"][r] @ a[k]["H"][r], b[k]["W"][r] @ b[k]["H"][r], X) for r in range(R)) > 0.0
+
+
+@pytest.mark.parametrize("shape", [(700, 128), (333, 64), (1500, 256)])
+def test_resident_form_of_the_mfma_half_step(NMFk, ctx, oracle, shape, monkeypatch):
+    """Round 3: when the loop dimension of a half-step is a multiple of 64 and short enough for the whole loop factor to sit
+    in LDS (here the W half-step: D = m), the units of the matrix-pipe group run the RESIDENT form (hyb_res_kernel: the
+    factor staged once per workgroup of 16 waves, every wave walking several pairs of lane tiles without barriers, one
+    sum-table slot per workgroup).  Every kernel variant and ragged rank (k = 2..16), a lane dimension that is not a
+    multiple of the tile (n = 700, 333), sweeps with many and with few units (workgroups per unit 1..n/512); against the
+    oracle, against the streaming form (NMFK_HYB_RES=0) and with the default stop rule's bookkeeping intact."""
+    n, m = shape
+    X = (0.05 + oracle.uniform_fill(37, 0, n * m)).reshape(n, m).astype(np.float32)
+    ctx.set_X(X)
+    for ks, R in ((list(range(2, 17)), 3), ([4, 8, 16], 40), ([3], 1)):
+        iters = 30
+        seeds = _seeds(NMFk, 17, ks, R)
+        monkeypatch.setenv("NMFK_HYB", "1")
+        monkeypatch.setenv("NMFK_HYB_MINK", "2")
+        a = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
+        assert ctx.last_sweep_info()["mfma_group_units"] == R * len(ks)
+        monkeypatch.setenv("NMFK_HYB_RES", "0")
+        b = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
+        monkeypatch.delenv("NMFK_HYB_RES")
+        differs = 0.0
+        for q, k in enumerate(ks):
+            for r in range(R):
+                e = _rel(a[k]["W"][r] @ a[k]["H"][r], b[k]["W"][r] @ b[k]["H"][r], X)
+                assert e <= 5e-6, (k, r, e)
+                differs = max(differs, e)
+                np.testing.assert_allclose(a[k]["H"][r].sum(axis=1), 1.0, atol=1e-4)
+            for r in sorted({0, R - 1}):
+                W0, H0 = oracle.init_factors(int(seeds[q, r]), n, m, k)
+                ref = oracle.singlerun(X, k, W0, H0, maxiter=iters, **NOSTOP)
+                assert _rel(a[k]["W"][r] @ a[k]["H"][r], ref["W"] @ ref["H"], X) <= 1e-4, (k, r)
+                assert abs(a[k]["objvalue"][r] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
+        assert differs > 0.0  # the resident form did run (reciprocal denominators: last-bit differences)
 
 
 def test_up_to_four_restarts_all_ranks_on_the_mfma_group(NMFk, ctx, oracle):
@@ -1013,8 +1050,11 @@ def test_merged_sweep_is_bitwise_reproducible_run_to_run(NMFk, oracle, forced_me
             ctx.set_X(X)
             res = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=20, **NOSTOP)
             info = ctx.last_sweep_info()
-            assert info["mfma_group_units"] == 4 * R, info
-            assert info["phases"] == 1 and info["merged_valu_groups"] == 1 and info["launch_groups"] == 3, info
+            if forced_merged_kernel:  # round 2's combination: ranks 6..16 on the MFMA group, ranks 2..5 on the mixed-rank packed-VALU kernel beside it
+                assert info["mfma_group_units"] == 4 * R, info
+                assert info["phases"] == 1 and info["merged_valu_groups"] == 1 and info["launch_groups"] == 3, info
+            else:  # round 3's default: every rank <= 16 on the MFMA group (its kernel variants side by side in one launch)
+                assert info["mfma_group_units"] == 7 * R and info["merged_valu_groups"] == 0 and info["launch_groups"] == 2, info
             if ref is None:
                 ref = res
                 continue

@@ -212,60 +212,64 @@ def main():
                        "mean_iterations_per_factorization": total_iters / nfact},
         }
         if prof and "mu_loop" in prof and prof["mu_loop"]["ms"] > 0:
-            # The hot kernel is one template, step_kernel<KP>, launched per half-step and per rank k on that rank's
-            # stream; the 15 rank groups run concurrently, so a single launch's duration is not exclusive GPU time.
-            # achieved = algorithmic flops of ALL half-step launches of the timed region / GPU time of the MU loop
-            # (HIP events on the library's stream around the loop).  Per-rank sampled launch durations are listed too
-            # and are what `rocprofv3 --kernel-trace --stats` reports per step_kernel<KP> (profiles/).
+            # Round-3 schedule: every factorization of the sweep (ranks 2..16) runs on the split-operand MFMA half-step, ALL
+            # units in one launch per half-step (the kernels switch between their rank variants per workgroup):
+            #   H half-step  hyb_step_kernel<2,8,false>   streaming form (loop dimension n = 8192)
+            #   W half-step  hyb_res_kernel<2,false>      resident form  (loop factor H, 512 rows, in LDS)
+            # A launch has the GPU to itself, so its sampled duration (HIP events on the launching stream, every 47th
+            # iteration) is exclusive GPU time; rocprofv3 --kernel-trace --stats of the same command gives the same
+            # averages (profiles/r03/bench_default_kernel_stats.csv).
             loop = prof["mu_loop"]
             tf = loop["flops"] / (loop["ms"] * 1e-3) / 1e12
             per_kp = {}
             for name, v in prof.items():
                 if name.startswith(("h_step", "w_step")) and v["launches"]:
                     per_kp[name] = {"avg_launch_ms": round(v["ms"] / v["launches"], 4), "sampled_launches": v["launches"],
-                                    "TFLOPs_while_sharing_the_GPU": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                                    "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
             dom = max(per_kp, key=lambda k_: prof[k_]["ms"]) if per_kp else None
             xbytes = sum(float(np.sum(iters_by_k[k])) for k in ks) * 2.0 * args.n * args.m * 4.0 * args.steps / max(world, 1)
             whole = {"achieved": tf, "frac": tf / PEAK_FP32_TFLOPS, "mu_loop_gpu_ms": loop["ms"],
-                     "note": "algorithmic flops of ALL half-step launches / GPU time of the whole MU loop (HIP events)"}
-            if dom is not None and dom.endswith("<mfma>"):
-                # Two-phase sweep: the ranks 9..16 run first, as ONE mixed-rank launch group (256 factorizations per
-                # launch) with the GPU to themselves, so the sampled launch durations of that kernel are exclusive GPU time.
-                h, w = prof["h_step<mfma>"], prof["w_step<mfma>"]
-                tfd = (h["flops"] + w["flops"]) / ((h["ms"] + w["ms"]) * 1e-3) / 1e12
+                     "note": "algorithmic flops of ALL half-step launches / GPU time of the whole MU loop (HIP events), check blocks included"}
+            kernel_of = {"h_step<mfma>": "hyb_step_kernel<2,8,false> (nmfk_step_hyb.hip, streaming form): the H half-step of ALL units of the sweep in one launch",
+                         "w_step<mfma>": "hyb_res_kernel<2,false> (nmfk_step_hyb.hip, resident form: the loop factor H in LDS): the W half-step of ALL units of the sweep in one launch"}
+            traffic, tsrc = _pmc_traffic()
+            if dom in kernel_of:
+                d = prof[dom]
+                tfd = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                other = [k_ for k_ in kernel_of if k_ != dom and k_ in prof and prof[k_]["launches"]]
                 line["roofline"] = {
-                    "kernel": "hyb_step_kernel<16,2,8,false> (nmfk_step_hyb.hip): H and W half-step launches of the mixed-rank group "
-                              "(ranks 9..16 x 32 restarts = 256 factorizations per launch), alone on the GPU in phase 1 of the sweep",
+                    "kernel": kernel_of[dom] + f" ({nfact // max(world, 1)} factorizations per launch: kernel variants by rank -- one bf16 MFMA "
+                              "+ 4x4x1 fp32 numerator blocks for k <= 4, two + two sets for k <= 8, three + 16-signal fp32 MFMAs for k <= 16)",
                     "bound": "mfma", "achieved": tfd, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tfd / PEAK_FP32_TFLOPS,
-                    "traffic": _pmc_traffic()[0], "traffic_source": _pmc_traffic()[1],
-                    "avg_launch_ms": {"h_step": h["ms"] / h["launches"], "w_step": w["ms"] / w["launches"]},
-                    "sampled_launches": h["launches"] + w["launches"],
-                    "whole_mu_loop": whole, "per_rank_kernel": per_kp,
+                    "traffic": traffic, "traffic_source": tsrc,
+                    "avg_launch_ms": d["ms"] / d["launches"], "sampled_launches": d["launches"],
+                    "other_half_step": {k_: {"kernel": kernel_of[k_], "avg_launch_ms": prof[k_]["ms"] / prof[k_]["launches"],
+                                             "achieved": prof[k_]["flops"] / (prof[k_]["ms"] * 1e-3) / 1e12,
+                                             "frac": prof[k_]["flops"] / (prof[k_]["ms"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS} for k_ in other},
+                    "whole_mu_loop": whole,
                     "note": "flops = 4*n*m*k per half-step per ACTIVE restart (W*H and the product with the ratio; SURVEY 8d: "
-                            "8*n*m*k per iteration), launch durations from HIP events on the launching stream (every 47th "
-                            "iteration). The kernel computes W*H on the bf16 matrix pipe from exact three-term bf16 splits "
-                            "(fp32-accurate) and the numerators on the fp32 matrix pipe; the peak quoted is the fp32 MFMA = "
-                            "fp32 vector peak of gfx950. The other ranks (2..8) run afterwards on step_kernel<KP> (packed "
-                            "fp32 FMAs, concurrent streams); X is L2/Infinity-Cache resident, HBM is not the bound.",
+                            "8*n*m*k per iteration). The kernel computes W*H on the bf16 matrix pipe from exact three-term bf16 "
+                            "splits (fp32-accurate) and the numerators on the fp32 matrix pipe; the peak quoted is the fp32 MFMA = "
+                            "fp32 vector peak of gfx950 (the bf16 part of the work is cheaper than its fp32 equivalent, so this "
+                            "fraction is against the arithmetic the REFERENCE does, not against the pipes' own peaks). "
+                            "X is L2/Infinity-Cache resident, HBM is not the bound.",
                     "x_GBps_if_every_restart_streamed_X": xbytes / (loop["ms"] * 1e-3) / 1e9,
-                    "x_GBps_note": "SURVEY 8d's 2*n*m*4 B per restart and iteration over the MU-loop time: an ON-DIE figure "
-                                   "(L2 / Infinity Cache serve X to the restarts of a launch), NOT HBM traffic and not to be "
-                                   "read against the 8 TB/s HBM peak; `traffic` is the measured HBM bytes per launch",
+                    "x_GBps_note": "SURVEY 8d's 2*n*m*4 B per restart and iteration over the MU-loop time: an ON-DIE figure (L2 / "
+                                   "Infinity Cache serve X to the restarts of a launch), NOT HBM traffic and not to be read against "
+                                   "the 8 TB/s HBM peak; `traffic` is the measured HBM bytes per launch",
                 }
             else:
                 line["roofline"] = {
-                    "kernel": "step_kernel<KP> (half-step numerators + fused finish; all ranks, concurrent streams)",
+                    "kernel": "step_kernel<KP> / hyb kernels per launch group (schedule other than the bench default)",
                     "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
-                    "traffic": _pmc_traffic()[0], "traffic_source": _pmc_traffic()[1], "mu_loop_gpu_ms": loop["ms"], "dominant_rank_kernel": dom, "per_rank_kernel": per_kp,
-                    "note": "flops = 4*n*m*k per half-step per ACTIVE restart (W*H and the product with the ratio; SURVEY 8d: "
-                            "8*n*m*k per iteration). fp32 vector and fp32 MFMA share the 157.3 TFLOP/s peak on gfx950; the "
-                            "kernels issue packed fp32 FMAs (v_pk_fma_f32) or, for the mixed-rank group of few-restart sweeps, "
-                            "MFMAs. The rank groups run concurrently, so a launch's duration is not exclusive GPU time and the "
-                            "fraction is the aggregate over the MU loop. HBM view: X is L2/Infinity-Cache resident "
-                            "(2 x 16.8 MB), so the algorithmic X bytes below are served on-die, not by HBM.",
+                    "traffic": traffic, "traffic_source": tsrc, "mu_loop_gpu_ms": loop["ms"], "dominant_rank_kernel": dom,
+                    "per_rank_kernel": per_kp,
+                    "note": "flops = 4*n*m*k per half-step per ACTIVE restart; launch groups run concurrently, so the fraction is the "
+                            "aggregate over the MU loop.",
                     "x_GBps_if_every_restart_streamed_X": xbytes / (loop["ms"] * 1e-3) / 1e9,
                     "x_GBps_note": "on-die figure (L2 / Infinity Cache), not HBM traffic",
                 }
+            line["config"]["schedule"] = ctx.last_sweep_info()
         if not args.no_kopt_check and world == 1 and (args.n, args.m, args.kmin, args.kmax, args.nruns) == (8192, 512, 2, 16, 32):
             # "same kopt" half of the metric, outside the timed region: SURVEY 8d's planted rank-6 matrix through the same
             # sweep in fp32 (the product) and in fp64 compute (the reference's arithmetic and stop decisions,

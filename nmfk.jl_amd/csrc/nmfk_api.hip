@@ -649,7 +649,23 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       const int ntp = (L + 31) / 32;                                     // pairs of 16-lane tiles
       const int fill = (4 * cus + hyb_units - 1) / hyb_units;            // workgroups per unit that fill the chip a few times
       const int rw = nmfk_hyb_resident_waves();
-      res_wgs[which] = std::max(1, std::min(std::max(1, ntp / rw), std::max(std::max(1, ntp / (rw * T.hyb_res_tpw)), fill)));
+      // between "a few pairs per wave" / "enough workgroups to fill the chip" and "one pair per wave": the count that
+      // leaves the fewest wave slots without a pair in the last round (240 units: 8 workgroups x 2 pairs per wave, not
+      // 5 x 3.2 -- a fifth of the waves would walk a fourth pair while the others wait)
+      // (at least two pairs per wave: with one, a workgroup stages the whole factor for a single pair per wave and the form
+      //  loses against the streaming kernel -- 120 units: W half-step 0.237 vs 0.218 ms)
+      const int gmax = std::max(1, ntp / (2 * rw)), gmin = std::min(gmax, std::max(std::max(1, ntp / (rw * T.hyb_res_tpw)), fill));
+      int best = gmin;
+      double waste = 1e30;
+      for (int gq = gmin; gq <= gmax; ++gq) {
+        const int rounds = (ntp + rw * gq - 1) / (rw * gq);
+        const double wq = (double)rounds * rw * gq / ntp;
+        if (wq < waste - 1e-9) {
+          waste = wq;
+          best = gq;
+        }
+      }
+      res_wgs[which] = best;
     }
   }
   // workgroups (= lane tiles = sum-table slots) of one unit of rank k in the half-step `which`
@@ -674,7 +690,13 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       return std::max<int64_t>(t, 1);
     };
     g.wsplit = 1;
-    if (wgs(1) < target) g.wsplit = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
+    // the waves of a workgroup split the loop range (and stage for themselves) when whole workgroups would not fill the
+    // chip: below 2 per CU for the packed-VALU kernels, below 1.5 per CU when the phase runs the split-operand MFMA
+    // kernel, whose per-wave staging form is the slower one (240 units x 2 lane tiles: 0.376 ms shared vs 0.436 ms split)
+    bool phase_hyb = false;
+    for (int q = 0; q < nk; ++q) phase_hyb = phase_hyb || (phase_of_k(ks[q]) == phase && use_hyb_k(ks[q]));
+    const int target_ws = (T.target_wgs > 0 || !phase_hyb) ? target : 3 * cus / 2;
+    if (wgs(1) < target_ws) g.wsplit = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
     const int64_t have = wgs(g.wsplit);
     int S = (int)((target + have - 1) / have);
     const int maxS = std::max(1, D / (64 * g.wsplit));

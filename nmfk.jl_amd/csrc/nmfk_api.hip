@@ -104,13 +104,14 @@ struct Sampler {
 //   NMFK_MFMA_SSE, NMFK_HYB_SSE   0: monitored objective of the MFMA groups on the packed-VALU objective kernel
 //   NMFK_STREAMS      concurrent rank-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1 prints the host's share of the loop
 //   NMFK_MERGE_PHASED 1: merged sweeps run their matrix-pipe groups first and the packed-VALU group behind them (default: side by side)
+//   NMFK_WIDE2        0: ranks > 16 on the all-fp32 MFMA kernel only (default: split-operand first product where it pays)
 //   NMFK_HYB_RES      0: no resident form of the split-operand MFMA half-step (short loop dimension: the loop factor in LDS)
 //   NMFK_HYB_RES_TPW  pairs of lane tiles a wave of the resident form should walk (4)
 //   NMFK_HYB_SMALL    0: ranks <= 8 keep the round-2 forms (packed-VALU / 16-signal MFMA) -- A/B switch for the 4x4x1 variants
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, hyb_groups = 1, merge = -1, phases = -1, max_wsplit = 8;
   int wide_sse = 1, hyb_sse = 1, streams = -1, host_timing = 0, merge_phased = 0, hyb_small = 1;
-  int hyb_res = 1, hyb_res_tpw = 4;
+  int hyb_res = 1, hyb_res_tpw = 4, wide2 = 1;
 };
 Tuning read_tuning() {
   Tuning t;
@@ -135,6 +136,7 @@ Tuning read_tuning() {
   geti("NMFK_HOST_TIMING", t.host_timing);
   geti("NMFK_MERGE_PHASED", t.merge_phased);
   geti("NMFK_HYB_SMALL", t.hyb_small);
+  geti("NMFK_WIDE2", t.wide2);
   geti("NMFK_HYB_RES", t.hyb_res);
   geti("NMFK_HYB_RES_TPW", t.hyb_res_tpw);
   t.hyb_res_tpw = std::max(1, t.hyb_res_tpw);
@@ -559,6 +561,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   const bool mfma_ok = !f64 && !ctx->sparse && ctx->nan_count == 0 && n >= 16 && m >= 16;
   const bool wide_ok = T.wide && mfma_ok;
   auto use_wide_k = [&](int k) { return wide_ok && k > 16; };
+  // ... and of those the widths whose first product runs from bf16 splits (wide2_step_kernel, nmfk_step_hyb.hip)
+  const bool tile_fits = (int64_t)n * m * 4 < ((int64_t)1 << 32) - 4096;  // (buffer loads: 32-bit byte offsets into the tiled X)
+  auto use_wide2_k = [&](int k) { return use_wide_k(k) && T.wide2 && tile_fits && nmfk_wide2_ok(nmfk_padded_k(k)); };
   // Ranks in [hyb_mink, 16]: split-operand MFMA half-step (nmfk_step_hyb.hip).  Its cost does not depend on the rank
   // and ONE instantiation serves all ranks, so its units share one launch group.  Two schedules use it:
   //  * few restarts per rank (<= 8; a rank's share at 4-8 GPUs): the ranks >= 6 as one group on it, the small ranks
@@ -631,6 +636,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // lane elements per workgroup (= per sum-table slot) of the half-step kernel a rank runs
   auto lane_tile = [&](int k, int ws) {
     if (ctx->sparse) return NMFK_TILE;
+    if (use_wide2_k(k) && ws == 1) return nmfk_wide2_lane_tile();
     if (use_wide_k(k)) return nmfk_mfma_wide_lane_tile(ws);
     if (use_hyb_k(k)) return nmfk_hyb_lane_tile(ws);
     if (valu_merged && k <= NMFK_MULTI_MAXK && !use_hyb_k(k)) return (ws > 1 ? 64 : NMFK_TILE) * NMFK_MULTI_LB;
@@ -696,7 +702,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     bool phase_hyb = false;
     for (int q = 0; q < nk; ++q) phase_hyb = phase_hyb || (phase_of_k(ks[q]) == phase && use_hyb_k(ks[q]));
     const int target_ws = (T.target_wgs > 0 || !phase_hyb) ? target : 3 * cus / 2;
-    if (wgs(1) < target_ws) g.wsplit = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
+    // (the split-operand wide-rank kernel has no form in which the waves of a workgroup split the loop range: a phase
+    //  that runs it fills the chip by splitting the range over workgroups instead, S below)
+    bool phase_wide2 = false;
+    for (int q = 0; q < nk; ++q) phase_wide2 = phase_wide2 || (phase_of_k(ks[q]) == phase && use_wide2_k(ks[q]));
+    if (wgs(1) < target_ws && !phase_wide2) g.wsplit = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
     const int64_t have = wgs(g.wsplit);
     int S = (int)((target + have - 1) / have);
     const int maxS = std::max(1, D / (64 * g.wsplit));
@@ -880,7 +890,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   else
     nmfk_launch_init_f32(ia, st);
   bool any_hyb = false;
-  for (int q = 0; q < nk; ++q) any_hyb = any_hyb || use_hyb_k(ks[q]);
+  for (int q = 0; q < nk; ++q) any_hyb = any_hyb || use_hyb_k(ks[q]) || use_wide2_k(ks[q]);  // (kernels that read the tiled X)
   const size_t tile_h = (size_t)((m + 15) / 16) * ((n + 15) / 16) * 256, tile_w = tile_h;  // floats
   if (any_hyb) {
     if (ctx->xtile_gen != ctx->xgen) {
@@ -1116,6 +1126,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
 #endif
         else if (f64)
           nmfk_launch_step_f64(hs, d_hs, G.kp, G.begin, G.count, gs);
+        else if (use_wide(G) && use_wide2_k(G.k) && hs.wsplit == 1)
+          nmfk_launch_step_wide2_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         else if (use_wide(G))
           nmfk_launch_step_mfma_wide_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         else
@@ -1145,6 +1157,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
 #endif
         else if (f64)
           nmfk_launch_step_f64(ws, d_ws, G.kp, G.begin, G.count, gs);
+        else if (use_wide(G) && use_wide2_k(G.k) && ws.wsplit == 1)
+          nmfk_launch_step_wide2_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         else if (use_wide(G))
           nmfk_launch_step_mfma_wide_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         else

@@ -1038,6 +1038,247 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Wide ranks (16 < k <= 64; round 3): the split-operand first product where the split amortises.  mfma_wide_kernel
+// (nmfk_step_impl.h) runs both products in plain fp32: kp/4 + kp/4 MFMAs of 32 cycles per 16 x 16 tile and 16 loop steps
+// (k = 64: 1024 matrix cycles).  Here W*H comes from the three-term bf16 splits like above -- the six term pairs need
+// 6 * KS contraction slots, i.e. 3 * NB instructions of 16 cycles for KS = 16 * NB signals (k = 64: 12 * 16 = 192 cycles
+// instead of 512) -- and the numerators stay exact fp32 (4 * NB MFMAs of 32 cycles): 704 cycles per tile at k = 64,
+// 352 at k <= 32.  Contraction layout: slot group G = 4 j + g (MFMA j, k-lane group g) <-> term pair G / (2 NB), block of
+// eight signals G % (2 NB); a lane therefore only ever needs the blocks sub = g (NB = 2) or g, g + 4 (NB = 4) of its
+// lane-factor row, in the three terms: 3 * NB / 2 operand registers of 128 bits per lane tile.
+// Streaming form (a workgroup of 8 waves = 256 lane elements shares staged blocks of 64 loop rows, one barrier per block),
+// loop range optionally split over workgroups (S > 1: partial numerators, reduce_kernel finishes).  2 waves per SIMD.
+// ------------------------------------------------------------------------------------------------------
+template <int NB, int NT>
+__global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const float *__restrict__ Xt, const NmfkRun *__restrict__ runs,
+                                                            const NmfkState *__restrict__ state, const NmfkStepArgs *__restrict__ gp,
+                                                            int it, int u0) {
+  extern __shared__ double lds[];  // den[64], red[8][64], then two staged blocks
+  constexpr int KS = 16 * NB, NM = 3 * NB, NH = 2 * NB, CPB = 4;
+  constexpr int CHP = 3 * NH * 256, CHT = NB * 4 * 256;  // bytes of a chunk's split planes / transposed blocks
+  constexpr int BFB = CPB * CHP, STB = BFB + CPB * CHT;
+  constexpr int PPR = KS / 2, NITEM = 16 * CPB * PPR, NI = NITEM / 512;  // staging items (row, signal pair) per thread
+  constexpr int NSUB = NB / 2;  // blocks of eight signals of the lane factor a lane needs per term (sub = g + 4 i)
+  static_assert(NB == 2 || NB == 4, "KS = 32 or 64");
+  static_assert(NITEM % 512 == 0, "items divide evenly");
+  const int u = u0 + blockIdx.y, bx = blockIdx.x;
+  if (!gp->force && !state[u].active) return;
+  const NmfkRun *__restrict__ rdp = runs + u;
+  const int k = rdp->k, kp = rdp->kp;  // true rank, row stride (padding rows of the factors are zero and stay zero)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int which = gp->which, S = gp->S, L = gp->L, D = gp->D;
+  const int tile = bx / S, sp = bx - tile * S;
+  const int l0 = tile * (16 * NT * 8) + wave * 16 * NT;
+  const float *__restrict__ A = (const float *)(arena + (which == 0 ? NMFK_HOFF(*rdp, it) : rdp->oWt));      // lane factor
+  const float *__restrict__ B = (const float *)(arena + (which == 0 ? rdp->oWt : NMFK_HOFF(*rdp, it + 1)));  // loop factor
+  const int d0 = __builtin_amdgcn_readfirstlane(sp * gp->dchunk);
+  const int d1 = __builtin_amdgcn_readfirstlane(min(D, d0 + gp->dchunk));
+  const int nchunks = (d1 - d0 + 15) >> 4;
+  constexpr int tA[6] = {0, 0, 1, 1, 0, 2}, tB[6] = {0, 1, 0, 1, 2, 0};  // term pairs (hh, hm, mh, mm, hl, lh)
+
+  // lane-factor operand blocks: bopt[t][term][i] = signals [8 (g + 4 i), + 8) of row l in term `term`
+  bf16x8_t bopt[NT][3][NSUB];
+  int lt[NT];
+  bool lv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int l = l0 + 16 * t + c16;
+    lv[t] = l < L;
+    lt[t] = lv[t] ? l : L - 1;
+#pragma unroll
+    for (int i = 0; i < NSUB; ++i) {
+      const int s0 = 8 * (g + 4 * i);
+      const float *rp = A + (int64_t)lt[t] * kp + (s0 < kp ? s0 : 0);  // (a block that ends beyond the row reads into the next row: masked)
+      const f32x4_t r0 = *(const f32x4_u *)rp, r1 = *(const f32x4_u *)(rp + 4);
+      u32x4_t hh, mm, ll;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int c = 2 * w + e;
+          v[e] = (lv[t] && s0 + c < kp) ? (c < 4 ? r0[c & 3] : r1[c & 3]) : 0.0f;
+        }
+        uint32_t h, m, lo;
+        split3_pair(v[0], v[1], h, m, lo);
+        hh[w] = h;
+        mm[w] = m;
+        ll[w] = lo;
+      }
+      bopt[t][0][i] = __builtin_bit_cast(bf16x8_t, hh);
+      bopt[t][1][i] = __builtin_bit_cast(bf16x8_t, mm);
+      bopt[t][2][i] = __builtin_bit_cast(bf16x8_t, ll);
+    }
+  }
+  f32x4_t acc[NT][NB];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[t][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // X from the tiled copy: block (16-lane tile, chunk) = 1 KB in lane order
+  const int nD16 = (D + 15) >> 4, nL16 = (L + 15) >> 4;
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)Xt, 0, -1, 0x00020000);
+  const uint32_t xlane = (uint32_t)lane * 16u;
+  int xo[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) xo[t] = __builtin_amdgcn_readfirstlane(min((l0 >> 4) + t, nL16 - 1) * nD16 * 1024);
+  auto xload = [&](int dch, f32x4_t (&xv)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      xv[t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, xlane, xo[t] + dch * 64, 0));
+  };
+
+  // staging: item q = tid + 512 i -> (row r of the block, signal pair cp); the rows of a block are contiguous in memory
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void *)B, 0, -1, 0x00020000);
+  char *sb = (char *)(lds + 9 * NMFK_MAX_K);
+  float sv[NI][2];
+  auto stage_load = [&](int row0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int q = tid + 512 * i, r = q / PPR, cp = q - r * PPR;
+      const uint32_t vo = (uint32_t)((r * kp + min(2 * cp, max(kp - 2, 0))) * 4);
+      sv[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsb, vo, row0 * kp * 4, 0));
+      sv[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsb, vo + 4, row0 * kp * 4, 0));
+    }
+  };
+  auto stage_write = [&](char *dst, int row0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int q = tid + 512 * i, r = q / PPR, cp = q - r * PPR;
+      const bool ok = row0 + r < D;  // (rows past the factor's end and padding signals are staged as zeros)
+      const float v0 = (ok && 2 * cp < kp) ? sv[i][0] : 0.0f, v1 = (ok && 2 * cp + 1 < kp) ? sv[i][1] : 0.0f;
+      uint32_t h, m, lo;
+      split3_pair(v0, v1, h, m, lo);
+      const int ch = r >> 4, rr = r & 15;
+      char *d = dst + ch * CHP + (cp >> 2) * 256 + rr * 16 + (cp & 3) * 4;  // plane (term, block of eight signals cp >> 2)
+      *(uint32_t *)(d) = h;
+      *(uint32_t *)(d + NH * 256) = m;
+      *(uint32_t *)(d + 2 * NH * 256) = lo;
+      // transposed: plane (block of sixteen signals, loop steps [4g, 4g + 4)), signal c at (c & 15) * 16: four fp32 values
+      char *tr = dst + BFB + ch * CHT + (((2 * cp) >> 4) * 4 + (rr >> 2)) * 256 + ((2 * cp) & 15) * 16 + (rr & 3) * 4;
+      *(float *)(tr) = v0;
+      *(float *)(tr + 16) = v1;
+    }
+  };
+
+  f32x4_t xr[4][NT];
+  if (nchunks > 0) {
+    const int dlast = d0 + 16 * (nchunks - 1);
+    stage_load(d0);
+    xload(d0, xr[0]);
+    xload(min(d0 + 16, dlast), xr[1]);
+    stage_write(sb, d0);
+    const int nblocks = (nchunks + CPB - 1) / CPB;
+    for (int blk = 0; blk < nblocks; ++blk) {
+      char *cur = sb + (blk & 1) * STB, *nxt = sb + ((blk & 1) ^ 1) * STB;
+      const bool more = blk + 1 < nblocks;
+      if (more) stage_load(d0 + 64 * (blk + 1));
+      __syncthreads();  // this block is staged (and the other buffer is free: everybody left it a block ago)
+#pragma unroll
+      for (int ch = 0; ch < CPB; ++ch) {
+        const int c = blk * CPB + ch;
+        if (c >= nchunks) break;
+        const int dch = d0 + 16 * c;
+        xload(min(dch + 32, dlast), xr[(ch + 2) & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        // first product: P[d = 4g + r][l = c16] from the six term pairs
+        f32x4_t p[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NM; ++j) {
+          const int tp = NB == 4 ? (j >> 1) : j, i = NB == 4 ? (j & 1) : 0;  // group G = 4j + g: term pair, block sub = g + 4 i
+          const bf16x8_t av = *(const bf16x8_t *)(cur + ch * CHP + (tA[tp] * NH + 4 * i + g) * 256 + c16 * 16);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bopt[t][tB[tp]][i], p[t], 0, 0, 0);
+        }
+        // ratios; loop steps beyond the range give zero
+        f32x4_t q[NT];
+        const bool edge = dch + 16 > d1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const f32x2_t rc = {__builtin_amdgcn_rcpf(p[t][r]), __builtin_amdgcn_rcpf(p[t][r + 1])};
+            const f32x2_t q2 = (f32x2_t){xr[ch & 3][t][r], xr[ch & 3][t][r + 1]} * rc;
+            q[t][r] = (!edge || dch + 4 * g + r < d1) ? q2.x : 0.0f;
+            q[t][r + 1] = (!edge || dch + 4 * g + r + 1 < d1) ? q2.y : 0.0f;
+          }
+        // second product: numerators of the signals 16 nb + 4g + r'
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const f32x4_t bn = *(const f32x4_t *)(cur + BFB + ch * CHT + (nb * 4 + g) * 256 + c16 * 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[r], q[t][r], acc[t][nb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (more) stage_write(nxt, d0 + 64 * (blk + 1));
+    }
+  }
+  // acc[t][nb][r] = numerator of signal c = 16 nb + 4g + r at lane element l0 + 16t + c16
+
+  if (!gp->fused) {
+    float *__restrict__ part = (float *)(arena + rdp->opart);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (lv[t]) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 16 * nb + 4 * g + r;
+            if (c < kp) part[((int64_t)sp * L + lt[t]) * kp + c] = acc[t][nb][r];
+          }
+      }
+    return;
+  }
+  const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
+  const int PB = which == 0 ? gp->PW : gp->PH;
+  double *den = lds;
+  __syncthreads();  // (the staging buffers are not touched below, but den/red live in front of them: keep the phases apart)
+  if (tid < kp) {
+    double sd = 0;
+    for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * kp + tid];
+    den[tid] = sd;
+  }
+  __syncthreads();
+  float *__restrict__ Anew = which == 0 ? (float *)(arena + NMFK_HOFF(*rdp, it + 1)) : (float *)(arena + rdp->oWt);
+  double *sumA = (double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)) + (int64_t)tile * kp;
+  double *red = den + NMFK_MAX_K;  // [8][kp]
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * nb + 4 * g + r;
+      float vs = 0.f;
+      if (c < kp) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (lv[t]) {
+            float v = 0.f;
+            if (c < k) v = A[c + (int64_t)lt[t] * kp] * acc[t][nb][r] / (float)den[c];  // Mult:67 / Mult:70 order
+            Anew[c + (int64_t)lt[t] * kp] = v;
+            vs += v;
+          }
+      }
+      double v = (double)vs;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (c16 == 0 && c < kp) red[wave * kp + c] = v;
+    }
+  __syncthreads();
+  if (tid < kp) {
+    double t = red[tid];
+    for (int w = 1; w < 8; ++w) t += red[w * kp + tid];
+    sumA[tid] = tid < k ? t : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // The kernels.  ONE launch serves units of different kernel variants (NmfkRun::hyb = 4 / 8 / 16, see nmfk_hyb_variant):
 // a workgroup belongs to one unit, so the switch is workgroup-uniform; registers and LDS are those of the widest variant
 // (the same 4 waves per SIMD for all).  With a launch per variant the 96 + 128 + 256 factorizations of the bench sweep
@@ -1162,4 +1403,29 @@ void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double w
   const dim3 grid((w.L + lpw - 1) / lpw, cnt), blk(64 * NW);
   const size_t ldsb = sizeof(double) * 17 * 16 + 2 * NMFK_HYB_CPB * 3 * (size_t)(vmax <= 8 ? 1 : 2) * 256;  // two blocks of split planes
   hipLaunchKernelGGL((hyb_step_kernel<NT, NW, true>), grid, blk, ldsb, s, w.arena, w.Xalt, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
+}
+
+// Wide ranks on the split-operand first product (wide2_step_kernel): kp <= 32 (KS = 32) and kp >= 56 (KS = 64); at kp = 40, 48
+// the padding to 64 signals costs more than the split saves (measured at 65536 x 2048, k = 48: 7.39 vs 5.68 ms per
+// iteration of 8 restarts), those widths stay on mfma_wide_kernel.
+int nmfk_wide2_ok(int kp) { return (kp > 16 && kp <= 32) || (kp >= 56 && kp <= 64); }
+int nmfk_wide2_lane_tile() { return 16 * NMFK_HYB_NT * 8; }
+
+void nmfk_launch_step_wide2_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s) {
+  constexpr int NT = NMFK_HYB_NT;
+  const int lpw = 16 * NT * 8, ntile = (a.L + lpw - 1) / lpw;
+  const dim3 grid(ntile * a.S, cnt), blk(512);
+  const int nb = kp <= 32 ? 2 : 4;
+  const size_t chunkb = 3 * (size_t)(2 * nb) * 256 + (size_t)nb * 1024;
+  const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + 2 * 4 * chunkb;
+  if (nb == 2) {
+    hipLaunchKernelGGL((wide2_step_kernel<2, NT>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0);
+  } else {
+    static bool once = false;  // 86 KB of dynamic LDS
+    if (!once) {
+      (void)hipFuncSetAttribute((const void *)wide2_step_kernel<4, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      once = true;
+    }
+    hipLaunchKernelGGL((wide2_step_kernel<4, NT>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0);
+  }
 }

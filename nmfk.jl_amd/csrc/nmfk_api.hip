@@ -721,6 +721,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     for (int q = 0; q < nk; ++q)
       if (phase_of_k(ks[q]) == phase)
         g.slots = std::max(g.slots, tiles_of(ks[q], which, L, g.wsplit));
+    // not fused: reduce_kernel finishes the half-step, one workgroup per (slot, unit) -- with the few lane tiles that made
+    // the split necessary that was 8 workgroups per unit walking 16 K elements x S partials each (345 us per launch at
+    // 65536 x 2048, k = 64, 8 units, against a 1.8 ms half-step): any partition of the lane range into slots is valid,
+    // so give it up to 64 slots of >= 32 lane elements
+    if (!g.fused) g.slots = std::max(g.slots, std::min(64, (L + 31) / 32));
     return g;
   };
   Geo ghp[2] = {geometry(m, n, 0, 0), geometry(m, n, phased ? 1 : 0, 0)};
@@ -1182,6 +1187,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_sse_f64(sa, G.begin, G.count, gs);
         } else if (use_hyb(G) && sa.Wgt == nullptr && hyb_sse) {
           nmfk_launch_hyb_sse(wsP[G.phase], d_wsP[G.phase], P.weight, (it + 1) & 1, G.hyb, G.begin, G.count, gs);
+        } else if (use_wide(G) && use_wide2_k(G.k) && sa.Wgt == nullptr && wide_sse) {
+          nmfk_launch_wide2_sse(wsP[G.phase], d_wsP[G.phase], P.weight, (it + 1) & 1, G.kp, G.begin, G.count, gs);
         } else if (use_wide(G) && sa.Wgt == nullptr && wide_sse) {
           nmfk_launch_sse_mfma_wide_f32(sa, G.kp, G.begin, G.count, gs);
         } else {

@@ -258,6 +258,7 @@ int nmfk_hyb_lane_tile(int wsplit);
 int nmfk_wide2_ok(int kp);  // wide rank width served by the split-operand form of the all-MFMA half-step (wide2_step_kernel)
 int nmfk_wide2_lane_tile();
 void nmfk_launch_step_wide2_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s);
+void nmfk_launch_wide2_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double weight, int hsel, int kp, int u0, int cnt, hipStream_t s);
 int nmfk_hyb_resident_waves();  // waves per workgroup of the resident form
 size_t nmfk_hyb_resident_lds(int variant, int D);  // LDS bytes of the resident form for a loop dimension D, 0 = not applicable
 int nmfk_hyb_variant(int k);  // kernel variant of rank k on the split-operand MFMA half-step: 4 / 8 / 12 / 16

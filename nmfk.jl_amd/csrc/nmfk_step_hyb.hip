@@ -1049,10 +1049,13 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
 // Streaming form (a workgroup of 8 waves = 256 lane elements shares staged blocks of 64 loop rows, one barrier per block),
 // loop range optionally split over workgroups (S > 1: partial numerators, reduce_kernel finishes).  2 waves per SIMD.
 // ------------------------------------------------------------------------------------------------------
-template <int NB, int NT>
+// OBJ: the monitored objective (Mult:74) instead of a half-step -- gp = the W half-step's arguments, `it` = parity of the H
+// buffer that holds the current H, whole loop range, first product only, one partial per workgroup (256 rows of X) in
+// ossepart[tile] like sse_kernel.
+template <int NB, int NT, bool OBJ>
 __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const float *__restrict__ Xt, const NmfkRun *__restrict__ runs,
                                                             const NmfkState *__restrict__ state, const NmfkStepArgs *__restrict__ gp,
-                                                            int it, int u0) {
+                                                            int it, int u0, double weight) {
   extern __shared__ double lds[];  // den[64], red[8][64], then two staged blocks
   constexpr int KS = 16 * NB, NM = 3 * NB, NH = 2 * NB, CPB = 4;
   constexpr int CHP = 3 * NH * 256, CHT = NB * 4 * 256;  // bytes of a chunk's split planes / transposed blocks
@@ -1062,17 +1065,18 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
   static_assert(NB == 2 || NB == 4, "KS = 32 or 64");
   static_assert(NITEM % 512 == 0, "items divide evenly");
   const int u = u0 + blockIdx.y, bx = blockIdx.x;
-  if (!gp->force && !state[u].active) return;
+  if (!(gp->force && !OBJ) && !state[u].active) return;
   const NmfkRun *__restrict__ rdp = runs + u;
   const int k = rdp->k, kp = rdp->kp;  // true rank, row stride (padding rows of the factors are zero and stay zero)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const int which = gp->which, S = gp->S, L = gp->L, D = gp->D;
+  const int which = gp->which, S = OBJ ? 1 : gp->S, L = gp->L, D = gp->D;
   const int tile = bx / S, sp = bx - tile * S;
   const int l0 = tile * (16 * NT * 8) + wave * 16 * NT;
   const float *__restrict__ A = (const float *)(arena + (which == 0 ? NMFK_HOFF(*rdp, it) : rdp->oWt));      // lane factor
-  const float *__restrict__ B = (const float *)(arena + (which == 0 ? rdp->oWt : NMFK_HOFF(*rdp, it + 1)));  // loop factor
-  const int d0 = __builtin_amdgcn_readfirstlane(sp * gp->dchunk);
-  const int d1 = __builtin_amdgcn_readfirstlane(min(D, d0 + gp->dchunk));
+  const float *__restrict__ B = (const float *)(arena + (which == 0 ? rdp->oWt : NMFK_HOFF(*rdp, OBJ ? it : it + 1)));  // loop factor
+  const int d0 = __builtin_amdgcn_readfirstlane(OBJ ? 0 : sp * gp->dchunk);
+  const int d1 = __builtin_amdgcn_readfirstlane(OBJ ? D : min(D, d0 + gp->dchunk));
+  double ssum = 0.0;
   const int nchunks = (d1 - d0 + 15) >> 4;
   constexpr int tA[6] = {0, 0, 1, 1, 0, 2}, tB[6] = {0, 1, 0, 1, 2, 0};  // term pairs (hh, hm, mh, mm, hl, lh)
 
@@ -1156,9 +1160,11 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
       *(uint32_t *)(d + NH * 256) = m;
       *(uint32_t *)(d + 2 * NH * 256) = lo;
       // transposed: plane (block of sixteen signals, loop steps [4g, 4g + 4)), signal c at (c & 15) * 16: four fp32 values
-      char *tr = dst + BFB + ch * CHT + (((2 * cp) >> 4) * 4 + (rr >> 2)) * 256 + ((2 * cp) & 15) * 16 + (rr & 3) * 4;
-      *(float *)(tr) = v0;
-      *(float *)(tr + 16) = v1;
+      if (!OBJ) {
+        char *tr = dst + BFB + ch * CHT + (((2 * cp) >> 4) * 4 + (rr >> 2)) * 256 + ((2 * cp) & 15) * 16 + (rr & 3) * 4;
+        *(float *)(tr) = v0;
+        *(float *)(tr + 16) = v1;
+      }
     }
   };
 
@@ -1193,9 +1199,27 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
 #pragma unroll
           for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bopt[t][tB[tp]][i], p[t], 0, 0, 0);
         }
+        const bool edge = dch + 16 > d1;
+        if (OBJ) {  // residuals: squares of a chunk in fp32 (packed), the chunk's partial into the fp64 sum (see hyb_step_body)
+          float part = 0.0f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            f32x2_t s2 = {0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+              f32x2_t e2 = (f32x2_t){xr[ch & 3][t][r], xr[ch & 3][t][r + 1]} - (f32x2_t){p[t][r], p[t][r + 1]};
+              e2.x = (!edge || dch + 4 * g + r < d1) ? e2.x : 0.0f;
+              e2.y = (!edge || dch + 4 * g + r + 1 < d1) ? e2.y : 0.0f;
+              s2 = __builtin_elementwise_fma(e2, e2, s2);
+            }
+            part += lv[t] ? s2.x + s2.y : 0.0f;
+          }
+          ssum += (double)part;
+          __builtin_amdgcn_sched_barrier(0);
+          continue;
+        }
         // ratios; loop steps beyond the range give zero
         f32x4_t q[NT];
-        const bool edge = dch + 16 > d1;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -1221,6 +1245,19 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
   }
   // acc[t][nb][r] = numerator of signal c = 16 nb + 4g + r at lane element l0 + 16t + c16
 
+  if (OBJ) {  // workgroup sum in wave order (fixed order => reproducible)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ssum += __shfl_down(ssum, o, 64);
+    __syncthreads();
+    if (lane == 0) lds[wave] = ssum;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0;
+      for (int w = 0; w < 8; ++w) t += lds[w];
+      ((double *)(arena + rdp->ossepart))[tile] = t * weight * weight;
+    }
+    return;
+  }
   if (!gp->fused) {
     float *__restrict__ part = (float *)(arena + rdp->opart);
 #pragma unroll
@@ -1419,13 +1456,34 @@ void nmfk_launch_step_wide2_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs
   const size_t chunkb = 3 * (size_t)(2 * nb) * 256 + (size_t)nb * 1024;
   const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + 2 * 4 * chunkb;
   if (nb == 2) {
-    hipLaunchKernelGGL((wide2_step_kernel<2, NT>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0);
+    hipLaunchKernelGGL((wide2_step_kernel<2, NT, false>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
   } else {
     static bool once = false;  // 86 KB of dynamic LDS
     if (!once) {
-      (void)hipFuncSetAttribute((const void *)wide2_step_kernel<4, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void *)wide2_step_kernel<4, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       once = true;
     }
-    hipLaunchKernelGGL((wide2_step_kernel<4, NT>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0);
+    hipLaunchKernelGGL((wide2_step_kernel<4, NT, false>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
+  }
+}
+
+// monitored objective of wide-rank units (scalar weight, no missing data): the kernel above in its objective mode.
+// w: the W half-step's arguments (dw: device copy); hsel: parity of the H buffer that holds the current H
+void nmfk_launch_wide2_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double weight, int hsel, int kp, int u0, int cnt, hipStream_t s) {
+  constexpr int NT = NMFK_HYB_NT;
+  const int lpw = 16 * NT * 8;  // = NMFK_TILE: the partials line up with sse_kernel's
+  const dim3 grid((w.L + lpw - 1) / lpw, cnt), blk(512);
+  const int nb = kp <= 32 ? 2 : 4;
+  const size_t chunkb = 3 * (size_t)(2 * nb) * 256 + (size_t)nb * 1024;
+  const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + 2 * 4 * chunkb;
+  if (nb == 2) {
+    hipLaunchKernelGGL((wide2_step_kernel<2, NT, true>), grid, blk, ldsb, s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
+  } else {
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute((const void *)wide2_step_kernel<4, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      once = true;
+    }
+    hipLaunchKernelGGL((wide2_step_kernel<4, NT, true>), grid, blk, ldsb, s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
   }
 }

@@ -26,7 +26,10 @@
 namespace {
 
 void free_sparse(nmfk_ctx *ctx) {
-  void *ps[] = {ctx->colptr, ctx->rowptr, ctx->rec_csc, ctx->rec_csr};
+  void *ps[] = {ctx->colptr, ctx->rowptr, ctx->rec_csc, ctx->rec_csr, ctx->ell[0], ctx->ell[1], ctx->ellptr[0], ctx->ellptr[1]};
+  ctx->ell[0] = ctx->ell[1] = nullptr;
+  ctx->ellptr[0] = ctx->ellptr[1] = nullptr;
+  ctx->ell_ngb[0] = ctx->ell_ngb[1] = 0;
   for (void *q : ps)
     if (q) (void)hipFree(q);
   ctx->colptr = ctx->rowptr = nullptr;
@@ -104,6 +107,7 @@ struct Sampler {
 //   NMFK_MFMA_SSE, NMFK_HYB_SSE   0: monitored objective of the MFMA groups on the packed-VALU objective kernel
 //   NMFK_STREAMS      concurrent rank-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1 prints the host's share of the loop
 //   NMFK_MERGE_PHASED 1: merged sweeps run their matrix-pipe groups first and the packed-VALU group behind them (default: side by side)
+//   NMFK_SP_BLK       0: sparse X: the W half-step in the gather form (default: column blocks of H staged in LDS)
 //   NMFK_WIDE2        0: ranks > 16 on the all-fp32 MFMA kernel only (default: split-operand first product where it pays)
 //   NMFK_HYB_RES      0: no resident form of the split-operand MFMA half-step (short loop dimension: the loop factor in LDS)
 //   NMFK_HYB_RES_TPW  pairs of lane tiles a wave of the resident form should walk (4)
@@ -111,7 +115,7 @@ struct Sampler {
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, hyb_groups = 1, merge = -1, phases = -1, max_wsplit = 8;
   int wide_sse = 1, hyb_sse = 1, streams = -1, host_timing = 0, merge_phased = 0, hyb_small = 1;
-  int hyb_res = 1, hyb_res_tpw = 4, wide2 = 1;
+  int hyb_res = 1, hyb_res_tpw = 4, wide2 = 1, sp_blk = 1;
 };
 Tuning read_tuning() {
   Tuning t;
@@ -137,6 +141,7 @@ Tuning read_tuning() {
   geti("NMFK_MERGE_PHASED", t.merge_phased);
   geti("NMFK_HYB_SMALL", t.hyb_small);
   geti("NMFK_WIDE2", t.wide2);
+  geti("NMFK_SP_BLK", t.sp_blk);
   geti("NMFK_HYB_RES", t.hyb_res);
   geti("NMFK_HYB_RES_TPW", t.hyb_res_tpw);
   t.hyb_res_tpw = std::max(1, t.hyb_res_tpw);
@@ -278,11 +283,69 @@ NMFK_EXPORT int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, 
   return NMFK_OK;
 }
 
+namespace {
+// Sliced ELL of one orientation (NmfkSparseArgs::ell): L lane elements (ptr / idx / val: their records, sorted by index),
+// D rows of the gathered factor.  Skipped (the gather form serves) when the slots exceed NMFK_ELL_MAX_PAD x the records:
+// a wave walks the longest lane element of its slice, so skewed lane elements would waste its time as well as the memory.
+constexpr double NMFK_ELL_MAX_PAD = 4.0;
+int build_ell(nmfk_ctx *ctx, int o, int64_t L, int64_t D, const std::vector<int32_t> &ptr, const std::vector<int32_t> &idx,
+              const std::vector<float> &val) {
+  const int64_t nsl = (L + 63) / 64, ngb = (D + NMFK_SPB_ROWS - 1) / NMFK_SPB_ROWS, nz = ptr[L];
+  if (nz == 0) return NMFK_OK;
+  std::vector<int32_t> ep((size_t)(nsl * ngb + 1), 0);
+  std::vector<int32_t> cnt((size_t)ngb);
+  int64_t rows = 0;
+  for (int64_t sl = 0; sl < nsl; ++sl) {
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (int64_t l = sl * 64; l < std::min(L, sl * 64 + 64); ++l) {
+      int32_t p = ptr[l];
+      while (p < ptr[l + 1]) {
+        const int64_t b = idx[p] / NMFK_SPB_ROWS;
+        int32_t q = p;
+        while (q < ptr[l + 1] && idx[q] / NMFK_SPB_ROWS == b) ++q;
+        cnt[b] = std::max(cnt[b], q - p);
+        p = q;
+      }
+    }
+    for (int64_t b = 0; b < ngb; ++b) {
+      ep[(size_t)(sl * ngb + b)] = (int32_t)rows;
+      rows += cnt[b];
+      if (rows * 64 > (int64_t)(NMFK_ELL_MAX_PAD * nz) + 64 * 1024 || rows > 0x7ffffff0 / 64) return NMFK_OK;  // (too skewed)
+    }
+  }
+  ep[(size_t)(nsl * ngb)] = (int32_t)rows;
+  const int64_t pad = 8;  // slot rows the kernel's run-ahead loads may read past the last run
+  std::vector<int2> e((size_t)((rows + pad) * 64), int2{-1, 0});
+  for (int64_t sl = 0; sl < nsl; ++sl)
+    for (int64_t l = sl * 64; l < std::min(L, sl * 64 + 64); ++l) {
+      int32_t p = ptr[l];
+      while (p < ptr[l + 1]) {
+        const int64_t b = idx[p] / NMFK_SPB_ROWS;
+        int64_t r = ep[(size_t)(sl * ngb + b)];
+        for (; p < ptr[l + 1] && idx[p] / NMFK_SPB_ROWS == b; ++p, ++r) {
+          int2 &w = e[(size_t)(r * 64 + (l - sl * 64))];
+          w.x = idx[p];
+          memcpy(&w.y, &val[p], 4);
+        }
+      }
+    }
+  HIPCHECK(hipMalloc((void **)&ctx->ell[o], sizeof(int2) * e.size()));
+  HIPCHECK(hipMalloc((void **)&ctx->ellptr[o], sizeof(int32_t) * ep.size()));
+  HIPCHECK(hipMemcpy(ctx->ell[o], e.data(), sizeof(int2) * e.size(), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(ctx->ellptr[o], ep.data(), sizeof(int32_t) * ep.size(), hipMemcpyHostToDevice));
+  ctx->ell_ngb[o] = (int)ngb;
+  ctx->ell_pad[o] = (double)(rows * 64) / (double)nz;
+  return NMFK_OK;
+}
+}  // namespace
+
 NMFK_EXPORT int nmfk_set_X_csc(nmfk_ctx *ctx, int64_t n, int64_t m, int64_t nnz, const int64_t *colptr,
                                const int32_t *rowidx, const float *vals, int64_t *kept) {
   if (!ctx || !colptr || (nnz > 0 && (!rowidx || !vals))) return fail(NMFK_ERR_BAD_ARG, "null argument");
   if (n <= 0 || m <= 0) return fail(NMFK_ERR_BAD_ARG, "Input array has a zero dimension!");
   if (n > 0x7fffff00 || m > 0x7fffff00 || nnz > 0x7fffff00) return fail(NMFK_ERR_UNSUPPORTED, "size exceeds int32 range");
+  // (the sparse kernels index a factor's elements with 32 bits: rows * NMFK_MAX_K < 2^31)
+  if (n > (1 << 24) || m > (1 << 24)) return fail(NMFK_ERR_UNSUPPORTED, "sparse X: dimension exceeds 2^24");
   if (colptr[0] != 0 || colptr[m] != nnz) return fail(NMFK_ERR_BAD_ARG, "bad colptr");
   HIPCHECK(hipSetDevice(ctx->device));
   // host-side: validate, drop entries <= 0 (they are zeros: Mult:17-18 turns them into lambda), build CSR
@@ -346,6 +409,13 @@ NMFK_EXPORT int nmfk_set_X_csc(nmfk_ctx *ctx, int64_t n, int64_t m, int64_t nnz,
       memcpy(&rec[p].y, &vr[p], 4);
     }
     HIPCHECK(hipMemcpy(ctx->rec_csr, rec.data(), sizeof(int2) * nz, hipMemcpyHostToDevice));
+  }
+  // blocked form (sp_blk_kernel): the sliced ELL of the rows (W half-step) and of the columns (H half-step)
+  {
+    const int rc = build_ell(ctx, 0, n, m, rp, ci, vr);
+    if (rc != NMFK_OK) return rc;
+    const int rc2 = build_ell(ctx, 1, m, n, cp, ri, vc);
+    if (rc2 != NMFK_OK) return rc2;
   }
   ctx->sparse = true;
   ctx->nnz = nz;
@@ -730,12 +800,22 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   };
   Geo ghp[2] = {geometry(m, n, 0, 0), geometry(m, n, phased ? 1 : 0, 0)};
   Geo gwp[2] = {geometry(n, m, 0, 1), geometry(n, m, phased ? 1 : 0, 1)};
+  // sparse X, ranks 9..32: blocked form (a lane element per thread, the gathered factor through LDS) when the sliced ELL of
+  // the orientation exists (nmfk_set_X_csc) and the launch fills the GPU (1024 lane elements per workgroup: the H half-step
+  // of a matrix with few columns does not, the gather form serves it)
+  bool sp_blk[2] = {false, false};  // [0]: H half-step, [1]: W half-step
   if (ctx->sparse) {  // gather kernels, always finished in-kernel; the H half-step's slots are per pass (see NmfkSparseArgs)
     int slots_h = 1;
     for (int q = 0; q < nk; ++q) {
       const int sl = nmfk_sp_slot(nmfk_padded_k(ks[q]), 1);
       slots_h = std::max(slots_h, (m + sl - 1) / sl);
     }
+    int64_t blk_units = 0;
+    for (int q = 0; q < nk; ++q) blk_units += nmfk_sp_blk_rank(nmfk_padded_k(ks[q])) ? nruns : 0;
+    const int64_t cus = ctx->prop.multiProcessorCount;
+    const int64_t fill = T.sp_blk >= 2 ? 0 : cus / 2;  // (NMFK_SP_BLK=2: whatever the size -- the tests' small cases)
+    sp_blk[0] = T.sp_blk && ctx->ell[1] && tsz == 4 && blk_units * ((m + NMFK_SPB_ROWS - 1) / NMFK_SPB_ROWS) >= fill;
+    sp_blk[1] = T.sp_blk && ctx->ell[0] && tsz == 4 && blk_units * ((n + NMFK_SPB_ROWS - 1) / NMFK_SPB_ROWS) >= fill;
     ghp[0] = ghp[1] = Geo{1, 1, n, 1, slots_h};
     gwp[0] = gwp[1] = Geo{1, 1, m, 1, (n + NMFK_TILE - 1) / NMFK_TILE};
   }
@@ -826,8 +906,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         // slots the unit's kernels write: the fused half-step one per lane tile, the grid-parallel helpers any count
         const Geo &gh = ghp[phase_of_k(k)], &gw = gwp[phase_of_k(k)];
         rd.nsH = (gh.fused || (use_hyb_k(k) && res_wgs[0] > 0)) ? tiles_of(k, 0, m, gh.wsplit) : PH;
-        if (ctx->sparse) rd.nsH = (m + nmfk_sp_slot(kp, 1) - 1) / nmfk_sp_slot(kp, 1);
+        if (ctx->sparse)  // (a slot per pass of 256 / LPR columns in the gather form, per 1024 columns in the blocked form)
+          rd.nsH = sp_blk[0] && nmfk_sp_blk_rank(kp) ? (m + NMFK_SPB_ROWS - 1) / NMFK_SPB_ROWS : (m + nmfk_sp_slot(kp, 1) - 1) / nmfk_sp_slot(kp, 1);
         rd.nsW = (gw.fused || (use_hyb_k(k) && res_wgs[1] > 0)) ? tiles_of(k, 1, n, gw.wsplit) : PW;
+        if (ctx->sparse)  // (256 rows per slot in the gather form, 1024 in the blocked form)
+          rd.nsW = sp_blk[1] && nmfk_sp_blk_rank(kp) ? (n + NMFK_SPB_ROWS - 1) / NMFK_SPB_ROWS : gw.slots;
         rd.hyb = rd.pad0 = 0;
         if (use_hyb_k(k)) rd.hyb = hyb_variant_of(k);
       }
@@ -1018,8 +1101,16 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   sph.PH = PH;
   sph.force = 0;
   sph.split = 1;
+  sph.ell = sp_blk[0] ? ctx->ell[1] : nullptr;
+  sph.ellptr = ctx->ellptr[1];
+  sph.ngb = ctx->ell_ngb[1];
+  sph.D = n;
   spw = sph;
   spw.split = 0;
+  spw.ell = sp_blk[1] ? ctx->ell[0] : nullptr;
+  spw.ellptr = ctx->ellptr[0];
+  spw.ngb = ctx->ell_ngb[0];
+  spw.D = m;
   spw.ptr = ctx->rowptr;
   spw.rec = ctx->rec_csr;
   spw.L = n;
@@ -1540,6 +1631,10 @@ NMFK_EXPORT int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float
     sp.PW = sp.PH = 1;
     sp.force = 1;
     sp.split = 0;
+    sp.ell = nullptr;
+    sp.ellptr = nullptr;
+    sp.ngb = 0;
+    sp.D = m;
     nmfk_launch_sp_obj_f32(&sp, n, m, 0, 0, 1.0, 0, 1, st);
     nmfk_launch_sum_parts_f32(S, ia.runs, 1, tiles + 1, (double *)(S + oOut), st);
     HIPCHECK(hipGetLastError());

@@ -108,7 +108,26 @@ struct NmfkSparseArgs {
   int32_t L, which, it, PW, PH, force;
   int32_t split;  // half-step: 1 = a workgroup walks ONE pass of its tile (NMFK_TILE / LPR lane elements) and owns a
                   // sum-table slot of that size -- LPR x the workgroups (the H half-step has few lane elements)
+  // blocked form (round 3, sp_blk_kernel): the non-zeros as sliced ELL -- slices of 64 lane elements (one per lane of a
+  // wave) x granules of NMFK_SPB_ROWS rows of the gathered factor; the run of (slice s, granule b) starts at slot row
+  // ellptr[s * ngb + b] and is ellptr[.. + 1] - ellptr[..] slot rows long (the longest lane element of the slice in that
+  // granule); slot row r holds 64 records ell[64 r + lane], .x = -1 where a lane element has fewer.  Null = the gather form.
+  const int2 *ell;
+  const int32_t *ellptr;
+  int32_t ngb;
+  int32_t D;      // the loop dimension (rows of the gathered factor)
 };
+#define NMFK_SPB_ROWS 1024  // blocked form: lane elements per workgroup (one per thread; = its sum-table slot) and rows of the
+                            // gathered factor per granule of the sliced ELL
+#define NMFK_SPB_LDS (160 * 1024)
+// ranks the blocked form serves: from 9 (below that the walk is bound by the record stream, not by the gathers) to 32
+// (1024 rows of the gathered factor in LDS)
+static inline int nmfk_sp_blk_rank(int kp) { return kp > 8 && kp <= 32; }
+// words between the staged rows of 4 * nc signals: + 4 so that 64 lanes reading 16 bytes of 64 different rows spread over
+// the banks, never a multiple of 32
+static inline int nmfk_spb_stride(int nc) { return (4 * nc + 4) % 32 == 0 ? 4 * nc + 8 : 4 * nc + 4; }
+// granules of the gathered factor staged at a time
+static inline int nmfk_spb_gps(int nc) { return NMFK_SPB_LDS / (nmfk_spb_stride(nc) * 4) / NMFK_SPB_ROWS; }
 // lanes per lane element of the sparse kernels (four signals each) and lane elements per sum-table slot
 static inline int nmfk_sp_lpr(int kp) { return kp <= 4 ? 1 : kp <= 8 ? 2 : kp <= 16 ? 4 : kp <= 32 ? 8 : 16; }
 static inline int nmfk_sp_slot(int kp, int split) { return split ? 256 / nmfk_sp_lpr(kp) : 256; }

@@ -69,6 +69,12 @@ struct nmfk_ctx {
   int64_t nnz = 0;
   // the non-zeros are (index, value) records of 8 bytes, so that a walk costs one load per non-zero
   int32_t *colptr = nullptr, *rowptr = nullptr;
+  // blocked form of the sparse half-steps: sliced ELL of the rows ([0]: W half-step) and of the columns ([1]: H half-step),
+  // see NmfkSparseArgs::ell; null when the padding would exceed NMFK_ELL_MAX_PAD x the non-zeros (skewed lane elements)
+  int2 *ell[2] = {nullptr, nullptr};
+  int32_t *ellptr[2] = {nullptr, nullptr};
+  int32_t ell_ngb[2] = {0, 0};
+  double ell_pad[2] = {0, 0};  // slots / non-zeros
   int2 *rec_csc = nullptr, *rec_csr = nullptr;
   int64_t nan_count = 0, zero_count = 0;
   double lambda = 1e-32;

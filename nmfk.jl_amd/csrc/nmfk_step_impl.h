@@ -997,45 +997,97 @@ __device__ __forceinline__ T sp_group_sum(T s) {
   return s;
 }
 
+// ... of N independent values, level by level: a DPP operand needs two wait states behind the VALU write of its
+// source, which the other values' additions fill (one value at a time leaves an s_nop behind every addition)
+template <int LPR, int N>
+__device__ __forceinline__ void sp_group_sum_n(T (&s)[N]) {
+#pragma unroll
+  for (int t = 0; t < N; ++t)
+    if (LPR >= 2) s[t] += sp_dpp<0xB1>(s[t]);
+#pragma unroll
+  for (int t = 0; t < N; ++t)
+    if (LPR >= 4) s[t] += sp_dpp<0x4E>(s[t]);
+#pragma unroll
+  for (int t = 0; t < N; ++t)
+    if (LPR >= 8) s[t] += sp_dpp<0x141>(s[t]);
+#pragma unroll
+  for (int t = 0; t < N; ++t)
+    if (LPR >= 16) s[t] += sp_dpp<0x140>(s[t]);
+}
+
 // the lanes' view of the factor rows and the walk over a lane element's non-zeros, shared by the half-step and the
-// objective.  f(t, live, x, p, b): record t of the chunk, `live` false past the end of the range (x = 0 then),
-// p = <a, b_d> (the same bits in every lane of the group), b = this lane's four signals of the gathered row.
+// objective.  f(t, live, x, p, b): record t of the chunk, `live` false past the end of the range (x and p are then
+// those of some other record: the caller drops them), p = <a, b_d> (the same bits in every lane of the group),
+// b = this lane's four signals of the gathered row.
+// The walk is bound by VALU issue (round 3: 31 instructions per record slot, 7 of them selects), so the inner loop carries
+// nothing it does not need:
+//  * a lane's four signals start at sig0 = min(4 sub, kp - 4): the last lane of a ragged row (kp not a multiple of 4)
+//    re-reads signals of its neighbour instead of reading into the next row, and `own` says which of its four are its
+//    own -- a is zero elsewhere, so the dot product needs no mask on the gathered values and nothing outside a row is read
+//    (LPR = 1 with kp < 4 is the exception: one lane, rows shorter than its load; the values are masked there);
+//  * the row offset d * kp is computed once per fetched record, before the records are handed round;
+//  * records past the end of a range are clamped to the array, so their row index is valid without a select.
 template <int LPR>
 struct SpWalk {
   static constexpr int RL = LPR >= 4 ? 1 : 4 / LPR;  // records a lane fetches per block
   static constexpr int NB = LPR * RL;                // records per block of a group (4, 4, 4, 8, 16)
   static constexpr int CH = NB < 8 ? NB : 8;         // gathers in flight per lane
-  int kp, sub, sofs;
-  bool on, ragged, cm[4];
+  int kp, sub, sig0;
+  bool on, full, ragged, own[4];
   __device__ __forceinline__ void init(int kp_, int tid) {
     kp = kp_;
     sub = tid % LPR;
-    on = 4 * sub < kp;  // this lane holds signals of the factor rows
+    const int first = 4 * sub;
+    on = first < kp;  // this lane holds signals of the factor rows
+    sig0 = (LPR == 1 || !on) ? 0 : min(first, kp - 4);  // (lanes beyond the row re-read its first signals: no traffic)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) cm[e] = 4 * sub + e < kp;  // ... and which of its four exist
-    ragged = (kp & 3) != 0;  // (wave-uniform) rows end inside a lane's four signals: the tail lane reads into the next row
-    sofs = on ? 4 * sub : 0;  // lanes beyond the row re-read its first signals (same address: no traffic)
+    for (int e = 0; e < 4; ++e) own[e] = on && sig0 + e >= first && sig0 + e < kp;
+    full = own[0] && own[3];
+    ragged = LPR == 1 && kp < 4;  // (wave-uniform)
   }
   // Nothing may USE a gathered value between the loads of a chunk: a select or a branch right behind a load makes
-  // the compiler wait for vmcnt(0) on the spot and the gathers run one after the other.  Masking happens in keep().
-  __device__ __forceinline__ sp_vec4 row4(const T *__restrict__ F, int r) const {
-    return *(const sp_vec4u *)(F + (int64_t)r * kp + sofs);
+  // the compiler wait for vmcnt(0) on the spot and the gathers run one after the other.
+  // ofs = row * kp (elements; the sparse path keeps a factor below 2^31 elements -- checked on the host)
+  __device__ __forceinline__ sp_vec4 row4(const T *__restrict__ F, int ofs) const {
+    return *(const sp_vec4u *)(F + (uint32_t)(ofs + sig0));
   }
   __device__ __forceinline__ sp_vec4 keep(sp_vec4 v) const {
-    if (ragged) {
+    if (LPR == 1 && ragged) {
 #pragma unroll
-      for (int e = 1; e < 4; ++e) v[e] = cm[e] ? v[e] : (T)0;
+      for (int e = 1; e < 4; ++e) v[e] = own[e] ? v[e] : (T)0;
     }
     return v;
   }
-  __device__ __forceinline__ sp_vec4 lane_row(const T *__restrict__ F, int r) const {
-    sp_vec4 a = keep(row4(F, r));
-    if (!on) a = (sp_vec4)((T)0);
+  __device__ __forceinline__ sp_vec4 mask_own(sp_vec4 a) const {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = own[e] ? a[e] : (T)0;
     return a;
+  }
+  __device__ __forceinline__ sp_vec4 lane_row(const T *__restrict__ F, int r) const { return mask_own(row4(F, r * kp)); }
+  // <a, b> over this lane's four signals, as two packed operations and an add
+  __device__ __forceinline__ T dot4(const sp_vec4 &a, const sp_vec4 &b) const {
+    T2 t = T2{a[0], a[1]} * T2{b[0], b[1]};
+    t = fma2(T2{a[2], a[3]}, T2{b[2], b[3]}, t);
+    return t.x + t.y;
+  }
+  // acc += q * b
+  __device__ __forceinline__ void axpy4(sp_vec4 &acc, T q, const sp_vec4 &b) const {
+    const T2 lo = fma2(splat2(q), T2{b[0], b[1]}, T2{acc[0], acc[1]}), hi = fma2(splat2(q), T2{b[2], b[3]}, T2{acc[2], acc[3]});
+    acc = sp_vec4{lo.x, lo.y, hi.x, hi.y};
   }
   template <class Fn>
   __device__ __forceinline__ void walk(const NmfkSparseArgs &g, const T *__restrict__ B, const sp_vec4 a, int p0, int p1,
                                        Fn &&f) const {
+    const T *__restrict__ Bs = B + sig0;
+    walk_rows<CH>(g, kp, 0, [&](int ofs) __attribute__((always_inline)) { return *(const sp_vec4u *)(Bs + (uint32_t)ofs); }, a, p0, p1, f);
+  }
+  // rowfn(ofs): this lane's four signals of the gathered factor's row d, ofs = (d - d0) * mul (global memory above; the
+  // staged block in LDS for the blocked W half-step)
+  // CHW: gathers in flight per lane (8 from global memory; LDS answers in ~100 cycles, 4 are plenty and leave registers)
+  template <int CHW, class RowFn, class Fn>
+  __device__ __forceinline__ void walk_rows(const NmfkSparseArgs &g, int mul, int d0, RowFn &&rowfn, const sp_vec4 a, int p0,
+                                            int p1, Fn &&f) const {
+    constexpr int CH = NB < CHW ? NB : CHW;
     // a block's records: lane `sub` of the group fetches RL consecutive ones (clamped to the array), one block ahead
     int2 rec[RL], nxt[RL];
 #pragma unroll
@@ -1044,6 +1096,7 @@ struct SpWalk {
 #pragma unroll
       for (int j = 0; j < RL; ++j) {
         rec[j] = nxt[j];
+        rec[j].x = (rec[j].x - d0) * mul;
         nxt[j] = g.rec[min(pp + NB + sub * RL + j, g.nrec - 1)];
       }
 #pragma unroll
@@ -1053,23 +1106,23 @@ struct SpWalk {
 #pragma unroll
         for (int t = 0; t < CH; ++t) {  // all gathers of the chunk first: they overlap
           const int ti = c0 + t;
-          int d = rec[ti % RL].x, xb = rec[ti % RL].y;
+          int ofs = rec[ti % RL].x, xb = rec[ti % RL].y;
           if (LPR > 1) {
-            d = __shfl(d, ti / RL, LPR);
+            ofs = __shfl(ofs, ti / RL, LPR);
             xb = __shfl(xb, ti / RL, LPR);
           }
-          const bool live = pp + ti < p1;  // (records past the lane element's range: x = 0)
-          x[t] = live ? (T)__builtin_bit_cast(float, xb) : (T)0;
-          b[t] = row4(B, live ? d : 0);
+          x[t] = (T)__builtin_bit_cast(float, xb);
+          b[t] = rowfn(ofs);
         }
+        T pr[CH];
 #pragma unroll
         for (int t = 0; t < CH; ++t) {
           b[t] = keep(b[t]);
-          T s = a[0] * b[t][0];
-#pragma unroll
-          for (int e = 1; e < 4; ++e) s = fma_t(a[e], b[t][e], s);
-          f(t, pp + c0 + t < p1, x[t], sp_group_sum<LPR>(s), b[t]);
+          pr[t] = dot4(a, b[t]);
         }
+        sp_group_sum_n<LPR, CH>(pr);
+#pragma unroll
+        for (int t = 0; t < CH; ++t) f(t, pp + c0 + t < p1, x[t], pr[t], b[t]);
       }
     }
   }
@@ -1131,7 +1184,6 @@ __global__ __launch_bounds__(NMFK_TILE) void sp_step_kernel(NmfkSparseArgs g, in
 
   SpWalk<LPR> w;
   w.init(kp, tid);
-  const int sub = w.sub;
   double vs[4] = {0, 0, 0, 0};  // this lane's share of the sums of the new factor's signals 4 sub .. 4 sub + 3
 #pragma unroll 1
   for (int pass = pz * ppw; pass < (pz + 1) * ppw; ++pass) {
@@ -1142,27 +1194,25 @@ __global__ __launch_bounds__(NMFK_TILE) void sp_step_kernel(NmfkSparseArgs g, in
     sp_vec4 acc = (sp_vec4)((T)0);
     const int p0 = valid ? g.ptr[lc] : 0, p1 = valid ? g.ptr[lc + 1] : 0;
     w.walk(g, B, a, p0, p1, [&](int, bool live, T x, T pr, const sp_vec4 &b) __attribute__((always_inline)) {
-      const T q = live ? div_t(x, pr) : (T)0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = fma_t(b[e], q, acc[e]);
+      w.axpy4(acc, live ? div_t(x, pr) : (T)0, b);
     });
     // fused finish of the pass (Mult:67 / Mult:70 order)
     if (w.on) {
       sp_vec4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int c = 4 * sub + e;
-        v[e] = (c < k && valid) ? a[e] * acc[e] / (T)den[c < kp ? c : 0] : (T)0;
+        const int c = w.sig0 + e;
+        v[e] = (w.own[e] && c < k && valid) ? a[e] * acc[e] / (T)den[c < kp ? c : 0] : (T)0;
         vs[e] += (double)v[e];
       }
       if (valid) {
-        T *dst = Anew + (int64_t)lc * kp + 4 * sub;
-        if (w.cm[3]) {
+        T *dst = Anew + (int64_t)lc * kp + w.sig0;
+        if (w.full) {
           *(sp_vec4u *)dst = v;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (w.cm[e]) dst[e] = v[e];
+            if (w.own[e]) dst[e] = v[e];
         }
       }
     }
@@ -1174,7 +1224,7 @@ __global__ __launch_bounds__(NMFK_TILE) void sp_step_kernel(NmfkSparseArgs g, in
     double v = vs[e];
 #pragma unroll
     for (int o = 32; o >= LPR; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane < LPR) red[wave * 4 * LPR + 4 * sub + e] = v;
+    if (lane < LPR && w.own[e]) red[wave * 4 * LPR + w.sig0 + e] = v;
   }
   __syncthreads();
   if (tid < kp && slot < (g.which == 0 ? g.PH : g.PW)) {
@@ -1182,6 +1232,200 @@ __global__ __launch_bounds__(NMFK_TILE) void sp_step_kernel(NmfkSparseArgs g, in
     sumA[tid] = (red[tid] + red[4 * LPR + tid]) + (red[2 * 4 * LPR + tid] + red[3 * 4 * LPR + tid]);
   }
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Blocked form of the sparse half-steps (round 3), ranks 9..32.  The gather form above fetches one row of
+// the other factor (kp * 4 B) per non-zero through L2 -> L1 -- 105 GB per iteration of BASELINE configs[3], 3.5 x the
+// algorithmic bytes -- and spends a group of LPR lanes and ~22 instructions on every non-zero.  Here a workgroup of 1024
+// threads owns 1024 lane elements, ONE PER LANE with all its signals in registers (the row of its own factor and the
+// numerators), stages the gathered factor through LDS a block of granules at a time (1024 rows of 32 signals fit) and
+// serves the non-zeros of its lane elements in that block from LDS: a wave instruction now works on 64 non-zeros instead of
+// 8, and a staged row is used ~5 times (0.5 % fill x 1024 lane elements) instead of being fetched ~5 times.
+// The non-zeros come as sliced ELL (NmfkSparseArgs::ell): slot row t of a (slice, granule) run is one coalesced 512-byte
+// load per wave, addressed without looking at the data, so the loads run ahead of the arithmetic; lanes whose lane element
+// has run out sit the step out (execution mask), they cost no LDS traffic.
+// A first blocked form kept the gather form's lane groups and CSR order (a group per row, column blocks of H in LDS): it
+// was 30 % SLOWER than the gather form -- a row has ~5 non-zeros per block, so most of a group's 8..16 record slots per
+// block were empty and the instruction count per non-zero went up, not down (profiles/r03/sparse_blocked.txt).
+// ------------------------------------------------------------------------------------------------------
+#ifdef NMFK_IS_F32
+template <int NC>
+__device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkRun &rd, char *lds) {
+  constexpr int KQ = 4 * NC;                   // signals a lane holds (kp rounded up to 4)
+  constexpr int STR = (KQ + 4) % 32 == 0 ? KQ + 8 : KQ + 4;  // = nmfk_spb_stride(NC)
+  constexpr int GPS = NMFK_SPB_LDS / (STR * 4) / NMFK_SPB_ROWS;  // = nmfk_spb_gps(NC)
+  constexpr int P = NC > 4 ? 2 : 4;            // slot rows loaded ahead
+  constexpr int RSTEP = 1024 / KQ;             // rows staged per sweep of the workgroup (padded rows)
+  const int kp = rd.kp, k = rd.k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
+  const T *__restrict__ Hcur = NMFK_PTR(const T, g, NMFK_HOFF(rd, g.it));
+  T *__restrict__ Hnew = NMFK_PTR(T, g, NMFK_HOFF(rd, g.it + 1));
+  T *__restrict__ Wt = NMFK_PTR(T, g, rd.oWt);
+  const T *__restrict__ A = g.which == 0 ? Hcur : Wt;
+  const T *__restrict__ B = g.which == 0 ? Wt : Hnew;
+  T *__restrict__ Anew = g.which == 0 ? Hnew : Wt;
+  T *hb = (T *)lds;
+  const int l = tile * NMFK_SPB_ROWS + tid;
+  const bool valid = l < g.L;
+  const bool vec = (kp & 3) == 0;  // (wave-uniform) rows are 16-byte multiples
+  sp_vec4 a[NC], acc[NC];
+  {
+    const T *ar = A + (int64_t)(valid ? l : 0) * kp;
+    if (vec) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) a[c] = *(const sp_vec4u *)(ar + 4 * c);
+    } else {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[c][e] = 4 * c + e < kp ? ar[4 * c + e] : (T)0;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = (sp_vec4)((T)0);
+  }
+  const int ngb = g.ngb;
+  const int slice = __builtin_amdgcn_readfirstlane(tile * 16 + wave);
+  const bool has = slice < (g.L + 63) / 64;  // (the last workgroup's waves past the lane elements have no runs)
+  const int32_t *__restrict__ ep = g.ellptr + (int64_t)(has ? slice : 0) * ngb;
+  for (int gb0 = 0; gb0 < ngb; gb0 += GPS) {
+    const int c0 = gb0 * NMFK_SPB_ROWS, rows = min(GPS * NMFK_SPB_ROWS, g.D - c0);
+    __syncthreads();  // (everybody is done with the previous block)
+    if (vec) {
+      const sp_vec4u *src = (const sp_vec4u *)(B + (int64_t)c0 * kp);
+      for (int e = tid; e < rows * NC; e += 1024) {
+        const int r = e / NC, c = e - r * NC;
+        *(sp_vec4 *)(hb + r * STR + 4 * c) = src[e];
+      }
+    } else {  // pad the rows to KQ values with zeros
+      const int c = tid % KQ;
+      if (tid < RSTEP * KQ)
+        for (int r = tid / KQ; r < rows; r += RSTEP) hb[r * STR + c] = c < kp ? B[(int64_t)(c0 + r) * kp + c] : (T)0;
+    }
+    __syncthreads();
+    const int gb1 = min(gb0 + GPS, ngb);
+    for (int gb = gb0; gb < gb1; ++gb) {
+      const int base = ep[gb], len = has ? ep[gb + 1] - base : 0;  // (wave-uniform)
+      if (len <= 0) continue;
+      const int2 *__restrict__ e = g.ell + (int64_t)base * 64 + lane;
+      int2 r[P];
+#pragma unroll
+      for (int j = 0; j < P; ++j) r[j] = e[j * 64];  // (past the run: the next run's records or the array's padding)
+      for (int t = 0; t < len; t += P) {
+        int2 cur[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          cur[j] = r[j];
+          r[j] = e[(t + P + j) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          if (t + j < len && cur[j].x >= 0) {  // (the first test is wave-uniform; the second masks lanes out)
+            const T *hr = hb + (cur[j].x - c0) * STR;
+            const T x = __builtin_bit_cast(float, cur[j].y);
+            sp_vec4 h[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) h[c] = *(const sp_vec4 *)(hr + 4 * c);
+            T2 s0 = T2{a[0][0], a[0][1]} * T2{h[0][0], h[0][1]}, s1 = T2{a[0][2], a[0][3]} * T2{h[0][2], h[0][3]};
+#pragma unroll
+            for (int c = 1; c < NC; ++c) {
+              s0 = fma2(T2{a[c][0], a[c][1]}, T2{h[c][0], h[c][1]}, s0);
+              s1 = fma2(T2{a[c][2], a[c][3]}, T2{h[c][2], h[c][3]}, s1);
+            }
+            const T q = div_t(x, (s0.x + s0.y) + (s1.x + s1.y));
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              const T2 lo = fma2(splat2(q), T2{h[c][0], h[c][1]}, T2{acc[c][0], acc[c][1]});
+              const T2 hi = fma2(splat2(q), T2{h[c][2], h[c][3]}, T2{acc[c][2], acc[c][3]});
+              acc[c] = sp_vec4{lo.x, lo.y, hi.x, hi.y};
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();  // the staged block is dead: its LDS serves the denominators, then the sums of the new values
+  // denominators: the other factor's sum table, thread (j, c) adds the slots j, j + 32, ... of signal c, then the 32 partial
+  // sums are added in order (a fixed order: reproducible)
+  double *red = (double *)lds, *den = red + 1024;
+  {
+    const double *sumB = NMFK_PTR(const double, g, g.which == 0 ? rd.osumW : rd.osumH);
+    const int PB = g.which == 0 ? rd.nsW : rd.nsH;
+    const int c = tid & 31, j = tid >> 5;
+    double sd = 0;
+    if (c < kp)
+      for (int q = j; q < PB; q += 32) sd += sumB[q * kp + c];
+    red[tid] = sd;
+    __syncthreads();
+    if (tid < kp) {
+      sd = 0;
+      for (int jj = 0; jj < 32; ++jj) sd += red[jj * 32 + tid];
+      den[tid] = sd;
+    }
+    __syncthreads();
+  }
+  // fused finish (Mult:67 / Mult:70 order)
+  sp_vec4 v[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int sig = 4 * c + e;
+      v[c][e] = (valid && sig < k) ? a[c][e] * acc[c][e] / (T)den[sig < kp ? sig : 0] : (T)0;
+    }
+  if (valid) {
+    T *dst = Anew + (int64_t)l * kp;
+    if (vec) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) *(sp_vec4u *)(dst + 4 * c) = v[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * c + e < kp) dst[4 * c + e] = v[c][e];
+    }
+  }
+  // sums of the new values over the workgroup's lane elements -> slot `tile`: through LDS ([1024][KQ + 1] values behind
+  // den), thread (j, c) adds the lane elements 32 j .. 32 j + 31 of signal c in fp64, then the 32 partial sums in order
+  __syncthreads();  // (den has been read)
+  T *vt = (T *)(lds + 1024 * sizeof(double));
+  double *red2 = (double *)lds;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vt[tid * (KQ + 1) + 4 * c + e] = v[c][e];
+  __syncthreads();
+  {
+    const int c = tid & 31, j = tid >> 5;
+    double sd = 0;
+    if (c < kp)
+      for (int r = 0; r < 32; ++r) sd += (double)vt[(32 * j + r) * (KQ + 1) + c];
+    red2[tid] = sd;
+    __syncthreads();
+    if (tid < kp && tile < (g.which == 0 ? g.PH : g.PW)) {
+      sd = 0;
+      for (int jj = 0; jj < 32; ++jj) sd += red2[jj * 32 + tid];
+      NMFK_PTR(double, g, g.which == 0 ? rd.osumH : rd.osumW)[(int64_t)tile * kp + tid] = sd;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void sp_blk_kernel(NmfkSparseArgs g, int u0) {
+  extern __shared__ char spb_lds[];
+  const int u = u0 + blockIdx.y;
+  if (!g.force && !g.state[u].active) return;
+  const NmfkRun rd = g.runs[u];
+  switch ((rd.kp + 3) >> 2) {  // (a launch holds the units of one lane-group class: ranks 9..16 or 17..32)
+    case 3: sp_blk_body<3>(g, rd, spb_lds); break;
+    case 4: sp_blk_body<4>(g, rd, spb_lds); break;
+    case 5: sp_blk_body<5>(g, rd, spb_lds); break;
+    case 6: sp_blk_body<6>(g, rd, spb_lds); break;
+    case 7: sp_blk_body<7>(g, rd, spb_lds); break;
+    case 8: sp_blk_body<8>(g, rd, spb_lds); break;
+    default: break;
+  }
+}
+#endif
 
 // objective on sparse X:  sum_all (x - p)^2 = sum_nz [(x - p)^2 - p^2] + sum_all p^2,  sum_all p^2 = <W'W, HH'>.
 // part 1: the non-zero terms, the same walk over the rows (CSR) as the W half-step, fp64 accumulation, one partial per
@@ -1774,6 +2018,17 @@ void nmfk_launch_step_mfma_wide_f32(const NmfkStepArgs &a, const NmfkStepArgs *d
 
 void NMFK_NAME(nmfk_launch_sp_step)(const void *argsv, int kp, int u0, int cnt, hipStream_t s) {
   const NmfkSparseArgs &a = *(const NmfkSparseArgs *)argsv;
+#ifdef NMFK_IS_F32
+  if (a.ell && nmfk_sp_blk_rank(kp)) {  // blocked form: a lane element per thread, the gathered factor through LDS
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute((const void *)sp_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMFK_SPB_LDS);
+      once = true;
+    }
+    hipLaunchKernelGGL(sp_blk_kernel, dim3((a.L + NMFK_SPB_ROWS - 1) / NMFK_SPB_ROWS, cnt), dim3(1024), NMFK_SPB_LDS, s, a, u0);
+    return;
+  }
+#endif
   // lanes per lane element: four signals each; split: a workgroup per pass
   const dim3 grid(((a.L + NMFK_TILE - 1) / NMFK_TILE) * (a.split ? nmfk_sp_lpr(kp) : 1), a.split ? (cnt + 7) / 8 * 8 : cnt);
   const dim3 blk(NMFK_TILE);

@@ -122,7 +122,7 @@ struct NmfkSparseArgs {
 #define NMFK_SPB_LDS (160 * 1024)
 // ranks the blocked form serves: from 9 (below that the walk is bound by the record stream, not by the gathers) to 32
 // (1024 rows of the gathered factor in LDS)
-static inline int nmfk_sp_blk_rank(int kp) { return kp > 8 && kp <= 32; }
+__host__ __device__ static inline int nmfk_sp_blk_rank(int kp) { return kp > 8 && kp <= 32; }
 // words between the staged rows of 4 * nc signals: + 4 so that 64 lanes reading 16 bytes of 64 different rows spread over
 // the banks, never a multiple of 32
 static inline int nmfk_spb_stride(int nc) { return (4 * nc + 4) % 32 == 0 ? 4 * nc + 8 : 4 * nc + 4; }

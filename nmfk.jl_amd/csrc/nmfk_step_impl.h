@@ -1249,22 +1249,26 @@ __global__ __launch_bounds__(NMFK_TILE) void sp_step_kernel(NmfkSparseArgs g, in
 // block were empty and the instruction count per non-zero went up, not down (profiles/r03/sparse_blocked.txt).
 // ------------------------------------------------------------------------------------------------------
 #ifdef NMFK_IS_F32
-template <int NC>
-__device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkRun &rd, char *lds) {
+// OBJ: the non-zero terms of the objective (see sp_obj_kernel) instead of a half-step: rows of W as lane elements, Hobj the
+// H to measure, the workgroup's partial in ossepart[1 + 4 tile] (the entries of the three other 256-row tiles are zeroed)
+template <int NC, bool OBJ>
+__device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkRun &rd, const int tile, char *lds,
+                                            const T *__restrict__ Hobj, double weight) {
   constexpr int KQ = 4 * NC;                   // signals a lane holds (kp rounded up to 4)
   constexpr int STR = (KQ + 4) % 32 == 0 ? KQ + 8 : KQ + 4;  // = nmfk_spb_stride(NC)
   constexpr int GPS = NMFK_SPB_LDS / (STR * 4) / NMFK_SPB_ROWS;  // = nmfk_spb_gps(NC)
   constexpr int P = NC > 4 ? 2 : 4;            // slot rows loaded ahead
   constexpr int RSTEP = 1024 / KQ;             // rows staged per sweep of the workgroup (padded rows)
   const int kp = rd.kp, k = rd.k;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T *__restrict__ Hcur = NMFK_PTR(const T, g, NMFK_HOFF(rd, g.it));
   T *__restrict__ Hnew = NMFK_PTR(T, g, NMFK_HOFF(rd, g.it + 1));
   T *__restrict__ Wt = NMFK_PTR(T, g, rd.oWt);
-  const T *__restrict__ A = g.which == 0 ? Hcur : Wt;
-  const T *__restrict__ B = g.which == 0 ? Wt : Hnew;
+  const T *__restrict__ A = OBJ ? Wt : g.which == 0 ? Hcur : Wt;
+  const T *__restrict__ B = OBJ ? Hobj : g.which == 0 ? Wt : Hnew;
   T *__restrict__ Anew = g.which == 0 ? Hnew : Wt;
   T *hb = (T *)lds;
+  double sobj = 0;
   const int l = tile * NMFK_SPB_ROWS + tid;
   const bool valid = l < g.L;
   const bool vec = (kp & 3) == 0;  // (wave-uniform) rows are 16-byte multiples
@@ -1331,12 +1335,18 @@ __device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkR
               s0 = fma2(T2{a[c][0], a[c][1]}, T2{h[c][0], h[c][1]}, s0);
               s1 = fma2(T2{a[c][2], a[c][3]}, T2{h[c][2], h[c][3]}, s1);
             }
-            const T q = div_t(x, (s0.x + s0.y) + (s1.x + s1.y));
+            const T pr = (s0.x + s0.y) + (s1.x + s1.y);
+            if (OBJ) {
+              const double xd = (double)x, p = (double)pr;
+              sobj += (xd - p) * (xd - p) - p * p;
+            } else {
+              const T q = div_t(x, pr);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-              const T2 lo = fma2(splat2(q), T2{h[c][0], h[c][1]}, T2{acc[c][0], acc[c][1]});
-              const T2 hi = fma2(splat2(q), T2{h[c][2], h[c][3]}, T2{acc[c][2], acc[c][3]});
-              acc[c] = sp_vec4{lo.x, lo.y, hi.x, hi.y};
+              for (int c = 0; c < NC; ++c) {
+                const T2 lo = fma2(splat2(q), T2{h[c][0], h[c][1]}, T2{acc[c][0], acc[c][1]});
+                const T2 hi = fma2(splat2(q), T2{h[c][2], h[c][3]}, T2{acc[c][2], acc[c][3]});
+                acc[c] = sp_vec4{lo.x, lo.y, hi.x, hi.y};
+              }
             }
           }
         }
@@ -1344,6 +1354,22 @@ __device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkR
     }
   }
   __syncthreads();  // the staged block is dead: its LDS serves the denominators, then the sums of the new values
+  if (OBJ) {  // lanes of a wave in a butterfly (the same bits in every lane), then the 16 waves in order
+    double *wsum = (double *)lds;
+    sobj *= weight * weight;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sobj += __shfl_xor(sobj, o, 64);
+    if (lane == 0) wsum[wave] = sobj;
+    __syncthreads();
+    if (tid < 4) {
+      double t = 0;
+      if (tid == 0)
+        for (int wv = 0; wv < 16; ++wv) t += wsum[wv];
+      const int slot = 4 * tile + tid;
+      if (slot < (g.L + NMFK_TILE - 1) / NMFK_TILE) NMFK_PTR(double, g, rd.ossepart)[1 + slot] = t;
+    }
+    return;
+  }
   // denominators: the other factor's sum table, thread (j, c) adds the slots j, j + 32, ... of signal c, then the 32 partial
   // sums are added in order (a fixed order: reproducible)
   double *red = (double *)lds, *den = red + 1024;
@@ -1410,18 +1436,60 @@ __device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkR
   }
 }
 
-__global__ __launch_bounds__(1024) void sp_blk_kernel(NmfkSparseArgs g, int u0) {
+// Which (tile, unit) a workgroup serves.  A workgroup streams its tile's share of the sliced ELL and the whole gathered
+// factor of its unit; workgroups go round-robin over the 8 XCDs in linear-id order, so linear id -> (xcd, slot) and the
+// slots of an XCD run through the tiles of one unit, then its next unit: a unit's gathered factor is fetched into ONE L2
+// (0.5 MB of H stays there across the W half-step's tiles; the H half-step's tiles stream the 12.8 MB of W side by side).
+// (Letting U units share a tile's records side by side instead -- U = 2, 4, 8 -- changed nothing: profiles/r03.)
+__device__ __forceinline__ bool sp_blk_where(const NmfkSparseArgs &g, int cnt, int &tile, int &unit) {
+  const int nt = (g.L + NMFK_SPB_ROWS - 1) / NMFK_SPB_ROWS;
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  tile = slot % nt;
+  unit = (slot / nt) * 8 + xcd;
+  return unit < cnt;
+}
+// workgroups of a launch over cnt units
+static int sp_blk_grid(const NmfkSparseArgs &a, int cnt) {
+  return (a.L + NMFK_SPB_ROWS - 1) / NMFK_SPB_ROWS * ((cnt + 7) / 8 * 8);
+}
+
+__global__ __launch_bounds__(1024) void sp_blk_kernel(NmfkSparseArgs g, int u0, int cnt) {
   extern __shared__ char spb_lds[];
-  const int u = u0 + blockIdx.y;
+  int tile, ul;
+  if (!sp_blk_where(g, cnt, tile, ul)) return;
+  const int u = u0 + ul;
   if (!g.force && !g.state[u].active) return;
   const NmfkRun rd = g.runs[u];
   switch ((rd.kp + 3) >> 2) {  // (a launch holds the units of one lane-group class: ranks 9..16 or 17..32)
-    case 3: sp_blk_body<3>(g, rd, spb_lds); break;
-    case 4: sp_blk_body<4>(g, rd, spb_lds); break;
-    case 5: sp_blk_body<5>(g, rd, spb_lds); break;
-    case 6: sp_blk_body<6>(g, rd, spb_lds); break;
-    case 7: sp_blk_body<7>(g, rd, spb_lds); break;
-    case 8: sp_blk_body<8>(g, rd, spb_lds); break;
+    case 3: sp_blk_body<3, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    case 4: sp_blk_body<4, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    case 5: sp_blk_body<5, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    case 6: sp_blk_body<6, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    case 7: sp_blk_body<7, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    case 8: sp_blk_body<8, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    default: break;
+  }
+}
+// the objective's non-zero terms of the units of ranks 9..32 (the others leave at once: sp_obj_kernel serves them)
+__global__ __launch_bounds__(1024) void sp_blk_obj_kernel(NmfkSparseArgs g, int hsel, int total_iters, double weight, int u0,
+                                                          int cnt) {
+  extern __shared__ char spb_lds[];
+  int tile, ul;
+  if (!sp_blk_where(g, cnt, tile, ul)) return;
+  const int u = u0 + ul;
+  const NmfkState st = g.state[u];
+  if (!g.force && !st.active) return;
+  const NmfkRun rd = g.runs[u];
+  if (!nmfk_sp_blk_rank(rd.kp)) return;
+  const int sel = hsel >= 0 ? hsel : ((st.active ? total_iters : st.iters) & 1);
+  const T *H = NMFK_PTR(const T, g, NMFK_HOFF(rd, sel));
+  switch ((rd.kp + 3) >> 2) {
+    case 3: sp_blk_body<3, true>(g, rd, tile, spb_lds, H, weight); break;
+    case 4: sp_blk_body<4, true>(g, rd, tile, spb_lds, H, weight); break;
+    case 5: sp_blk_body<5, true>(g, rd, tile, spb_lds, H, weight); break;
+    case 6: sp_blk_body<6, true>(g, rd, tile, spb_lds, H, weight); break;
+    case 7: sp_blk_body<7, true>(g, rd, tile, spb_lds, H, weight); break;
+    case 8: sp_blk_body<8, true>(g, rd, tile, spb_lds, H, weight); break;
     default: break;
   }
 }
@@ -1461,6 +1529,9 @@ __global__ __launch_bounds__(NMFK_TILE) void sp_obj_kernel(NmfkSparseArgs g, int
   const NmfkState st = g.state[u];
   if (!g.force && !st.active) return;
   const NmfkRun rd = g.runs[u];
+#ifdef NMFK_IS_F32
+  if (g.ell && nmfk_sp_blk_rank(rd.kp)) return;  // (sp_blk_obj_kernel serves it)
+#endif
   const int sel = hsel >= 0 ? hsel : ((st.active ? total_iters : st.iters) & 1);
   const T *H = NMFK_PTR(const T, g, NMFK_HOFF(rd, sel));
   if (rd.kp <= 4)
@@ -2025,7 +2096,7 @@ void NMFK_NAME(nmfk_launch_sp_step)(const void *argsv, int kp, int u0, int cnt, 
       (void)hipFuncSetAttribute((const void *)sp_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMFK_SPB_LDS);
       once = true;
     }
-    hipLaunchKernelGGL(sp_blk_kernel, dim3((a.L + NMFK_SPB_ROWS - 1) / NMFK_SPB_ROWS, cnt), dim3(1024), NMFK_SPB_LDS, s, a, u0);
+    hipLaunchKernelGGL(sp_blk_kernel, dim3(sp_blk_grid(a, cnt)), dim3(1024), NMFK_SPB_LDS, s, a, u0, cnt);
     return;
   }
 #endif
@@ -2050,6 +2121,17 @@ void NMFK_NAME(nmfk_launch_sp_obj)(const void *argsv, int n, int m, int hsel, in
   const NmfkSparseArgs &a = *(const NmfkSparseArgs *)argsv;  // CSR view: L = n
   hipLaunchKernelGGL(sp_obj_kernel, dim3((a.L + NMFK_TILE - 1) / NMFK_TILE, cnt), dim3(NMFK_TILE), 0, s, a, hsel,
                      total_iters, weight, u0);
+#ifdef NMFK_IS_F32
+  if (a.ell) {  // units of ranks 9..32 in the blocked form (either kernel leaves the other's units alone)
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute((const void *)sp_blk_obj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMFK_SPB_LDS);
+      once = true;
+    }
+    hipLaunchKernelGGL(sp_blk_obj_kernel, dim3(sp_blk_grid(a, cnt)), dim3(1024), NMFK_SPB_LDS, s, a, hsel, total_iters, weight,
+                       u0, cnt);
+  }
+#endif
   const int chunks = (n + NMFK_GRAM_ROWS - 1) / NMFK_GRAM_ROWS + (m + NMFK_GRAM_ROWS - 1) / NMFK_GRAM_ROWS;
   hipLaunchKernelGGL(sp_gram_part_kernel, dim3(chunks, cnt), dim3(NMFK_TILE), 0, s, a, n, m, hsel, total_iters, u0);
   hipLaunchKernelGGL(sp_gram_dot_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, n, m, weight, u0);

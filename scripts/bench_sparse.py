@@ -26,11 +26,15 @@ kmin = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 ks = list(range(kmin, kmax + 1))
 seeds = np.array([[N.run_seed(1, k, r) for r in range(R)] for k in ks], dtype=np.uint64)
 ctx.mu_sweep(ks, R, seeds=seeds, maxiter=10, maxbaditers=10 ** 9)
+ctx.set_profiling(True)
 t = time.perf_counter()
 res = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, maxbaditers=10 ** 9)
 dt = time.perf_counter() - t
 bytes_alg = sum((2 * ctx.nnz * 8 + 4 * (n + m) * k * 4) * R for k in ks) * iters
 flops = sum(8.0 * ctx.nnz * k * R for k in ks) * iters
+prof = ctx.get_profile()
+for name, e in sorted(prof.items()):
+    print(f"  {name:28s} {e['launches']:6d} x {e['ms'] / max(e['launches'], 1):9.4f} ms")
 print(f"{len(ks) * R} units: {1e3 * dt / iters:.2f} ms/iter (incl. checks + D2H of results), "
       f"{bytes_alg / dt / 1e9:.0f} GB/s algorithmic = {bytes_alg / dt / 8e12:.1%} of 8 TB/s, {flops / dt / 1e12:.2f} TFLOP/s; "
       f"obj[k={kmin}]={res[kmin]['objvalue'][0]:.3f} obj[k={kmax}]={res[kmax]['objvalue'][0]:.3f}")

@@ -1,7 +1,7 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the sparse cfg4 bench (run through gpurun from the repo root): gpurun_out/r02/sp/
+# rocprofv3 kernel stats of the sparse cfg4 bench (run through gpurun from the repo root): gpurun_out/r03/sp/
 set -u
-OUT=$PWD/gpurun_out/r02/sp
+OUT=$PWD/gpurun_out/r03/sp
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
@@ -13,7 +13,7 @@ grep units $OUT/log.txt
 cut -d, -f1-6 $OUT/kernel_stats.csv | head -14
 python3 - <<'PY'
 import csv,collections,glob,os
-f=glob.glob(os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/r02/sp/trace/*/*_kernel_trace.csv')[0]
+f=glob.glob(os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/r03/sp/trace/*/*_kernel_trace.csv')[0]
 d=collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n=r['Kernel_Name']

@@ -1,14 +1,15 @@
 #!/bin/bash
-# sparse cfg4: parity tests (gather form, then the blocked form forced onto the small cases), ms/iter of both forms
+# sparse cfg4: parity tests (library's choice, then the blocked form forced onto the small cases, then the gather form only),
+# ms/iter of both forms at 200 iterations (the D2H of the results diluted), kernel trace of the blocked form
 set -u
 mkdir -p gpurun_out
-NMFK_SP_BLK=2 timeout -k 10 400 python -m pytest tests -m gpu -x -q -k sparse > gpurun_out/sp_tests_blk.log 2>&1 || { tail -40 gpurun_out/sp_tests_blk.log; exit 1; }
-tail -2 gpurun_out/sp_tests_blk.log
-timeout -k 10 400 python -m pytest tests -m gpu -x -q -k sparse > gpurun_out/sp_tests.log 2>&1 || { tail -30 gpurun_out/sp_tests.log; exit 1; }
-tail -2 gpurun_out/sp_tests.log
-for rng in "32 16 2" "32 16 17" "16 16 9"; do
+for mode in "" 2 0; do
+  NMFK_SP_BLK=$mode timeout -k 10 500 python -m pytest tests -m gpu -x -q -k sparse > gpurun_out/sp_tests_$mode.log 2>&1 || { tail -40 gpurun_out/sp_tests_$mode.log; exit 1; }
+  echo "NMFK_SP_BLK='$mode': $(tail -1 gpurun_out/sp_tests_$mode.log)"
+done
+for rng in "32 16 2" "32 16 17" "16 16 9" "8 16 2"; do
   for blk in 1 0; do
-    echo -n "NMFK_SP_BLK=$blk [$rng]: "
-    NMFK_SP_BLK=$blk timeout -k 10 200 python3 scripts/bench_sparse.py 50 $rng 2>&1 | tail -1 | cut -c1-110 || exit 1
+    echo "NMFK_SP_BLK=$blk [kmax R kmin = $rng]:"
+    NMFK_SP_BLK=$blk timeout -k 10 300 python3 scripts/bench_sparse.py 200 $rng 2>&1 | grep -E "step|units" || exit 1
   done
 done

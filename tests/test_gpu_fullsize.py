@@ -123,7 +123,7 @@ def test_gather_form_reference_is_the_oracle(oracle):
     assert abs(obj - ref["objvalue"]) <= 1e-10 * ref["objvalue"]
 
 
-def test_sparse_cfg4_full_size(NMFk, ctx, oracle):
+def test_sparse_cfg4_full_size(NMFk, ctx, oracle, monkeypatch):
     """100000 x 4096, 0.5 % fill (2.04 M non-zeros, rows of ~20 and columns of ~500 non-zeros, some rows EMPTY), one
     restart of ranks of every lane class of the gather kernels (k = 3, 8, 13, 20, 32, 40) for 6 iterations, against
     the Float64 gather-form reference from identical initial factors: W*H on 3000 rows, objective, and the C-ABI objective
@@ -144,10 +144,16 @@ def test_sparse_cfg4_full_size(NMFk, ctx, oracle):
     assert ctx.nnz == Xs.nnz
     ks, iters = [3, 8, 13, 20, 32, 40], 6
     seeds = np.array([[NMFk.run_seed(4, k, 0)] for k in ks], dtype=np.uint64)
+    # the library's own choice (three units of ranks 9..32: the W half-step fills the GPU in the blocked form -- 98
+    # workgroups a unit --, the H half-step -- 4 -- does not and stays in the gather form), then both half-steps blocked
     res = ctx.mu_sweep(ks, 1, seeds=seeds, maxiter=iters, **NOSTOP)
+    monkeypatch.setenv("NMFK_SP_BLK", "2")
+    res_blk = ctx.mu_sweep([13, 20, 32], 1, seeds=seeds[2:5], maxiter=iters, **NOSTOP)
+    monkeypatch.delenv("NMFK_SP_BLK")
+    refs = {}
     for q, k in enumerate(ks):
         W0, H0 = oracle.init_factors(int(seeds[q, 0]), n, m, k)
-        W, H, obj = _gather_form_mu(Xs, W0, H0, iters)
+        W, H, obj = refs[k] = _gather_form_mu(Xs, W0, H0, iters)
         Wg, Hg = res[k]["W"][0].astype(np.float64), res[k]["H"][0].astype(np.float64)
         assert res[k]["iters"][0] == iters
         # (the sweep returns the factors with the reference's final scaling, so products are compared: 3000 rows of W*H)
@@ -157,6 +163,12 @@ def test_sparse_cfg4_full_size(NMFk, ctx, oracle):
         assert abs(res[k]["objvalue"][0] - obj) <= 1e-5 * obj, k
         assert abs(ctx.frobenius(res[k]["W"][0], res[k]["H"][0]) - res[k]["objvalue"][0]) <= 1e-5 * obj
         assert (Wg[12345] <= 1e-30).all() and (Hg[:, 777] <= 1e-30).all()  # no data: the factors' rows go to zero
+    sel = np.r_[0:1000, 12000:13000, n - 1000:n]
+    for k in (13, 20, 32):
+        W, H, obj = refs[k]
+        Pg = res_blk[k]["W"][0].astype(np.float64)[sel] @ res_blk[k]["H"][0].astype(np.float64)
+        assert np.linalg.norm(Pg - W[sel] @ H) <= 2e-5 * np.linalg.norm(W[sel] @ H), k
+        assert abs(res_blk[k]["objvalue"][0] - obj) <= 1e-5 * obj, k
 
 
 # ---------------------------------------------------------------------------------------------------------------------

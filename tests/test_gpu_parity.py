@@ -915,10 +915,14 @@ def _sparse_case(oracle, n, m, fill, seed):
     return X, sp.csc_matrix(X)
 
 
-@pytest.mark.parametrize("compute,tol", [("f64", 1e-6), ("f32", 1e-4)])
-@pytest.mark.parametrize("k", [1, 4, 7, 16, 20, 40])
-def test_sparse_gather_path_matches_dense_oracle(NMFk, ctx, oracle, compute, tol, k):
-    """BASELINE configs[3] semantics: the CSC/CSR gather kernels against the DENSE Float64 oracle (zeros -> lambda)."""
+@pytest.mark.parametrize("compute,tol,form", [("f64", 1e-6, "gather"), ("f32", 1e-4, "gather"), ("f32", 1e-4, "blocked")])
+@pytest.mark.parametrize("k", [1, 4, 7, 9, 16, 20, 23, 32, 40])
+def test_sparse_gather_path_matches_dense_oracle(NMFk, ctx, oracle, compute, tol, form, k, monkeypatch):
+    """BASELINE configs[3] semantics: the sparse half-steps against the DENSE Float64 oracle (zeros -> lambda).  `gather`:
+    the CSC/CSR gather kernels (NMFK_SP_BLK=0); `blocked`: ranks 9..32 take the sliced-ELL form of both half-steps, a lane
+    element per thread (NMFK_SP_BLK=2 forces it onto this small case: 300 rows = 5 waves of the one workgroup, 96 columns
+    = a granule of 96 rows; ragged ranks 9 and 23 take the zero-padded staging)."""
+    monkeypatch.setenv("NMFK_SP_BLK", "2" if form == "blocked" else "0")
     n, m = 300, 96
     X, Xs = _sparse_case(oracle, n, m, 0.04, 91)
     ctx.set_X_sparse(Xs)
@@ -932,6 +936,41 @@ def test_sparse_gather_path_matches_dense_oracle(NMFk, ctx, oracle, compute, tol
         assert _rel(res["W"][r] @ res["H"][r], ref["W"] @ ref["H"], X) <= tol
         assert abs(res["objvalue"][r] - ref["objvalue"]) <= max(tol, 1e-6) * ref["objvalue"]
         assert abs(ctx.frobenius(res["W"][r], res["H"][r]) - res["objvalue"][r]) <= 1e-4 * res["objvalue"][r]
+
+
+def test_sparse_blocked_form_spans_granules_and_skewed_rows(NMFk, ctx, oracle, monkeypatch):
+    """The blocked form where its bookkeeping matters: 2500 x 2300 (three workgroups and three granules in either
+    orientation, the last ones partial), ranks 12 (two granules staged at a time) and 29 (one, ragged), empty rows and
+    columns, and one row and one column 40 x as long as the others (their slice walks 40 x the slot rows).  Against the
+    gather form on the same seeds (different summation order: 1e-5) and against the Float64 oracle."""
+    import scipy.sparse as sp
+
+    n, m = 2500, 2300
+    X, _ = _sparse_case(oracle, n, m, 0.01, 17)
+    X[777, ::3] = 1.5      # a long row
+    X[::4, 2111] = 2.5     # a long column
+    X[100:164, :] = 0      # an empty slice of rows
+    X[:, 1030] = 0         # an empty column behind a granule boundary
+    Xs = sp.csc_matrix(X)
+    ctx.set_X_sparse(Xs)
+    ks = [12, 29]
+    seeds = _seeds(NMFk, 21, ks, 2)
+    out = {}
+    for form in ("0", "2"):
+        monkeypatch.setenv("NMFK_SP_BLK", form)
+        out[form] = ctx.mu_sweep(ks, 2, seeds=seeds, maxiter=20, **NOSTOP)
+    for q, k in enumerate(ks):
+        for r in range(2):
+            Pg = out["0"][k]["W"][r].astype(np.float64) @ out["0"][k]["H"][r].astype(np.float64)
+            Pb = out["2"][k]["W"][r].astype(np.float64) @ out["2"][k]["H"][r].astype(np.float64)
+            assert np.linalg.norm(Pb - Pg) <= 1e-5 * np.linalg.norm(Pg), (k, r)
+            assert abs(out["2"][k]["objvalue"][r] - out["0"][k]["objvalue"][r]) <= 1e-5 * out["0"][k]["objvalue"][r]
+            # no data: the factors' rows go to zero (up to the clamp of the reference's every-10th-iteration check)
+            assert (out["2"][k]["W"][r][100:164] <= 1e-12).all() and (out["2"][k]["H"][r][:, 1030] <= 1e-12).all()
+        W0, H0 = oracle.init_factors(int(seeds[q, 0]), n, m, k)
+        ref = oracle.singlerun(X, k, W0, H0, maxiter=20, **NOSTOP)
+        assert _rel(out["2"][k]["W"][0] @ out["2"][k]["H"][0], ref["W"] @ ref["H"], X) <= 1e-4
+        assert abs(out["2"][k]["objvalue"][0] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
 
 
 def test_sparse_execute_equals_dense_execute(NMFk, oracle):

@@ -93,7 +93,10 @@ int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, int64_t ldx,
  * lambda = 1e-32 (Mult:17-18), so only the stored non-zeros contribute to the update ratios; the gather kernels
  * selected by this call are that arithmetic to < 1e-30 and stream 8 B + 4k B per non-zero instead of the dense
  * n x m passes.  colptr: m+1 offsets, rowidx/vals: nnz entries (entries <= 0 are dropped, negative => error,
- * NaN (missing data) needs the dense path).  *kept (optional) receives the number of stored non-zeros. */
+ * NaN (missing data) needs the dense path).  *kept (optional) receives the number of stored non-zeros.
+ * Also builds, on the host, the CSR twin and the sliced-ELL copies of both orientations that the blocked form of the
+ * half-steps reads (ranks 9..32; skipped for an orientation whose padding would exceed 4 slots per non-zero).
+ * n, m <= 2^24 (NMFK_ERR_UNSUPPORTED beyond: the sparse kernels index a factor's elements with 32 bits). */
 int nmfk_set_X_csc(nmfk_ctx *ctx, int64_t n, int64_t m, int64_t nnz, const int64_t *colptr, const int32_t *rowidx,
                    const float *vals, int64_t *kept);
 

@@ -1294,16 +1294,47 @@ __device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkR
   for (int gb0 = 0; gb0 < ngb; gb0 += GPS) {
     const int c0 = gb0 * NMFK_SPB_ROWS, rows = min(GPS * NMFK_SPB_ROWS, g.D - c0);
     __syncthreads();  // (everybody is done with the previous block)
+    // (all loads of a thread first, then its LDS writes: one load -> wait -> write per trip left the latency of every
+    //  trip exposed -- 3.6 us per granule where the L1 fill rate allows 1)
     if (vec) {
       const sp_vec4u *src = (const sp_vec4u *)(B + (int64_t)c0 * kp);
-      for (int e = tid; e < rows * NC; e += 1024) {
-        const int r = e / NC, c = e - r * NC;
-        *(sp_vec4 *)(hb + r * STR + 4 * c) = src[e];
+      // loads in flight per thread: 28..32 signals leave registers for two (four or eight in flight spill into the record
+      // loop: 3.4 -> 4.4 -> 5.2 ms per H half-step of k = 17:32)
+      constexpr int SB = NC >= 7 ? 2 : NC > 4 ? 4 : GPS * NC;
+#pragma unroll 1
+      for (int i0 = 0; i0 < GPS * NC; i0 += SB) {
+        sp_vec4 tmp[SB];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+          const int e = tid + (i0 + i) * 1024;
+          if (i0 + i < GPS * NC && e < rows * NC) tmp[i] = src[e];
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+          const int e = tid + (i0 + i) * 1024, r = e / NC, c = e - r * NC;
+          if (i0 + i < GPS * NC && e < rows * NC) *(sp_vec4 *)(hb + r * STR + 4 * c) = tmp[i];
+        }
       }
     } else {  // pad the rows to KQ values with zeros
-      const int c = tid % KQ;
-      if (tid < RSTEP * KQ)
-        for (int r = tid / KQ; r < rows; r += RSTEP) hb[r * STR + c] = c < kp ? B[(int64_t)(c0 + r) * kp + c] : (T)0;
+      const int c = tid % KQ, r0 = tid / KQ;
+      if (tid < RSTEP * KQ) {
+        constexpr int SS = NC >= 7 ? 4 : 8;
+        for (int rb = r0; rb < rows; rb += SS * RSTEP) {
+          T tmp[SS];
+#pragma unroll
+          for (int i = 0; i < SS; ++i) {
+            const int r = min(rb + i * RSTEP, rows - 1);
+            tmp[i] = B[(int64_t)(c0 + r) * kp + min(c, kp - 1)];
+          }
+#pragma unroll
+          for (int i = 0; i < SS; ++i) tmp[i] = c < kp ? tmp[i] : (T)0;
+#pragma unroll
+          for (int i = 0; i < SS; ++i) {
+            const int r = rb + i * RSTEP;
+            if (r < rows) hb[r * STR + c] = tmp[i];
+          }
+        }
+      }
     }
     __syncthreads();
     const int gb1 = min(gb0 + GPS, ngb);
@@ -1470,6 +1501,21 @@ __global__ __launch_bounds__(1024) void sp_blk_kernel(NmfkSparseArgs g, int u0, 
     default: break;
   }
 }
+#ifdef NMFK_SPB_PROBE  // per-body register/spill counts (scripts/kernel_resources.py sp_blk_probe)
+template <int NC>
+__global__ __launch_bounds__(1024) void sp_blk_probe_kernel(NmfkSparseArgs g, int u0, int cnt) {
+  extern __shared__ char spb_lds[];
+  int tile, ul;
+  if (!sp_blk_where(g, cnt, tile, ul)) return;
+  sp_blk_body<NC, false>(g, g.runs[u0 + ul], tile, spb_lds, nullptr, 0.0);
+}
+template __global__ void sp_blk_probe_kernel<3>(NmfkSparseArgs, int, int);
+template __global__ void sp_blk_probe_kernel<4>(NmfkSparseArgs, int, int);
+template __global__ void sp_blk_probe_kernel<5>(NmfkSparseArgs, int, int);
+template __global__ void sp_blk_probe_kernel<6>(NmfkSparseArgs, int, int);
+template __global__ void sp_blk_probe_kernel<7>(NmfkSparseArgs, int, int);
+template __global__ void sp_blk_probe_kernel<8>(NmfkSparseArgs, int, int);
+#endif
 // the objective's non-zero terms of the units of ranks 9..32 (the others leave at once: sp_obj_kernel serves them)
 __global__ __launch_bounds__(1024) void sp_blk_obj_kernel(NmfkSparseArgs g, int hsel, int total_iters, double weight, int u0,
                                                           int cnt) {

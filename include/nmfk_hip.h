@@ -95,7 +95,7 @@ int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, int64_t ldx,
  * n x m passes.  colptr: m+1 offsets, rowidx/vals: nnz entries (entries <= 0 are dropped, negative => error,
  * NaN (missing data) needs the dense path).  *kept (optional) receives the number of stored non-zeros.
  * Also builds, on the host, the CSR twin and the sliced-ELL copies of both orientations that the blocked form of the
- * half-steps reads (ranks 9..32; skipped for an orientation whose padding would exceed 4 slots per non-zero).
+ * half-steps reads (ranks up to 32; skipped for an orientation whose padding would exceed 4 slots per non-zero).
  * n, m <= 2^24 (NMFK_ERR_UNSUPPORTED beyond: the sparse kernels index a factor's elements with 32 bits). */
 int nmfk_set_X_csc(nmfk_ctx *ctx, int64_t n, int64_t m, int64_t nnz, const int64_t *colptr, const int32_t *rowidx,
                    const float *vals, int64_t *kept);

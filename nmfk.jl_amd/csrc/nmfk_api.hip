@@ -800,7 +800,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   };
   Geo ghp[2] = {geometry(m, n, 0, 0), geometry(m, n, phased ? 1 : 0, 0)};
   Geo gwp[2] = {geometry(n, m, 0, 1), geometry(n, m, phased ? 1 : 0, 1)};
-  // sparse X, ranks 9..32: blocked form (a lane element per thread, the gathered factor through LDS) when the sliced ELL of
+  // sparse X, ranks up to 32: blocked form (a lane element per thread, the gathered factor through LDS) when the sliced ELL of
   // the orientation exists (nmfk_set_X_csc) and the launch fills the GPU (1024 lane elements per workgroup: the H half-step
   // of a matrix with few columns does not, the gather form serves it)
   bool sp_blk[2] = {false, false};  // [0]: H half-step, [1]: W half-step

@@ -120,9 +120,13 @@ struct NmfkSparseArgs {
 #define NMFK_SPB_ROWS 1024  // blocked form: lane elements per workgroup (one per thread; = its sum-table slot) and rows of the
                             // gathered factor per granule of the sliced ELL
 #define NMFK_SPB_LDS (160 * 1024)
-// ranks the blocked form serves: from 9 (below that the walk is bound by the record stream, not by the gathers) to 32
-// (1024 rows of the gathered factor in LDS)
-__host__ __device__ static inline int nmfk_sp_blk_rank(int kp) { return kp > 8 && kp <= 32; }
+// ranks the blocked form serves: up to 32 signals (a lane holds its lane element's row and numerators in registers, and
+// 1024 rows of the gathered factor fit in LDS).  NMFK_SPB_MINK (a build-time knob of the A/B runs in profiles/r03) keeps
+// the ranks up to it in the gather form.
+#ifndef NMFK_SPB_MINK
+#define NMFK_SPB_MINK 0
+#endif
+__host__ __device__ static inline int nmfk_sp_blk_rank(int kp) { return kp > NMFK_SPB_MINK && kp <= 32; }
 // words between the staged rows of 4 * nc signals: + 4 so that 64 lanes reading 16 bytes of 64 different rows spread over
 // the banks, never a multiple of 32
 static inline int nmfk_spb_stride(int nc) { return (4 * nc + 4) % 32 == 0 ? 4 * nc + 8 : 4 * nc + 4; }

@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(NMFK_TILE) void sp_step_kernel(NmfkSparseArgs g, in
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Blocked form of the sparse half-steps (round 3), ranks 9..32.  The gather form above fetches one row of
+// Blocked form of the sparse half-steps (round 3), ranks up to 32.  The gather form above fetches one row of
 // the other factor (kp * 4 B) per non-zero through L2 -> L1 -- 105 GB per iteration of BASELINE configs[3], 3.5 x the
 // algorithmic bytes -- and spends a group of LPR lanes and ~22 instructions on every non-zero.  Here a workgroup of 1024
 // threads owns 1024 lane elements, ONE PER LANE with all its signals in registers (the row of its own factor and the
@@ -1491,7 +1491,9 @@ __global__ __launch_bounds__(1024) void sp_blk_kernel(NmfkSparseArgs g, int u0, 
   const int u = u0 + ul;
   if (!g.force && !g.state[u].active) return;
   const NmfkRun rd = g.runs[u];
-  switch ((rd.kp + 3) >> 2) {  // (a launch holds the units of one lane-group class: ranks 9..16 or 17..32)
+  switch ((rd.kp + 3) >> 2) {  // signals per lane / 4
+    case 1: sp_blk_body<1, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    case 2: sp_blk_body<2, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
     case 3: sp_blk_body<3, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
     case 4: sp_blk_body<4, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
     case 5: sp_blk_body<5, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
@@ -1516,7 +1518,7 @@ template __global__ void sp_blk_probe_kernel<6>(NmfkSparseArgs, int, int);
 template __global__ void sp_blk_probe_kernel<7>(NmfkSparseArgs, int, int);
 template __global__ void sp_blk_probe_kernel<8>(NmfkSparseArgs, int, int);
 #endif
-// the objective's non-zero terms of the units of ranks 9..32 (the others leave at once: sp_obj_kernel serves them)
+// the objective's non-zero terms of the units of ranks up to 32 (the others leave at once: sp_obj_kernel serves them)
 __global__ __launch_bounds__(1024) void sp_blk_obj_kernel(NmfkSparseArgs g, int hsel, int total_iters, double weight, int u0,
                                                           int cnt) {
   extern __shared__ char spb_lds[];
@@ -1530,6 +1532,8 @@ __global__ __launch_bounds__(1024) void sp_blk_obj_kernel(NmfkSparseArgs g, int 
   const int sel = hsel >= 0 ? hsel : ((st.active ? total_iters : st.iters) & 1);
   const T *H = NMFK_PTR(const T, g, NMFK_HOFF(rd, sel));
   switch ((rd.kp + 3) >> 2) {
+    case 1: sp_blk_body<1, true>(g, rd, tile, spb_lds, H, weight); break;
+    case 2: sp_blk_body<2, true>(g, rd, tile, spb_lds, H, weight); break;
     case 3: sp_blk_body<3, true>(g, rd, tile, spb_lds, H, weight); break;
     case 4: sp_blk_body<4, true>(g, rd, tile, spb_lds, H, weight); break;
     case 5: sp_blk_body<5, true>(g, rd, tile, spb_lds, H, weight); break;
@@ -2168,7 +2172,7 @@ void NMFK_NAME(nmfk_launch_sp_obj)(const void *argsv, int n, int m, int hsel, in
   hipLaunchKernelGGL(sp_obj_kernel, dim3((a.L + NMFK_TILE - 1) / NMFK_TILE, cnt), dim3(NMFK_TILE), 0, s, a, hsel,
                      total_iters, weight, u0);
 #ifdef NMFK_IS_F32
-  if (a.ell) {  // units of ranks 9..32 in the blocked form (either kernel leaves the other's units alone)
+  if (a.ell) {  // units of ranks up to 32 in the blocked form (either kernel leaves the other's units alone)
     static bool once = false;
     if (!once) {
       (void)hipFuncSetAttribute((const void *)sp_blk_obj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMFK_SPB_LDS);

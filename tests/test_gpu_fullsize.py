@@ -144,11 +144,12 @@ def test_sparse_cfg4_full_size(NMFk, ctx, oracle, monkeypatch):
     assert ctx.nnz == Xs.nnz
     ks, iters = [3, 8, 13, 20, 32, 40], 6
     seeds = np.array([[NMFk.run_seed(4, k, 0)] for k in ks], dtype=np.uint64)
-    # the library's own choice (three units of ranks 9..32: the W half-step fills the GPU in the blocked form -- 98
-    # workgroups a unit --, the H half-step -- 4 -- does not and stays in the gather form), then both half-steps blocked
+    # the library's own choice (five units of ranks up to 32: the W half-step fills the GPU in the blocked form -- 98
+    # workgroups a unit --, the H half-step -- 4 -- does not and stays in the gather form; rank 40 is gather form
+    # throughout), then both half-steps blocked
     res = ctx.mu_sweep(ks, 1, seeds=seeds, maxiter=iters, **NOSTOP)
     monkeypatch.setenv("NMFK_SP_BLK", "2")
-    res_blk = ctx.mu_sweep([13, 20, 32], 1, seeds=seeds[2:5], maxiter=iters, **NOSTOP)
+    res_blk = ctx.mu_sweep(ks[:5], 1, seeds=seeds[:5], maxiter=iters, **NOSTOP)
     monkeypatch.delenv("NMFK_SP_BLK")
     refs = {}
     for q, k in enumerate(ks):
@@ -164,7 +165,7 @@ def test_sparse_cfg4_full_size(NMFk, ctx, oracle, monkeypatch):
         assert abs(ctx.frobenius(res[k]["W"][0], res[k]["H"][0]) - res[k]["objvalue"][0]) <= 1e-5 * obj
         assert (Wg[12345] <= 1e-30).all() and (Hg[:, 777] <= 1e-30).all()  # no data: the factors' rows go to zero
     sel = np.r_[0:1000, 12000:13000, n - 1000:n]
-    for k in (13, 20, 32):
+    for k in ks[:5]:
         W, H, obj = refs[k]
         Pg = res_blk[k]["W"][0].astype(np.float64)[sel] @ res_blk[k]["H"][0].astype(np.float64)
         assert np.linalg.norm(Pg - W[sel] @ H) <= 2e-5 * np.linalg.norm(W[sel] @ H), k

@@ -919,9 +919,9 @@ def _sparse_case(oracle, n, m, fill, seed):
 @pytest.mark.parametrize("k", [1, 4, 7, 9, 16, 20, 23, 32, 40])
 def test_sparse_gather_path_matches_dense_oracle(NMFk, ctx, oracle, compute, tol, form, k, monkeypatch):
     """BASELINE configs[3] semantics: the sparse half-steps against the DENSE Float64 oracle (zeros -> lambda).  `gather`:
-    the CSC/CSR gather kernels (NMFK_SP_BLK=0); `blocked`: ranks 9..32 take the sliced-ELL form of both half-steps, a lane
+    the CSC/CSR gather kernels (NMFK_SP_BLK=0); `blocked`: ranks up to 32 take the sliced-ELL form of both half-steps, a lane
     element per thread (NMFK_SP_BLK=2 forces it onto this small case: 300 rows = 5 waves of the one workgroup, 96 columns
-    = a granule of 96 rows; ragged ranks 9 and 23 take the zero-padded staging)."""
+    = a granule of 96 rows; ragged ranks 1, 7, 9 and 23 take the zero-padded staging)."""
     monkeypatch.setenv("NMFK_SP_BLK", "2" if form == "blocked" else "0")
     n, m = 300, 96
     X, Xs = _sparse_case(oracle, n, m, 0.04, 91)

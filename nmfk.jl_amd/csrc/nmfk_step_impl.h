@@ -1257,7 +1257,7 @@ __device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkR
   constexpr int KQ = 4 * NC;                   // signals a lane holds (kp rounded up to 4)
   constexpr int STR = (KQ + 4) % 32 == 0 ? KQ + 8 : KQ + 4;  // = nmfk_spb_stride(NC)
   constexpr int GPS = NMFK_SPB_LDS / (STR * 4) / NMFK_SPB_ROWS;  // = nmfk_spb_gps(NC)
-  constexpr int P = NC > 4 ? 2 : 4;            // slot rows loaded ahead
+  constexpr int P = NC > 4 ? 2 : 4;            // slot rows loaded ahead (four at 20..28 signals: no change, profiles/r03)
   constexpr int RSTEP = 1024 / KQ;             // rows staged per sweep of the workgroup (padded rows)
   const int kp = rd.kp, k = rd.k;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 // One unit of the flat work list = one restart of one rank k: "a factorization".
 // Internal factor layout (both factors "signal-major", so the two half-steps are the same kernel):
@@ -96,6 +97,18 @@ struct NmfkSseArgs {
   int32_t force;        // finish pass: every unit, NaN residuals skipped (normnan)
   int32_t total_iters;  // iterations the host loop executed (selects the final H buffer of still-active units)
 };
+
+// More than 64 KB of dynamic LDS has to be allowed per kernel AND per device: the one-process multi-GPU form
+// (nmfk_multi_*) launches the same kernel on several devices from several threads.  `done`: one bit per device.
+static inline void nmfk_allow_dynamic_lds(const void *kernel, std::atomic<uint64_t> &done, int bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+  }
+}
 
 // half-step / objective on sparse X: CSC view for the H half-step (L = m), CSR view otherwise (L = n)
 struct NmfkSparseArgs {

@@ -1391,11 +1391,8 @@ size_t nmfk_hyb_resident_lds(int vmax, int D) {
 void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int vmax, int u0, int cnt, hipStream_t s) {
   constexpr int NT = NMFK_HYB_NT, NW = NMFK_HYB_NW;
   if (a.res_wgs > 0) {  // resident form (the host has checked nmfk_hyb_resident_lds)
-    static bool once = false;  // more than 64 KB of dynamic LDS has to be allowed per kernel
-    if (!once) {
-      (void)hipFuncSetAttribute((const void *)hyb_res_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      once = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
+    nmfk_allow_dynamic_lds((const void *)hyb_res_kernel<NT, false>, lds_ok, 160 * 1024);
     hipLaunchKernelGGL((hyb_res_kernel<NT, false>), dim3(a.res_wgs, cnt), dim3(64 * NMFK_HYB_RW), nmfk_hyb_resident_lds(vmax, a.D), s,
                        a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0, 0);
     return;
@@ -1426,11 +1423,8 @@ void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double w
                          hipStream_t s) {
   constexpr int NT = NMFK_HYB_NT, NW = 8;
   if (w.res_wgs > 0) {  // resident form (W orientation: the loop factor H sits in LDS), res_wgs partials per unit
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute((const void *)hyb_res_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      once = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
+    nmfk_allow_dynamic_lds((const void *)hyb_res_kernel<NT, true>, lds_ok, 160 * 1024);
     const int ntile = (w.L + NMFK_TILE - 1) / NMFK_TILE;  // partials check_a_kernel adds (sse_kernel's count)
     hipLaunchKernelGGL((hyb_res_kernel<NT, true>), dim3(std::min(w.res_wgs, ntile), cnt), dim3(64 * NMFK_HYB_RW),
                        nmfk_hyb_resident_lds(vmax, w.D), s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight, ntile);
@@ -1458,11 +1452,8 @@ void nmfk_launch_step_wide2_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs
   if (nb == 2) {
     hipLaunchKernelGGL((wide2_step_kernel<2, NT, false>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
   } else {
-    static bool once = false;  // 86 KB of dynamic LDS
-    if (!once) {
-      (void)hipFuncSetAttribute((const void *)wide2_step_kernel<4, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      once = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
+    nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<4, NT, false>, lds_ok, 160 * 1024);
     hipLaunchKernelGGL((wide2_step_kernel<4, NT, false>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
   }
 }
@@ -1479,11 +1470,8 @@ void nmfk_launch_wide2_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double
   if (nb == 2) {
     hipLaunchKernelGGL((wide2_step_kernel<2, NT, true>), grid, blk, ldsb, s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
   } else {
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute((const void *)wide2_step_kernel<4, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      once = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
+    nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<4, NT, true>, lds_ok, 160 * 1024);
     hipLaunchKernelGGL((wide2_step_kernel<4, NT, true>), grid, blk, ldsb, s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
   }
 }

@@ -2141,11 +2141,8 @@ void NMFK_NAME(nmfk_launch_sp_step)(const void *argsv, int kp, int u0, int cnt, 
   const NmfkSparseArgs &a = *(const NmfkSparseArgs *)argsv;
 #ifdef NMFK_IS_F32
   if (a.ell && nmfk_sp_blk_rank(kp)) {  // blocked form: a lane element per thread, the gathered factor through LDS
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute((const void *)sp_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMFK_SPB_LDS);
-      once = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    nmfk_allow_dynamic_lds((const void *)sp_blk_kernel, lds_ok, NMFK_SPB_LDS);
     hipLaunchKernelGGL(sp_blk_kernel, dim3(sp_blk_grid(a, cnt)), dim3(1024), NMFK_SPB_LDS, s, a, u0, cnt);
     return;
   }
@@ -2173,11 +2170,8 @@ void NMFK_NAME(nmfk_launch_sp_obj)(const void *argsv, int n, int m, int hsel, in
                      total_iters, weight, u0);
 #ifdef NMFK_IS_F32
   if (a.ell) {  // units of ranks up to 32 in the blocked form (either kernel leaves the other's units alone)
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute((const void *)sp_blk_obj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMFK_SPB_LDS);
-      once = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    nmfk_allow_dynamic_lds((const void *)sp_blk_obj_kernel, lds_ok, NMFK_SPB_LDS);
     hipLaunchKernelGGL(sp_blk_obj_kernel, dim3(sp_blk_grid(a, cnt)), dim3(1024), NMFK_SPB_LDS, s, a, hsel, total_iters, weight,
                        u0, cnt);
   }

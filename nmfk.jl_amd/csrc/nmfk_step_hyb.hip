@@ -34,6 +34,9 @@
 // per chunk; 2 = the loop factor staged once (first block only); 4 = no reciprocal; 8 = no second product; 16 = no barriers;
 // resident form: 32 = no chunk loop (a tile pair's prologue and finish only), 64 = no prologue / finish work (constant operand
 // blocks, nothing loaded or stored per tile pair), 128 = no X loads inside the chunk loop
+#ifndef NMFK_HYB_PIPE
+#define NMFK_HYB_PIPE 1  // the resident form's chunk loop as a software pipeline (see hyb_res_body)
+#endif
 #ifndef NMFK_HYB_ABLATE
 #define NMFK_HYB_ABLATE 0
 #endif
@@ -946,9 +949,92 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
         __builtin_amdgcn_sched_barrier(0);
       }
     };
+    // Software pipeline over the chunks (round 3, late): the first product of chunk c + 1 is issued BEFORE the ratios of
+    // chunk c are formed, so that the reciprocals and multiplies of chunk c (which wait for nothing but chunk c's product,
+    // finished a trip earlier) issue in the free vector slots of those matrix instructions instead of behind them.
+    // pc: W*H of the chunk whose ratios are due; avn: the operands of the chunk after it.
+    f32x4_t pc[NT];
+    if (!OBJ && NMFK_HYB_PIPE) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) pc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NM; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          pc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, avn[j]), bop[t][j], pc[t], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(sb + ST::CHP + fofs[j]);
+    }
+    auto trip_pipe = [&](int c0, auto tail_tag) __attribute__((always_inline)) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {
+        const int c = c0 + ci;
+        constexpr bool dummy = false;
+        (void)dummy;
+        const bool last = TAIL && ci == 3;  // (compile-time after unrolling) the tile pair's last chunk: nothing behind it
+        if (TAIL && ci >= 2)
+          xload(xn, ci - 2, xr[(ci + 2) & 3]);
+        else
+          xload(xo, c + 2, xr[(ci + 2) & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4_t bn[NSA];
+#pragma unroll
+        for (int sn = 0; sn < NSA; ++sn) bn[sn] = *(const f32x4_t *)(sb + nofs + sn * 64 + c * ST::CHT);
+        f32x4_t pn[NT];
+        if (!last) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) pn[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < NM; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              pn[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, avn[j]), bop[t][j], pn[t], 0, 0, 0);
+        }
+        f32x4_t q[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const f32x2_t rc = {__builtin_amdgcn_rcpf(pc[t][r]), __builtin_amdgcn_rcpf(pc[t][r + 1])};
+            const f32x2_t q2 = (f32x2_t){xr[ci][t][r], xr[ci][t][r + 1]} * rc;
+            q[t][r] = q2.x;
+            q[t][r + 1] = q2.y;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!last) {  // operands of the chunk after next (the last-but-one chunk fetches chunk 0 again: the next tile pair's)
+          const char *nx = sb + ((TAIL && ci == 2) ? 0 : (c + 2) * ST::CHP);
+#pragma unroll
+          for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(nx + fofs[j]);
+        }
+        if (NS > 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int sn = 0; sn < NSA; ++sn)
+#pragma unroll
+              for (int t = 0; t < NT; ++t) accs[t][sn] = __builtin_amdgcn_mfma_f32_4x4x1f32(bn[sn][r], q[t][r], accs[t][sn], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) accs[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[0][r], q[t][r], accs[t][0], 0, 0, 0);
+        }
+        if (!last) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) pc[t] = pn[t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
 #if !(NMFK_HYB_ABLATE & 32)
-    for (int c0 = 0; c0 + 4 < nch; c0 += 4) trip(c0, std::false_type());
-    trip(nch - 4, std::true_type());
+    if (!OBJ && NMFK_HYB_PIPE) {
+      for (int c0 = 0; c0 + 4 < nch; c0 += 4) trip_pipe(c0, std::false_type());
+      trip_pipe(nch - 4, std::true_type());
+    } else {
+      for (int c0 = 0; c0 + 4 < nch; c0 += 4) trip(c0, std::false_type());
+      trip(nch - 4, std::true_type());
+    }
 #endif
 #pragma unroll
     for (int t = 0; t < NT; ++t) xo[t] = xn[t];

@@ -949,7 +949,8 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    // Software pipeline over the chunks (round 3, late): the first product of chunk c + 1 is issued BEFORE the ratios of
+    // Software pipeline over the chunks (round 3, late; the same lag of one chunk in the streaming form's full trips needs
+    // 12 more registers there: 22 spilled at 128 per wave, H half-step 0.682 -> 0.695 ms -- not kept): the first product of chunk c + 1 is issued BEFORE the ratios of
     // chunk c are formed, so that the reciprocals and multiplies of chunk c (which wait for nothing but chunk c's product,
     // finished a trip earlier) issue in the free vector slots of those matrix instructions instead of behind them.
     // pc: W*H of the chunk whose ratios are due; avn: the operands of the chunk after it.

@@ -37,6 +37,9 @@
 #ifndef NMFK_HYB_PIPE
 #define NMFK_HYB_PIPE 1  // the resident form's chunk loop as a software pipeline (see hyb_res_body)
 #endif
+#ifndef NMFK_HYB_SKEW
+#define NMFK_HYB_SKEW 1  // the streaming form's chunk skewed by lane tile (see hyb_step_body's trip)
+#endif
 #ifndef NMFK_HYB_ABLATE
 #define NMFK_HYB_ABLATE 0
 #endif
@@ -458,6 +461,39 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
         for (int t = 0; t < NT; ++t) accs[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[0][r], q[t][r], accs[t][0], 0, 0, 0);
     }
   };
+  // the same work per lane tile, for the skewed order of the half-step's chunk (see the trip): first product of tile t,
+  // its ratios, its second product
+  auto p_tile = [&](int t, const u32x4_t (&av)[NM], f32x4_t (&p)[NT]) __attribute__((always_inline)) {
+    p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+      p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[j]), bop[t][j], p[t], 0, 0, 0);
+  };
+  auto q_tile = [&](int t, int dch, const f32x4_t (&xcur)[NT], const f32x4_t (&p)[NT], f32x4_t (&q)[NT], bool mask)
+                    __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      const f32x2_t rc = {__builtin_amdgcn_rcpf(p[t][r]), __builtin_amdgcn_rcpf(p[t][r + 1])};
+      const f32x2_t q2 = (f32x2_t){xcur[t][r], xcur[t][r + 1]} * rc;
+      q[t][r] = q2.x;
+      q[t][r + 1] = q2.y;
+      if (mask) {
+        q[t][r] = (dch + 4 * g + r < d1) ? q[t][r] : 0.0f;
+        q[t][r + 1] = (dch + 4 * g + r + 1 < d1) ? q[t][r + 1] : 0.0f;
+      }
+    }
+  };
+  auto f_tile = [&](int t, const f32x4_t (&bn)[NSA], const f32x4_t (&q)[NT]) __attribute__((always_inline)) {
+    if (NS > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int sn = 0; sn < NSA; ++sn) accs[t][sn] = __builtin_amdgcn_mfma_f32_4x4x1f32(bn[sn][r], q[t][r], accs[t][sn], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) accs[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[0][r], q[t][r], accs[t][0], 0, 0, 0);
+    }
+  };
   // inputs of the fused finish, fetched before the loop so that the finish does not wait for memory: the other
   // factor's sums (denominators of Mult:67 / Mult:70) and this lane's old factor values
   const bool fused = !OBJ && gp->fused != 0;
@@ -539,11 +575,11 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
         const bool more2 = FULLT || (c - ch + 2 * CPB < nchunks);  // and one after that
         xload(FULLT ? dch + 32 : min(dch + 32, dlast), xr[(ci + 2) & 3]);
         // (vmcnt retires in order: the staging requests go out AFTER this chunk's X prefetch)
-        if (ch == 0 && more2 && !(NMFK_HYB_ABLATE & 2)) stage.load(dch + 32 * CPB, sv[buf], svrow[buf]);
+        if (ch == 0 && more2 && !(NMFK_HYB_ABLATE & (2 | 512))) stage.load(dch + 32 * CPB, sv[buf], svrow[buf]);
         // the next block (requested a block ago) goes to the free LDS buffer BEFORE this block's last chunk: conversion
         // and LDS writes overlap with that chunk's matrix work instead of sitting in front of the barrier
         const bool last_of_block = ch == CPB - 1 || (!FULLT && c == nchunks - 1);
-        if (last_of_block && more && !(NMFK_HYB_ABLATE & 2)) stage.write(sb + (buf ^ 1) * ST::STB, sv[buf ^ 1], svrow[buf ^ 1]);
+        if (last_of_block && more && !(NMFK_HYB_ABLATE & (2 | 256))) stage.write(sb + (buf ^ 1) * ST::STB, sv[buf ^ 1], svrow[buf ^ 1]);
         __builtin_amdgcn_sched_barrier(0);  // loads stay in front of the arithmetic they overlap with
         // The block's barrier sits HERE, in front of its last chunk's arithmetic: every wave has written its part of
         // the next block and has fetched its last operands of this one (the second product's block below; the first
@@ -557,7 +593,36 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           if (!OBJ) bn[sn] = *(const f32x4_t *)(b + nofs + sn * 64 + ch * ST::CHT);
         }
         if (last_of_block) barrier();
-        {
+        if (!OBJ && NMFK_HYB_SKEW) {
+          // The chunk's work skewed by lane tile (no register more): P(t0) | P(t1) + ratios(t0) | second product(t0) +
+          // ratios(t1) | second product(t1).  The reciprocals of a tile wait only for that tile's first product, so they
+          // issue in the free vector slots of the other tile's matrix instructions instead of behind all of them.
+          u32x4_t av[NM];
+#pragma unroll
+          for (int j = 0; j < NM; ++j) av[j] = avn[j];  // fetched behind the previous chunk's first product
+          f32x4_t p[NT], q[NT];
+          const bool mask = !FULLT && dch + 16 > d1;
+          p_tile(0, av, p);
+#pragma unroll
+          for (int t = 1; t < NT; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            p_tile(t, av, p);
+            q_tile(t - 1, dch, xr[ci & 3], p, q, mask);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (FULLT || c + 1 < nchunks) {  // (a following chunk at a block's end means a following block: `more`)
+            const char *bnx = ch + 1 < CPB ? b + (ch + 1) * ST::CHP : sb + (buf ^ 1) * ST::STB;
+#pragma unroll
+            for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(bnx + fofs[j]);
+          }
+          q_tile(NT - 1, dch, xr[ci & 3], p, q, mask);
+          f_tile(0, bn, q);
+#pragma unroll
+          for (int t = 1; t < NT; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            f_tile(t, bn, q);
+          }
+        } else {
           u32x4_t av[NM];
 #pragma unroll
           for (int j = 0; j < NM; ++j) av[j] = avn[j];  // fetched behind the previous chunk's first product

@@ -193,6 +193,14 @@ struct HybStage {
   // right behind the load made the compiler wait for vmcnt(0) on the spot, X prefetches included).
   __device__ __forceinline__ void load(int row0, float (&v)[NI][2], int &vrow0) const {
     vrow0 = row0;
+#if NMFK_HYB_ABLATE & 2048  // no loads: defined values instead (the conversion and the LDS writes stay whole)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      v[i][0] = __builtin_bit_cast(float, 0x3f800000u + voff[i] + (uint32_t)row0);
+      v[i][1] = __builtin_bit_cast(float, 0x3f900000u + voff[i] + (uint32_t)row0);
+    }
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < NI; ++i) {  // (threads without an item load item 0 again and drop it)
       v[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[i], row0 * rowbytes, 0));
@@ -201,6 +209,12 @@ struct HybStage {
   }
   // rows past the factor's end and padding signals become zeros
   __device__ __forceinline__ void write(char *dst, const float (&vin)[NI][2], int vrow0) const {
+#if NMFK_HYB_ABLATE & 1024  // no conversion, no LDS writes -- but the loads stay alive: their values reach memory if they are NaN
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (vin[i][0] != vin[i][0] || vin[i][1] != vin[i][1]) *(volatile float *)dst = vin[i][0];
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       if (NITEM % GT != 0 && !pv[i]) continue;

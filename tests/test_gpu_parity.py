@@ -959,6 +959,10 @@ def test_sparse_blocked_form_spans_granules_and_skewed_rows(NMFk, ctx, oracle, m
     for form in ("0", "2"):
         monkeypatch.setenv("NMFK_SP_BLK", form)
         out[form] = ctx.mu_sweep(ks, 2, seeds=seeds, maxiter=20, **NOSTOP)
+    again = ctx.mu_sweep(ks, 2, seeds=seeds, maxiter=20, **NOSTOP)  # fixed summation orders: a second run gives the same bits
+    for k in ks:
+        for key in ("W", "H", "objvalue"):
+            assert (again[k][key] == out["2"][k][key]).all(), (k, key)
     for q, k in enumerate(ks):
         for r in range(2):
             Pg = out["0"][k]["W"][r].astype(np.float64) @ out["0"][k]["H"][r].astype(np.float64)

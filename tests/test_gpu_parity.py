@@ -977,6 +977,32 @@ def test_sparse_blocked_form_spans_granules_and_skewed_rows(NMFk, ctx, oracle, m
         assert abs(out["2"][k]["objvalue"][0] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
 
 
+@pytest.mark.parametrize("n,m", [(5, 3), (70, 1100), (1100, 70), (64, 1024), (1025, 65)])
+def test_sparse_blocked_form_on_odd_shapes(NMFk, ctx, oracle, n, m, monkeypatch):
+    """Shapes at the edges of the blocked form's bookkeeping (fewer lane elements than a wave, one lane element past a
+    workgroup or a granule, exactly a slice / a granule), ranks with 1, 3 and 8 four-signal chunks per lane: blocked form
+    forced, against the gather form on the same seeds and against the Float64 oracle."""
+    import scipy.sparse as sp
+
+    X, _ = _sparse_case(oracle, n, m, 0.08, 23 + n)
+    ctx.set_X_sparse(sp.csc_matrix(X))
+    ks = [2, 9, 32]
+    seeds = _seeds(NMFk, 5, ks, 1)
+    out = {}
+    for form in ("0", "2"):
+        monkeypatch.setenv("NMFK_SP_BLK", form)
+        out[form] = ctx.mu_sweep(ks, 1, seeds=seeds, maxiter=12, **NOSTOP)
+    for q, k in enumerate(ks):
+        Pg = out["0"][k]["W"][0].astype(np.float64) @ out["0"][k]["H"][0].astype(np.float64)
+        Pb = out["2"][k]["W"][0].astype(np.float64) @ out["2"][k]["H"][0].astype(np.float64)
+        assert np.linalg.norm(Pb - Pg) <= 1e-5 * np.linalg.norm(Pg), k
+        # (k > min(n, m) fits exactly: the sparse objective, a difference of sums, is then rounding noise ~ 1e-4 ||X||)
+        assert abs(out["2"][k]["objvalue"][0] - out["0"][k]["objvalue"][0]) <= 1e-5 * out["0"][k]["objvalue"][0] + 5e-4 * np.linalg.norm(X)
+        W0, H0 = oracle.init_factors(int(seeds[q, 0]), n, m, k)
+        ref = oracle.singlerun(X, k, W0, H0, maxiter=12, **NOSTOP)
+        assert _rel(out["2"][k]["W"][0] @ out["2"][k]["H"][0], ref["W"] @ ref["H"], X) <= 1e-4
+
+
 def test_sparse_execute_equals_dense_execute(NMFk, oracle):
     """Whole execute() on a scipy.sparse X: same stop decisions, fit, robustness and kopt as the dense path."""
     n, m = 120, 40

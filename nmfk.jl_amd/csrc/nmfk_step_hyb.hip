@@ -40,6 +40,9 @@
 #ifndef NMFK_HYB_SKEW
 #define NMFK_HYB_SKEW 1  // the streaming form's chunk skewed by lane tile (see hyb_step_body's trip)
 #endif
+#ifndef NMFK_HYB_AOLD_EARLY
+#define NMFK_HYB_AOLD_EARLY 1
+#endif
 #ifndef NMFK_HYB_ABLATE
 #define NMFK_HYB_ABLATE 0
 #endif
@@ -1110,6 +1113,9 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
 #if !(NMFK_HYB_ABLATE & 32)
     if (!OBJ && NMFK_HYB_PIPE) {
       for (int c0 = 0; c0 + 4 < nch; c0 += 4) trip_pipe(c0, std::false_type());
+#if NMFK_HYB_AOLD_EARLY
+      load_aold();  // the finish's old values: requested a trip ahead of their use
+#endif
       trip_pipe(nch - 4, std::true_type());
     } else {
       for (int c0 = 0; c0 + 4 < nch; c0 += 4) trip(c0, std::false_type());
@@ -1128,7 +1134,11 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
       for (int sn = 0; sn < NSA; ++sn) vsf[0] += accs[t][sn][0] + accs[t][sn][1] + accs[t][sn][2] + accs[t][sn][3];
     continue;
 #endif
+#if !NMFK_HYB_AOLD_EARLY
     load_aold();
+#else
+    if (OBJ || !NMFK_HYB_PIPE) load_aold();
+#endif
     float vsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {

@@ -1003,6 +1003,28 @@ def test_sparse_blocked_form_on_odd_shapes(NMFk, ctx, oracle, n, m, monkeypatch)
         assert _rel(out["2"][k]["W"][0] @ out["2"][k]["H"][0], ref["W"] @ ref["H"], X) <= 1e-4
 
 
+@pytest.mark.parametrize("form", ["0", "2"])
+def test_sparse_fixed_factors_and_given_inits(NMFk, ctx, oracle, form, monkeypatch):
+    """Winit / Hinit with Wfixed or Hfixed on sparse X (the callers of SURVEY 8f row 1 on BASELINE configs[3] data): the half-
+    step of the fixed factor is skipped, the other one reads the sum table the initialisation wrote -- in the gather form and
+    in the blocked form (whose sum-table slots are a workgroup of 1024 lane elements wide)."""
+    import scipy.sparse as sp
+
+    monkeypatch.setenv("NMFK_SP_BLK", form)
+    n, m, k = 300, 96, 9
+    X, Xs = _sparse_case(oracle, n, m, 0.05, 57)
+    ctx.set_X_sparse(Xs)
+    W0, H0 = oracle.init_factors(78, n, m, k)
+    Wi = {k: np.broadcast_to(W0.astype(np.float32), (1, n, k))}
+    Hi = {k: np.broadcast_to(H0.astype(np.float32), (1, k, m))}
+    for fixed in ("Hfixed", "Wfixed"):
+        res = ctx.mu_sweep([k], 1, Winit=Wi, Hinit=Hi, maxiter=30, normalize=0, **{fixed: 1}, **NOSTOP)[k]
+        ref = oracle.singlerun(X, k, W0, H0, maxiter=30, modifymatrices=False, **{fixed: True}, **NOSTOP)
+        assert _rel(res["W"][0] @ res["H"][0], ref["W"] @ ref["H"], X) <= 1e-4, fixed
+        np.testing.assert_allclose(res["W"][0], ref["W"], rtol=2e-3, atol=1e-5)
+        np.testing.assert_allclose(res["H"][0], ref["H"], rtol=2e-3, atol=1e-5)
+
+
 def test_sparse_execute_equals_dense_execute(NMFk, oracle):
     """Whole execute() on a scipy.sparse X: same stop decisions, fit, robustness and kopt as the dense path."""
     n, m = 120, 40

@@ -144,6 +144,8 @@ def _f32(a):
 
 def _sweep_call(call, n, m, ks, nruns, seeds, Winit, Hinit, params, kw, need_W=None):
     """Marshals the arguments of nmfk_mu_sweep / nmfk_mu_sweep_sharded / nmfk_multi_sweep and unpacks the results."""
+    if not (n and m):  # (the result buffers are sized from them: a wrapper that was never given X must not reach the library)
+        raise NMFkError(ERR_NO_X, "nmfk_set_X has not been called through this object (set_X / set_X_sparse)")
     P = params if params is not None else default_params(**kw)
     ks = [int(k) for k in ks]
     nk = len(ks)
@@ -317,6 +319,15 @@ class Multi:
         nan, zero = C.c_int64(), C.c_int64()
         _check(lib().nmfk_multi_set_X(self._h, Xf.ctypes.data, n, m, max(n, 1), float(lambda_), C.byref(nan), C.byref(zero)))
         self.ctx0.n, self.ctx0.m, self.ctx0.nan_count, self.ctx0.zero_count = n, m, nan.value, zero.value
+        return self
+
+    def set_X_sparse(self, X):
+        """Sparse X on every rank (nmfk_set_X_csc takes host pointers, so every rank's context is given the matrix; there
+        is no device-side broadcast of the CSC arrays)."""
+        for g in range(self.ngpus):
+            c = self.context(g).set_X_sparse(X)
+        self.ctx0.n, self.ctx0.m, self.ctx0.nan_count, self.ctx0.zero_count = c.n, c.m, 0, c.zero_count
+        self.ctx0.nnz = c.nnz
         return self
 
     def mu_sweep(self, ks, nruns, seeds=None, Winit=None, Hinit=None, params=None, **kw):

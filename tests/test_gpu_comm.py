@@ -194,6 +194,35 @@ def test_loopback_sharded_sweep_is_bit_identical(NMFk, oracle, N, R):
     ref_ctx.close()
 
 
+def test_loopback_sharded_sweep_on_sparse_X(NMFk, oracle):
+    """BASELINE configs[3] data through the N > 1 code: sparse X is set on every rank's context (nmfk_set_X_csc takes host
+    pointers; there is no broadcast for it), the sharded sweep delivers every restart, and the result of each restart is
+    bit for bit what its shard gives swept alone on one context."""
+    import scipy.sparse as sp
+    from nmfk_jl_amd import _lib
+
+    n, m, N, R = 400, 130, 3, 5
+    pos = oracle.uniform_fill(61, 0, n * m).reshape(n, m) < 0.06
+    X = np.where(pos, 1 + 4 * oracle.uniform_fill(62, 0, n * m).reshape(n, m), 0.0).astype(np.float32)
+    Xs = sp.csc_matrix(X)
+    ks = [3, 10, 20, 36]  # blocked form where the library takes it, gather form for k = 36
+    seeds = np.array([[NMFk.run_seed(13, k, r) for r in range(R)] for k in ks], dtype=np.uint64)
+    ref_ctx = NMFk.Context(0)
+    ref_ctx.set_X_sparse(Xs)
+    ref = _shard_reference(NMFk, ref_ctx, ks, R, N, seeds=seeds, maxiter=25, **NOSTOP)
+    mh = _lib.Multi(N, loopback=True)
+    with pytest.raises(NMFk.NMFkError) as e:  # (no X yet: the binding refuses instead of handing out empty result buffers)
+        mh.mu_sweep(ks, R, seeds=seeds, maxiter=25, **NOSTOP)
+    assert e.value.code == 4
+    mh.set_X_sparse(Xs)
+    res = mh.mu_sweep(ks, R, seeds=seeds, maxiter=25, **NOSTOP)
+    for k in ks:
+        for key in ("W", "H", "objvalue", "iters", "reason"):
+            assert (res[k][key] == ref[k][key]).all(), (k, key)
+    mh.close()
+    ref_ctx.close()
+
+
 def test_loopback_given_inits_travel_through_the_shard_buffers(NMFk, oracle):
     from nmfk_jl_amd import _lib
 

@@ -228,7 +228,8 @@ int nmfk_comm_create_loopback(nmfk_ctx *ctx, nmfk_loop_group *group, int rank, n
 
 /* One process, several GPUs (what `NMFkHIP.execute(...; ngpus = 8)` calls): GPUs 0..ngpus-1, one context, communicator
  * and host thread each; the results are delivered through GPU 0.  nmfk_multi_context gives GPU g's context (GPU 0:
- * clustering, silhouettes and fit re-checks after the sweep). */
+ * clustering, silhouettes and fit re-checks after the sweep).  Sparse X: nmfk_set_X_csc on every GPU's context (it takes
+ * host pointers; nmfk_multi_set_X broadcasts dense X only), then nmfk_multi_sweep as usual. */
 typedef struct nmfk_multi nmfk_multi;
 int nmfk_multi_create(int ngpus, nmfk_multi **out);
 int nmfk_multi_destroy(nmfk_multi *mh);

@@ -43,6 +43,14 @@
 #ifndef NMFK_HYB_AOLD_EARLY
 #define NMFK_HYB_AOLD_EARLY 1
 #endif
+#ifndef NMFK_HYB_STAMP
+#define NMFK_HYB_STAMP 0  // 1: wave 0 of workgroup (0, 0) times the segments of the streaming chunk with s_memtime and prints them
+#endif
+#if NMFK_HYB_STAMP
+#define HYB_STAMP(i) do { const uint64_t t_ = __builtin_readcyclecounter(); stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } while (0)
+#else
+#define HYB_STAMP(i) do { } while (0)
+#endif
 #ifndef NMFK_HYB_ABLATE
 #define NMFK_HYB_ABLATE 0
 #endif
@@ -573,6 +581,10 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     barrier();
     // one trip; FULLT: every chunk of the trip exists, every block of it has a successor after next and no chunk touches
     // the end of the loop range -> no guards in the unrolled body
+#if NMFK_HYB_STAMP
+    uint64_t stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_readcyclecounter();
+    uint32_t stamp_n = 0;
+#endif
     u32x4_t avn[NM];  // first-product operands of the next chunk, see trip()
 #pragma unroll
     for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(sb + fofs[j]);
@@ -588,16 +600,19 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
         if (!FULLT && c >= nchunks) break;
         const int dch = d0 + 16 * c;
         const int buf = (ci / CPB) & 1, ch = ci % CPB;  // block parity (trips hold an even number of blocks)
+        HYB_STAMP(5);  // (loop overhead between chunks)
         const bool more = FULLT || (c - ch + CPB < nchunks);       // a block follows the one this chunk belongs to
         const bool more2 = FULLT || (c - ch + 2 * CPB < nchunks);  // and one after that
         xload(FULLT ? dch + 32 : min(dch + 32, dlast), xr[(ci + 2) & 3]);
         // (vmcnt retires in order: the staging requests go out AFTER this chunk's X prefetch)
         if (ch == 0 && more2 && !(NMFK_HYB_ABLATE & (2 | 512))) stage.load(dch + 32 * CPB, sv[buf], svrow[buf]);
+        HYB_STAMP(6);  // X (and staging) requests issued
         // the next block (requested a block ago) goes to the free LDS buffer BEFORE this block's last chunk: conversion
         // and LDS writes overlap with that chunk's matrix work instead of sitting in front of the barrier
         const bool last_of_block = ch == CPB - 1 || (!FULLT && c == nchunks - 1);
         if (last_of_block && more && !(NMFK_HYB_ABLATE & (2 | 256))) stage.write(sb + (buf ^ 1) * ST::STB, sv[buf ^ 1], svrow[buf ^ 1]);
         __builtin_amdgcn_sched_barrier(0);  // loads stay in front of the arithmetic they overlap with
+        HYB_STAMP(7);  // conversion + LDS writes of the next block (a block's last chunk only; waits for the staged rows)
         // The block's barrier sits HERE, in front of its last chunk's arithmetic: every wave has written its part of
         // the next block and has fetched its last operands of this one (the second product's block below; the first
         // product's came with the previous chunk), so this buffer is free for the block after next and the last chunk
@@ -609,7 +624,9 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           bn[sn] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
           if (!OBJ) bn[sn] = *(const f32x4_t *)(b + nofs + sn * 64 + ch * ST::CHT);
         }
+        HYB_STAMP(8);  // second product's operand requested
         if (last_of_block) barrier();
+        HYB_STAMP(0);  // X / staging requests, conversion + LDS writes of the next block, second product's operand, barrier
         if (!OBJ && NMFK_HYB_SKEW) {
           // The chunk's work skewed by lane tile (no register more): P(t0) | P(t1) + ratios(t0) | second product(t0) +
           // ratios(t1) | second product(t1).  The reciprocals of a tile wait only for that tile's first product, so they
@@ -620,6 +637,8 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           f32x4_t p[NT], q[NT];
           const bool mask = !FULLT && dch + 16 > d1;
           p_tile(0, av, p);
+          __builtin_amdgcn_sched_barrier(0);
+          HYB_STAMP(1);  // first product of tile 0
 #pragma unroll
           for (int t = 1; t < NT; ++t) {
             __builtin_amdgcn_sched_barrier(0);
@@ -627,6 +646,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
             q_tile(t - 1, dch, xr[ci & 3], p, q, mask);
           }
           __builtin_amdgcn_sched_barrier(0);
+          HYB_STAMP(2);  // first product of tile 1 + ratios of tile 0
           if (FULLT || c + 1 < nchunks) {  // (a following chunk at a block's end means a following block: `more`)
             const char *bnx = ch + 1 < CPB ? b + (ch + 1) * ST::CHP : sb + (buf ^ 1) * ST::STB;
 #pragma unroll
@@ -634,11 +654,18 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           }
           q_tile(NT - 1, dch, xr[ci & 3], p, q, mask);
           f_tile(0, bn, q);
+          __builtin_amdgcn_sched_barrier(0);
+          HYB_STAMP(3);  // next operands, ratios of tile 1, second product of tile 0
 #pragma unroll
           for (int t = 1; t < NT; ++t) {
             __builtin_amdgcn_sched_barrier(0);
             f_tile(t, bn, q);
           }
+          __builtin_amdgcn_sched_barrier(0);
+          HYB_STAMP(4);  // second product of tile 1
+#if NMFK_HYB_STAMP
+          ++stamp_n;
+#endif
         } else {
           u32x4_t av[NM];
 #pragma unroll
@@ -661,6 +688,13 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     int c0 = 0;
     for (; c0 + TRIP + AHEAD <= nchunks; c0 += TRIP) trip(c0, std::true_type());
     for (; c0 < nchunks; c0 += TRIP) trip(c0, std::false_type());
+#if NMFK_HYB_STAMP
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+      printf("stamp KS=%d chunks=%u ticks/chunk: requests %.1f | stage.write %.1f | bn %.1f | barrier %.1f | P(t0) %.1f | P(t1)+Q(t0) %.1f | avn+Q(t1)+F(t0) %.1f | F(t1) %.1f | loop %.1f\n", KS, stamp_n,
+             (double)stamp_acc[6] / stamp_n, (double)stamp_acc[7] / stamp_n, (double)stamp_acc[8] / stamp_n, (double)stamp_acc[0] / stamp_n,
+             (double)stamp_acc[1] / stamp_n, (double)stamp_acc[2] / stamp_n, (double)stamp_acc[3] / stamp_n, (double)stamp_acc[4] / stamp_n,
+             (double)stamp_acc[5] / stamp_n);
+#endif
   };
   if (OBJ) {
     HybStage<KS, NMFK_HYB_CPB, 64 * NW, 0> stage;

@@ -30,3 +30,27 @@ case("8 restarts, 400 repetitions", 700, 130, ks, 8, 40, 400)
 case("merged kernel on request, side by side", 700, 130, ks, 8, 40, 100, {"NMFK_HYB": "1", "NMFK_HYB_MINK": "6", "NMFK_MERGE": "1"})
 case("merged kernel for ALL ranks <= 16", 700, 130, ks, 8, 40, 100, {"NMFK_HYB": "0", "NMFK_MERGE": "2"})
 case("packed-VALU only", 700, 130, ks, 8, 40, 100, {"NMFK_HYB": "0"})
+
+
+def sparse_case(name, n, m, fill, ks, R, iters, reps, env=None):
+    import scipy.sparse as sp
+    for k_, v_ in (env or {}).items(): os.environ[k_] = v_
+    rng = np.random.default_rng(5)
+    nnz = int(n * m * fill)
+    Xs = sp.csc_matrix((rng.uniform(1, 5, nnz).astype(np.float32), (rng.integers(0, n, nnz), rng.integers(0, m, nnz))), shape=(n, m))
+    Xs.sum_duplicates()
+    seeds = np.array([[NMFk.run_seed(12, k, r) for r in range(R)] for k in ks], dtype=np.uint64)
+    ref, bad, t0 = None, 0, time.time()
+    for rep in range(reps):
+        ctx.set_X_sparse(Xs)
+        res = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, maxbaditers=10 ** 9)
+        if ref is None:
+            ref = res; continue
+        bad += any(not ((res[k]["W"] == ref[k]["W"]).all() and (res[k]["H"] == ref[k]["H"]).all() and (res[k]["objvalue"] == ref[k]["objvalue"]).all()) for k in ks)
+    for k_ in (env or {}): del os.environ[k_]
+    print(f"{name:34s} {n}x{m} fill={fill} R={R} iters={iters}: {bad} of {reps - 1} repetitions differ  ({time.time() - t0:.0f} s)", flush=True)
+
+
+sparse_case("sparse X, blocked form", 20000, 3000, 0.005, [3, 9, 20, 32, 40], 8, 20, 40)
+sparse_case("sparse X, blocked form forced", 3000, 1500, 0.01, [3, 9, 20, 32], 4, 20, 60, {"NMFK_SP_BLK": "2"})
+sparse_case("sparse X, gather form", 3000, 1500, 0.01, [3, 9, 20, 32, 40], 4, 20, 40, {"NMFK_SP_BLK": "0"})

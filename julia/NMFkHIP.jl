@@ -18,6 +18,7 @@ module NMFkHIP
 import Random
 import Statistics
 import LinearAlgebra
+import SparseArrays
 import SHA
 import Serialization
 import JLD
@@ -60,6 +61,7 @@ and a host thread per GPU; X is broadcast, the restarts are sharded, results com
 mutable struct Context
 	h::Ptr{Cvoid}       # nmfk_ctx of GPU 0 (clustering, silhouettes, fit checks)
 	multi::Ptr{Cvoid}   # nmfk_multi or C_NULL
+	ngpus::Int
 	function Context(; device::Integer=0, ngpus::Integer=1)
 		ENV["GPU_MAX_HW_QUEUES"] = get(ENV, "GPU_MAX_HW_QUEUES", "24") # one hardware queue per rank group; before HIP starts
 		r = Ref{Ptr{Cvoid}}(C_NULL)
@@ -67,11 +69,11 @@ mutable struct Context
 			check(ccall((:nmfk_multi_create, libnmfk), Cint, (Cint, Ref{Ptr{Cvoid}}), ngpus, r))
 			mh = r[]
 			check(ccall((:nmfk_multi_context, libnmfk), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), mh, 0, r))
-			c = new(r[], mh)
+			c = new(r[], mh, ngpus)
 			finalizer(x -> ccall((:nmfk_multi_destroy, libnmfk), Cint, (Ptr{Cvoid},), x.multi), c)
 		else
 			check(ccall((:nmfk_create, libnmfk), Cint, (Cint, Ref{Ptr{Cvoid}}), device, r))
-			c = new(r[], C_NULL)
+			c = new(r[], C_NULL, 1)
 			finalizer(x -> ccall((:nmfk_destroy, libnmfk), Cint, (Ptr{Cvoid},), x.h), c)
 		end
 		return c
@@ -94,6 +96,32 @@ function setX!(c::Context, X::AbstractMatrix{<:Real}; lambda::Number=1e-32)
 		end
 	end
 	return nan[]
+end
+
+"Sparse X (BASELINE configs[3]: zeros stay zeros, which is the reference arithmetic to < 1e-30 because a zero becomes
+lambda = 1e-32, Mult:17-18).  nmfk_set_X_csc takes HOST pointers and zero-based indices; with several GPUs every GPU's
+context is given the matrix (there is no device-side broadcast of the CSC arrays).  Returns 0 (no missing entries: NaN
+needs the dense path, the library says so)."
+function setX!(c::Context, X::SparseArrays.SparseMatrixCSC{<:Real,<:Integer}; lambda::Number=1e-32)
+	n, m = size(X)
+	colptr = Int64.(SparseArrays.getcolptr(X)) .- Int64(1)
+	rowidx = Int32.(SparseArrays.rowvals(X) .- 1)
+	vals = Float32.(SparseArrays.nonzeros(X))
+	kept = Ref{Int64}(0)
+	GC.@preserve colptr rowidx vals begin
+		for g in 0:(c.ngpus - 1)
+			h = c.h
+			if c.multi != C_NULL
+				r = Ref{Ptr{Cvoid}}(C_NULL)
+				check(ccall((:nmfk_multi_context, libnmfk), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), c.multi, g, r))
+				h = r[]
+			end
+			check(ccall((:nmfk_set_X_csc, libnmfk), Cint,
+				(Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Float32}, Ref{Int64}),
+				h, n, m, length(vals), colptr, rowidx, vals, kept))
+		end
+	end
+	return 0
 end
 
 "array-valued weight of the monitored objective (Mult:74); shapes of the assertion at Exec:484"

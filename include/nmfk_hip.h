@@ -94,6 +94,8 @@ int nmfk_set_X(nmfk_ctx *ctx, const float *X, int64_t n, int64_t m, int64_t ldx,
  * selected by this call are that arithmetic to < 1e-30 and stream 8 B + 4k B per non-zero instead of the dense
  * n x m passes.  colptr: m+1 offsets, rowidx/vals: nnz entries (entries <= 0 are dropped, negative => error,
  * NaN (missing data) needs the dense path).  *kept (optional) receives the number of stored non-zeros.
+ * Row indices need NOT be ascending inside a column (the library sorts a column that is not; Julia's SparseMatrixCSC
+ * always is); duplicate (row, column) entries are kept as separate records whose contributions add.
  * Also builds, on the host, the CSR twin and the sliced-ELL copies of both orientations that the blocked form of the
  * half-steps reads (ranks up to 32; skipped for an orientation whose padding would exceed 4 slots per non-zero).
  * n, m <= 2^24 (NMFK_ERR_UNSUPPORTED beyond: the sparse kernels index a factor's elements with 32 bits). */
@@ -174,11 +176,13 @@ int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float *H, double 
  *   costs        n cosine distances to the own centre;  counts k (sorted);  totalcost = sum(costs)
  *   nclusters    clusters found (< k: the reference warns, Clus:232-234)
  *   all_costs    repeats total costs (may be NULL);  silhouettes n point silhouettes of the best run on
- *                pairwise(CosineDist(), zerostoepsilon(X)) (Clus:204-213), NULL = compute_silhouettes_flag=false */
+ *                pairwise(CosineDist(), zerostoepsilon(X)) (Clus:204-213), NULL = compute_silhouettes_flag=false
+ *   converged    KmeansResult.converged of the winning repeat (1: the centre movement fell below tol before maxiter;
+ *                may be NULL) */
 int nmfk_robustkmeans(nmfk_ctx *ctx, int d, int64_t n, const float *X, int k, int repeats, int maxiter, double tol,
                       uint64_t seed, int32_t *assignments, float *centers, float *costs, int32_t *counts,
                       double *totalcost, int32_t *best_repeat, int32_t *iterations, int32_t *nclusters,
-                      double *all_costs, float *silhouettes);
+                      double *all_costs, float *silhouettes, int32_t *converged);
 
 /* multi-GPU -------------------------------------------------------------------------------------------------- */
 /* Replaces the reference's only parallelism on this path, Distributed.pmap over the restarts of one rank

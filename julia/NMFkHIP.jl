@@ -211,16 +211,16 @@ function robustkmeans(c::Context, X::Matrix{Float32}, k::Integer, repeats::Integ
 	d, n = size(X)
 	assignments = Vector{Int32}(undef, n); centers = Matrix{Float32}(undef, d, k); costs = Vector{Float32}(undef, n)
 	counts = Vector{Int32}(undef, k); totalcost = Ref{Float64}(0)
-	best = Ref{Int32}(0); iters = Ref{Int32}(0); nclusters = Ref{Int32}(0)
+	best = Ref{Int32}(0); iters = Ref{Int32}(0); nclusters = Ref{Int32}(0); converged = Ref{Int32}(0)
 	sil = compute_silhouettes_flag ? Vector{Float32}(undef, n) : Float32[]
 	GC.@preserve X sil check(ccall((:nmfk_robustkmeans, libnmfk), Cint,
 		(Ptr{Cvoid}, Cint, Int64, Ptr{Float32}, Cint, Cint, Cint, Cdouble, UInt64, Ptr{Int32}, Ptr{Float32}, Ptr{Float32},
-		 Ptr{Int32}, Ref{Float64}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ptr{Float64}, Ptr{Float32}),
+		 Ptr{Int32}, Ref{Float64}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ptr{Float64}, Ptr{Float32}, Ref{Int32}),
 		c.h, d, n, X, k, repeats, maxiter, tol, UInt64(seed), assignments, centers, costs, counts, totalcost, best, iters,
-		nclusters, C_NULL, compute_silhouettes_flag ? pointer(sil) : C_NULL))
+		nclusters, C_NULL, compute_silhouettes_flag ? pointer(sil) : C_NULL, converged))
 	nclusters[] < k && @warn("Robust k-means analysis could not find $k clusters! Only $(nclusters[]) clusters were found.")
 	res = (assignments=Int.(assignments), centers=centers[:, 1:nclusters[]], costs=costs, counts=Int.(counts[1:nclusters[]]),
-		totalcost=totalcost[], iterations=Int(iters[]))
+		totalcost=totalcost[], iterations=Int(iters[]), converged=converged[] != 0)
 	return compute_silhouettes_flag ? (res, sil) : res
 end
 

@@ -82,7 +82,7 @@ def lib():
     L.nmfk_set_weight.argtypes = [vp, fp, C.c_int64, C.c_int64]
     L.nmfk_cluster_stats.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int64, fp, fp, ip, fp, fp, fp, fp]
     L.nmfk_robustkmeans.argtypes = [vp, C.c_int, C.c_int64, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64, ip, fp, fp,
-                                    ip, C.POINTER(C.c_double), ip, ip, ip, C.c_void_p, C.c_void_p]
+                                    ip, C.POINTER(C.c_double), ip, ip, ip, C.c_void_p, C.c_void_p, ip]
     L.nmfk_frobenius.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_double)]
     L.nmfk_set_profiling.argtypes = [vp, C.c_int]
     L.nmfk_set_objective_trace.argtypes = [vp, C.c_int]
@@ -142,10 +142,15 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def _sweep_call(call, n, m, ks, nruns, seeds, Winit, Hinit, params, kw, need_W=None):
+def _sweep_call(call, n, m, ks, nruns, seeds, Winit, Hinit, params, kw, need_W=None, collective=False):
     """Marshals the arguments of nmfk_mu_sweep / nmfk_mu_sweep_sharded / nmfk_multi_sweep and unpacks the results."""
     if not (n and m):  # (the result buffers are sized from them: a wrapper that was never given X must not reach the library)
-        raise NMFkError(ERR_NO_X, "nmfk_set_X has not been called through this object (set_X / set_X_sparse)")
+        if not collective:
+            raise NMFkError(ERR_NO_X, "nmfk_set_X has not been called through this object (set_X / set_X_sparse)")
+        # a per-rank collective call: leaving here would strand the other ranks in the status agreement of
+        # nmfk_mu_sweep_sharded.  Enter the library with 1 x 1 result buffers instead: its local plan fails with
+        # NMFK_ERR_NO_X before anything is written, and agree() hands that status to every rank.
+        n = m = 1
     P = params if params is not None else default_params(**kw)
     ks = [int(k) for k in ks]
     nk = len(ks)
@@ -270,7 +275,7 @@ class Comm:
         """nmfk_mu_sweep_sharded: same arguments on every rank (ALL restarts); every rank gets all results.  need_W=False:
         W comes back for this rank's own restarts only (NaN elsewhere)."""
         return _sweep_call(lambda *a: lib().nmfk_mu_sweep_sharded(self.ctx._h, self._h, *a), self.ctx.n, self.ctx.m, ks, nruns,
-                           seeds, Winit, Hinit, params, kw, need_W=bool(need_W))
+                           seeds, Winit, Hinit, params, kw, need_W=bool(need_W), collective=True)
 
 
 class Multi:
@@ -397,6 +402,19 @@ class Context:
         self.nnz = kept.value
         return self
 
+    def set_X_csc_raw(self, n, m, colptr, rowidx, vals):
+        """nmfk_set_X_csc with the caller's arrays AS THEY ARE (no canonical form): what a direct user of the C ABI passes."""
+        colptr = np.ascontiguousarray(colptr, dtype=np.int64)
+        rowidx = np.ascontiguousarray(rowidx, dtype=np.int32)
+        vals = np.ascontiguousarray(vals, dtype=np.float32)
+        kept = C.c_int64()
+        _check(lib().nmfk_set_X_csc(self._h, int(n), int(m), len(vals), colptr.ctypes.data, rowidx.ctypes.data, vals.ctypes.data,
+                                    C.byref(kept)))
+        self.n, self.m = int(n), int(m)
+        self.nan_count, self.zero_count = 0, self.n * self.m - kept.value
+        self.nnz = kept.value
+        return self
+
     def fill_uniform(self, seed, offset, count):
         out = np.empty(count, dtype=np.float32)
         _check(lib().nmfk_fill_uniform(self._h, C.c_uint64(seed), C.c_uint64(offset), count, out.ctypes.data))
@@ -473,14 +491,17 @@ class Context:
         allc = np.empty(repeats, np.float64)
         sil = np.empty(n, np.float32) if compute_silhouettes_flag else None
         tc = C.c_double()
-        br, it, kf = C.c_int32(), C.c_int32(), C.c_int32()
+        br, it, kf, cv = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         I = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
         F = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
         _check(lib().nmfk_robustkmeans(self._h, d, n, F(Xf), int(k), int(repeats), int(maxiter), float(tol), C.c_uint64(seed),
                                        I(assign), F(centers), F(costs), I(counts), C.byref(tc), C.byref(br), C.byref(it),
-                                       C.byref(kf), allc.ctypes.data, None if sil is None else sil.ctypes.data))
+                                       C.byref(kf), allc.ctypes.data, None if sil is None else sil.ctypes.data, C.byref(cv)))
+        # centers / counts: the clusters found; centers_k / counts_k: all k columns / entries as Clustering.KmeansResult holds
+        # them (zero columns / counts for clusters that were not found)
         res = dict(assignments=assign, centers=centers[:, :kf.value], costs=costs, counts=counts[:kf.value], totalcost=tc.value,
-                   iterations=it.value, best_repeat=br.value, all_costs=allc, nclusters=kf.value)
+                   iterations=it.value, converged=bool(cv.value), best_repeat=br.value, all_costs=allc, nclusters=kf.value,
+                   centers_k=centers, counts_k=counts)
         return (res, sil) if compute_silhouettes_flag else res
 
     def frobenius(self, W, H):

@@ -65,14 +65,23 @@ def _robust_k(X, k, repeats, maxiter, tol, resultdir, casefilename, load, save, 
     fn = os.path.join(resultdir, f"{casefilename}-{k}-{'_'.join(str(v) for v in X.shape)}-{repeats}.jld")  # Clus:174,237
     if load and casefilename != "":
         if os.path.isfile(fn):  # Clus:175-196
-            f = resultio.load(fn)
+            try:
+                f = resultio.load(fn)
+            except (ValueError, AssertionError, KeyError, OSError) as e:  # unreadable file: recompute (and rewrite it)
+                warnings.warn(f"'{fn}' cannot be read ({e})")
+                f = {}
             sc = f.get("assignments")
             if isinstance(sc, dict) and "assignments_" in sc and (not sil_flag or "best_silhouettes" in f):
                 a = np.asarray(sc["assignments_"], dtype=np.int32)
-                res = dict(assignments=a, centers=np.asarray(sc["centers_"], dtype=np.float32),
-                           costs=np.asarray(sc["costs_"], dtype=np.float32), counts=np.asarray(sc["counts_"], dtype=np.int32),
+                kf = int(len(np.unique(a)))
+                ck = np.asarray(sc["centers_"], dtype=np.float32)
+                nk = np.asarray(sc["counts_"], dtype=np.int32)
+                # the file holds the KmeansResult (k columns / entries); the dict shows the clusters found, like the computed
+                # path.  best_repeat / all_costs are diagnostics of a computation and are not part of the reference's file:
+                # the key is absent (not None) after a cache load on BOTH paths' consumers (`res.get(...)`).
+                res = dict(assignments=a, centers=ck[:, :kf], costs=np.asarray(sc["costs_"], dtype=np.float32), counts=nk[:kf],
                            totalcost=float(sc["totalcost_"]), iterations=int(sc["iterations_"]), converged=bool(sc["converged_"]),
-                           nclusters=int(len(np.unique(a))), best_repeat=None, all_costs=None)
+                           nclusters=kf, centers_k=ck, counts_k=nk)
                 return (res, np.asarray(f["best_silhouettes"], dtype=np.float32)) if sil_flag else res
             warnings.warn(f"Failed to load robust k-means results from '{fn}'; Robust k-means analysis will be executed ...")
     out = ctx.robustkmeans(X, k, repeats, maxiter=maxiter, tol=tol, seed=seed, compute_silhouettes_flag=sil_flag)
@@ -81,11 +90,12 @@ def _robust_k(X, k, repeats, maxiter, tol, resultdir, casefilename, load, save, 
         warnings.warn(f"Robust k-means analysis could not find {k} clusters! Only {res['nclusters']} clusters were found.")
     if save and casefilename != "":  # Clus:236-244: JLD.save(filename, "assignments", sc[, "best_silhouettes", ...])
         os.makedirs(resultdir, exist_ok=True)
-        kf = res["nclusters"]
-        sc = dict(centers_=np.asarray(res["centers"], np.float64), assignments_=np.asarray(res["assignments"], np.int64),
-                  costs_=np.asarray(res["costs"], np.float64), counts_=np.asarray(res["counts"][:kf], np.int64),
-                  wcounts_=np.asarray(res["counts"][:kf], np.int64), totalcost_=float(res["totalcost"]),
-                  iterations_=int(res["iterations"]), converged_=int(res["iterations"] < maxiter))
+        # Clustering.KmeansResult: centers d x k and counts / wcounts of length k whatever the clusters found (zero columns /
+        # entries for the others), converged = the k-means convergence flag of the winning repeat
+        sc = dict(centers_=np.asarray(res["centers_k"], np.float64), assignments_=np.asarray(res["assignments"], np.int64),
+                  costs_=np.asarray(res["costs"], np.float64), counts_=np.asarray(res["counts_k"], np.int64),
+                  wcounts_=np.asarray(res["counts_k"], np.int64), totalcost_=float(res["totalcost"]),
+                  iterations_=int(res["iterations"]), converged_=int(bool(res["converged"])))
         payload = {"assignments": sc}
         if sil_flag:
             payload["best_silhouettes"] = np.asarray(sil, np.float64)

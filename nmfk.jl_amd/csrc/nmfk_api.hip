@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <map>
+#include <new>
 #include <string>
 #include <chrono>
 #include <vector>
@@ -329,18 +330,37 @@ int build_ell(nmfk_ctx *ctx, int o, int64_t L, int64_t D, const std::vector<int3
         }
       }
     }
-  HIPCHECK(hipMalloc((void **)&ctx->ell[o], sizeof(int2) * e.size()));
-  HIPCHECK(hipMalloc((void **)&ctx->ellptr[o], sizeof(int32_t) * ep.size()));
-  HIPCHECK(hipMemcpy(ctx->ell[o], e.data(), sizeof(int2) * e.size(), hipMemcpyHostToDevice));
-  HIPCHECK(hipMemcpy(ctx->ellptr[o], ep.data(), sizeof(int32_t) * ep.size(), hipMemcpyHostToDevice));
+  // no memory for the blocked form is not an error: the gather kernels need none of this
+  if (hipMalloc((void **)&ctx->ell[o], sizeof(int2) * e.size()) != hipSuccess ||
+      hipMalloc((void **)&ctx->ellptr[o], sizeof(int32_t) * ep.size()) != hipSuccess ||
+      hipMemcpy(ctx->ell[o], e.data(), sizeof(int2) * e.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(ctx->ellptr[o], ep.data(), sizeof(int32_t) * ep.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    if (ctx->ell[o]) (void)hipFree(ctx->ell[o]);
+    if (ctx->ellptr[o]) (void)hipFree(ctx->ellptr[o]);
+    ctx->ell[o] = nullptr;
+    ctx->ellptr[o] = nullptr;
+    return NMFK_OK;
+  }
   ctx->ell_ngb[o] = (int)ngb;
   ctx->ell_pad[o] = (double)(rows * 64) / (double)nz;
   return NMFK_OK;
 }
 }  // namespace
 
+static int set_X_csc_impl(nmfk_ctx *ctx, int64_t n, int64_t m, int64_t nnz, const int64_t *colptr, const int32_t *rowidx,
+                          const float *vals, int64_t *kept);
 NMFK_EXPORT int nmfk_set_X_csc(nmfk_ctx *ctx, int64_t n, int64_t m, int64_t nnz, const int64_t *colptr,
                                const int32_t *rowidx, const float *vals, int64_t *kept) {
+  try {
+    return set_X_csc_impl(ctx, n, m, nnz, colptr, rowidx, vals, kept);
+  } catch (const std::bad_alloc &) {  // (host-side CSR twin: no C++ exception crosses the boundary)
+    if (ctx) free_sparse(ctx);
+    return fail(NMFK_ERR_HIP, "out of host memory while building the CSR twin of X");
+  }
+}
+static int set_X_csc_impl(nmfk_ctx *ctx, int64_t n, int64_t m, int64_t nnz, const int64_t *colptr, const int32_t *rowidx,
+                          const float *vals, int64_t *kept) {
   if (!ctx || !colptr || (nnz > 0 && (!rowidx || !vals))) return fail(NMFK_ERR_BAD_ARG, "null argument");
   if (n <= 0 || m <= 0) return fail(NMFK_ERR_BAD_ARG, "Input array has a zero dimension!");
   if (n > 0x7fffff00 || m > 0x7fffff00 || nnz > 0x7fffff00) return fail(NMFK_ERR_UNSUPPORTED, "size exceeds int32 range");
@@ -368,6 +388,21 @@ NMFK_EXPORT int nmfk_set_X_csc(nmfk_ctx *ctx, int64_t n, int64_t m, int64_t nnz,
       }
     }
     cp[j + 1] = (int32_t)ri.size();
+    // row indices ascending inside a column (a Julia SparseMatrixCSC and scipy's canonical form are; a direct caller of
+    // the C ABI need not be): the sliced ELL below walks a lane element's granules in index order, and the CSR twin
+    // inherits the order.  Duplicates stay separate records (their contributions add, as in a COO sum).
+    const int32_t c0 = cp[j], c1 = cp[j + 1];
+    bool sorted = true;
+    for (int32_t p = c0 + 1; p < c1 && sorted; ++p) sorted = ri[p - 1] <= ri[p];
+    if (!sorted) {
+      std::vector<std::pair<int32_t, float>> col((size_t)(c1 - c0));
+      for (int32_t p = c0; p < c1; ++p) col[(size_t)(p - c0)] = {ri[p], vc[p]};
+      std::stable_sort(col.begin(), col.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+      for (int32_t p = c0; p < c1; ++p) {
+        ri[p] = col[(size_t)(p - c0)].first;
+        vc[p] = col[(size_t)(p - c0)].second;
+      }
+    }
   }
   const int64_t nz = (int64_t)ri.size();
   for (int64_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
@@ -411,11 +446,12 @@ NMFK_EXPORT int nmfk_set_X_csc(nmfk_ctx *ctx, int64_t n, int64_t m, int64_t nnz,
     HIPCHECK(hipMemcpy(ctx->rec_csr, rec.data(), sizeof(int2) * nz, hipMemcpyHostToDevice));
   }
   // blocked form (sp_blk_kernel): the sliced ELL of the rows (W half-step) and of the columns (H half-step)
-  {
-    const int rc = build_ell(ctx, 0, n, m, rp, ci, vr);
-    if (rc != NMFK_OK) return rc;
-    const int rc2 = build_ell(ctx, 1, m, n, cp, ri, vc);
-    if (rc2 != NMFK_OK) return rc2;
+  if (read_tuning().sp_blk) {  // (NMFK_SP_BLK=0: gather kernels only, no ELL copies)
+    try {
+      (void)build_ell(ctx, 0, n, m, rp, ci, vr);
+      (void)build_ell(ctx, 1, m, n, cp, ri, vc);
+    } catch (const std::bad_alloc &) {  // host memory for the ELL build: the gather form serves
+    }
   }
   ctx->sparse = true;
   ctx->nnz = nz;
@@ -456,7 +492,7 @@ NMFK_EXPORT int nmfk_fill_uniform(nmfk_ctx *ctx, uint64_t seed, uint64_t offset,
 NMFK_EXPORT int nmfk_robustkmeans(nmfk_ctx *ctx, int d, int64_t n64, const float *X, int k, int repeats, int maxiter,
                                   double tol, uint64_t seed, int32_t *assignments, float *centers, float *costs,
                                   int32_t *counts, double *totalcost, int32_t *best_repeat, int32_t *iterations,
-                                  int32_t *nclusters, double *all_costs, float *silhouettes) {
+                                  int32_t *nclusters, double *all_costs, float *silhouettes, int32_t *converged) {
   if (!ctx) return NMFK_ERR_BAD_ARG;
   if (!X || !assignments || !centers || !costs || !counts || !totalcost) return fail(NMFK_ERR_BAD_ARG, "null argument");
   if (d <= 0 || n64 <= 0 || n64 > (1 << 27) || repeats <= 0 || maxiter < 0) return fail(NMFK_ERR_BAD_ARG, "bad dimensions");
@@ -480,9 +516,10 @@ NMFK_EXPORT int nmfk_robustkmeans(nmfk_ctx *ctx, int d, int64_t n64, const float
                      (int32_t *)(S + oV), st);
   HIPCHECK(hipGetLastError());
   std::vector<double> tot(repeats);
-  std::vector<int32_t> its(repeats);
+  std::vector<int32_t> its(repeats), cvg(repeats);
   HIPCHECK(hipMemcpyAsync(tot.data(), S + oT, sizeof(double) * repeats, hipMemcpyDeviceToHost, st));
   HIPCHECK(hipMemcpyAsync(its.data(), S + oI, sizeof(int32_t) * repeats, hipMemcpyDeviceToHost, st));
+  HIPCHECK(hipMemcpyAsync(cvg.data(), S + oV, sizeof(int32_t) * repeats, hipMemcpyDeviceToHost, st));
   HIPCHECK(hipStreamSynchronize(st));
   int best = 0;
   for (int r = 1; r < repeats; ++r)
@@ -516,6 +553,7 @@ NMFK_EXPORT int nmfk_robustkmeans(nmfk_ctx *ctx, int d, int64_t n64, const float
   *totalcost = tot[best];
   if (best_repeat) *best_repeat = best;
   if (iterations) *iterations = its[best];
+  if (converged) *converged = cvg[best] != 0;
   if (nclusters) *nclusters = kf;
   if (silhouettes) {
     int amax = 0;

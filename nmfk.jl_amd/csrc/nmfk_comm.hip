@@ -163,6 +163,9 @@ int coll_allgather(nmfk_comm *c, const void *send, void *recv, size_t bytes, con
   HIPCHECK(e);
   return NMFK_OK;
 }
+// what a rank's status word holds between agreements (0xEE bytes): see agree()
+constexpr int NMFK_STATUS_POISON_BYTE = 0xEE;
+constexpr int32_t NMFK_STATUS_POISON = (int32_t)0xEEEEEEEEu;
 // Status agreement: every rank contributes the return code of its local step; all ranks get NMFK_OK, or the first
 // failing rank's code.  A rank that failed itself keeps its own message (nmfk_last_error); the others name the rank.
 int agree(nmfk_comm *c, int my_rc, const char *step) {
@@ -177,18 +180,26 @@ int agree(nmfk_comm *c, int my_rc, const char *step) {
     hipStream_t st = c->ctx->stream;
     int32_t *d = (int32_t *)c->stat.p;  // [0]: mine, [64 ...]: everybody's (allocated by nmfk_comm_create)
     const int32_t mine = my_rc;
-    HIPCHECK(hipMemcpyAsync(d, &mine, sizeof(mine), hipMemcpyHostToDevice, st));
+    // A local HIP failure must not keep this rank out of the all-gather (the peers would wait in it for ever): between
+    // agreements d[0] holds NMFK_STATUS_POISON, so a status word that could not be uploaded reaches the peers as a failure.
+    if (hipMemcpyAsync(d, &mine, sizeof(mine), hipMemcpyHostToDevice, st) != hipSuccess && my_rc == NMFK_OK)
+      my_rc = fail(NMFK_ERR_HIP, std::string("could not upload the status word of ") + step);
     RCCLCHECK(c, "ncclAllGather(status)", rccl().AllGather(d, d + 64, sizeof(int32_t), ncclChar, c->comm, st));
-    HIPCHECK(hipMemcpyAsync(all.data(), d + 64, sizeof(int32_t) * c->nranks, hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipStreamSynchronize(st));
+    hipError_t e = hipMemcpyAsync(all.data(), d + 64, sizeof(int32_t) * c->nranks, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipMemsetAsync(d, NMFK_STATUS_POISON_BYTE, sizeof(int32_t), st);
+    if (e != hipSuccess && my_rc == NMFK_OK)  // (every rank has contributed; the peers' words are unknown to this rank)
+      my_rc = fail(NMFK_ERR_HIP, std::string("could not read the status words of ") + step);
   }
   if (my_rc != NMFK_OK) return my_rc;  // (message of the local failure stays)
   for (int h = 0; h < c->nranks; ++h)
     if (all[h] != NMFK_OK) {
       char b[256];
-      snprintf(b, sizeof(b), "rank %d of %d failed with status %d in %s (this is rank %d; see that rank's nmfk_last_error)", h,
-               c->nranks, (int)all[h], step, c->rank);
-      return fail(all[h], b);
+      const bool poison = all[h] == NMFK_STATUS_POISON;
+      snprintf(b, sizeof(b), "rank %d of %d failed with status %d in %s%s (this is rank %d; see that rank's nmfk_last_error)", h,
+               c->nranks, poison ? (int)NMFK_ERR_HIP : (int)all[h], step, poison ? " (it could not upload its status word)" : "",
+               c->rank);
+      return fail(poison ? NMFK_ERR_HIP : all[h], b);
     }
   return NMFK_OK;
 }
@@ -227,6 +238,7 @@ int comm_new(nmfk_ctx *ctx, int nranks, int rank, nmfk_comm **out) {
     delete c;
     return fail(NMFK_ERR_HIP, "out of device memory (communicator)");
   }
+  (void)hipMemset(c->stat.p, NMFK_STATUS_POISON_BYTE, sizeof(int32_t));  // (agree(): the word between agreements)
   *out = c;
   return NMFK_OK;
 }

@@ -410,7 +410,8 @@ def check_x_hash(X, xfile, quiet=True):
     h = hash_sha256_hex(X)
     hashfile = xfile + ".sha256"
     if os.path.isfile(hashfile):
-        stored = open(hashfile).read().strip()
+        with open(hashfile) as f:
+            stored = f.read().strip()
         if stored and stored != h:
             warnings.warn(f"Matrix hash mismatch in '{hashfile}': Cached results may not correspond to this matrix! "
                           "Consider deleting the hash file and cached results to avoid confusion.")

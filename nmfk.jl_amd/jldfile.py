@@ -49,7 +49,13 @@ class _Reader:
         # their full file size with base = 512.  libhdf5 refuses addresses beyond (eof - base), so a wrong value makes a
         # file unreadable for JLD.jl although every object in it is intact: reject it here too.
         self.eof = struct.unpack_from("<Q", sb, 40)[0]
-        if self.eof != len(buf):
+        if self.eof == len(buf) - self.base and self.base:
+            # files this package wrote before round 3's fix stored the address relative to the user block: every object in them
+            # is intact, so they are read (JLD.jl would refuse them; a save through resultio rewrites the right value)
+            import warnings
+            warnings.warn(f"HDF5 end-of-file address {self.eof} is relative to the {self.base}-byte user block (file of an older "
+                          "version of this package); reading it anyway")
+        elif self.eof != len(buf):
             raise ValueError(f"HDF5 end-of-file address {self.eof} differs from the file size {len(buf)} (truncated or mis-written file)")
         self.root_header = struct.unpack_from("<Q", sb, 56 + 8)[0]
 

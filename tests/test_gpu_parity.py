@@ -977,6 +977,40 @@ def test_sparse_blocked_form_spans_granules_and_skewed_rows(NMFk, ctx, oracle, m
         assert abs(out["2"][k]["objvalue"][0] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
 
 
+def test_sparse_csc_with_unsorted_row_indices(NMFk, ctx, oracle, monkeypatch):
+    """a direct caller of nmfk_set_X_csc need not pass ascending row indices inside a column (the Python
+    wrapper and a Julia SparseMatrixCSC always do).  The sliced ELL of the blocked H half-step walked a column's granules
+    assuming index order -- rows (5, 2000, 7) dropped a record.  The library now sorts such a column: a matrix passed with
+    every column's entries shuffled gives the bits of the canonical call, in the blocked and in the gather form."""
+    import scipy.sparse as sp
+
+    n, m = 2300, 1200
+    X, _ = _sparse_case(oracle, n, m, 0.01, 41)
+    Xs = sp.csc_matrix(X)
+    Xs.sort_indices()
+    rng = np.random.default_rng(5)
+    ri, va = Xs.indices.copy(), Xs.data.copy()
+    for j in range(m):
+        a, b = Xs.indptr[j], Xs.indptr[j + 1]
+        perm = rng.permutation(b - a)
+        ri[a:b], va[a:b] = ri[a:b][perm], va[a:b][perm]
+    assert any((np.diff(ri[Xs.indptr[j]:Xs.indptr[j + 1]]) < 0).any() for j in range(m))
+    ks = [5, 12]
+    seeds = _seeds(NMFk, 3, ks, 2)
+    for form in ("2", "0"):
+        monkeypatch.setenv("NMFK_SP_BLK", form)
+        ctx.set_X_sparse(Xs)
+        ref = ctx.mu_sweep(ks, 2, seeds=seeds, maxiter=12, **NOSTOP)
+        ctx.set_X_csc_raw(n, m, Xs.indptr, ri, va)
+        got = ctx.mu_sweep(ks, 2, seeds=seeds, maxiter=12, **NOSTOP)
+        for k in ks:
+            for key in ("W", "H", "objvalue"):
+                assert (got[k][key] == ref[k][key]).all(), (form, k, key)
+    W0, H0 = oracle.init_factors(int(seeds[1, 0]), n, m, 12)
+    o = oracle.singlerun(X, 12, W0, H0, maxiter=12, **NOSTOP)
+    assert _rel(got[12]["W"][0] @ got[12]["H"][0], o["W"] @ o["H"], X) <= 1e-4
+
+
 @pytest.mark.parametrize("n,m", [(5, 3), (70, 1100), (1100, 70), (64, 1024), (1025, 65)])
 def test_sparse_blocked_form_on_odd_shapes(NMFk, ctx, oracle, n, m, monkeypatch):
     """Shapes at the edges of the blocked form's bookkeeping (fewer lane elements than a wave, one lane element past a
@@ -1113,6 +1147,23 @@ def test_robustkmeans_krange_and_cache(NMFk, ctx, oracle, tmp_path):
                                compute_silhouettes_flag=True)
     assert np.array_equal(r1["assignments"], r2["assignments"]) and np.array_equal(s1, s2) and r2["totalcost"] == r1["totalcost"]
     assert np.array_equal(r1["centers"], r2["centers"]) and np.array_equal(r1["costs"], r2["costs"]) and r2["iterations"] == r1["iterations"]
+    # the file holds what Clustering.KmeansResult holds -- the k-means convergence flag (not iterations < maxiter)
+    # and centers / counts with k columns / entries whatever the clusters found
+    from nmfk_jl_amd import resultio
+
+    sc = resultio.load(str(tmp_path / "Hmatrix-3-5_60-10.jld"))["assignments"]
+    assert bool(sc["converged_"]) == r1["converged"] == r2["converged"] and r1["converged"] == oracle.robustkmeans_k(X, 3, 10)["converged"]
+    assert np.asarray(sc["centers_"]).shape == (5, 3) and len(sc["counts_"]) == len(sc["wcounts_"]) == 3
+    capped = NMFk.robustkmeans(X, 3, 4, ctx=ctx, maxiter=1, save=True, resultdir=str(tmp_path), casefilename="cap")
+    assert capped["iterations"] <= 1 and not capped["converged"]
+    assert not resultio.load(str(tmp_path / "cap-3-5_60-4.jld"))["assignments"]["converged_"]
+    # fewer clusters than k (duplicate points): the struct still has k columns / entries, zero-padded
+    Xd = np.repeat(np.array([[1.0, 0.0], [0.0, 1.0]], np.float32), 3, axis=1)  # 2 x 6: two distinct directions
+    few = NMFk.robustkmeans(Xd, 3, 4, ctx=ctx, save=True, resultdir=str(tmp_path), casefilename="few")
+    scf = resultio.load(str(tmp_path / "few-3-2_6-4.jld"))["assignments"]
+    assert np.asarray(scf["centers_"]).shape == (2, 3) and len(scf["counts_"]) == 3 and few["centers"].shape[1] == few["nclusters"]
+    again = NMFk.robustkmeans(Xd, 3, 4, ctx=ctx, load=True, resultdir=str(tmp_path), casefilename="few")
+    assert again["nclusters"] == few["nclusters"] and np.array_equal(again["centers"], few["centers"]) and np.array_equal(again["counts"], few["counts"])
 
 
 def test_robustkmeans_rows_of_W_at_bench_size(NMFk, ctx, oracle):

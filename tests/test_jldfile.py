@@ -103,8 +103,8 @@ def test_superblock_fields_match_the_julia_written_files(tmp_path):
     """the superblock's end-of-file address is ABSOLUTE.  libhdf5 limits addresses to eof - base, so a
     file that stores (size - 512) puts its last 512 bytes -- where the root group header sits -- out of reach and
     JLD.load fails with an address overflow although our own reader (which ignored the field) was happy.  Pin base and EOF
-    of a written file to what both Julia-written fixtures hold: base = 512, EOF = file size; and the reader now rejects a
-    file whose EOF differs from its size."""
+    of a written file to what both Julia-written fixtures hold: base = 512, EOF = file size; the reader rejects a
+    file whose EOF differs from its size, except the relative value older versions of this package wrote (warning)."""
     import struct
 
     from nmfk_jl_amd import jldfile
@@ -124,7 +124,11 @@ def test_superblock_fields_match_the_julia_written_files(tmp_path):
     assert (at, base, eof) == (512, 512, size) == (512, 512, os.path.getsize(fn))
     assert set(jldfile.load(fn)) >= {"W", "fit", "big"}
     raw = bytearray(open(fn, "rb").read())
-    struct.pack_into("<Q", raw, 512 + 40, size - 512)  # the round-2 defect
+    struct.pack_into("<Q", raw, 512 + 40, size - 512)  # the round-2 defect: files this package wrote before the fix
+    open(fn, "wb").write(bytes(raw))
+    with pytest.warns(UserWarning, match="relative to the 512-byte user block"):  # (still readable, with a warning)
+        assert set(jldfile.load(fn)) >= {"W", "fit", "big"}
+    struct.pack_into("<Q", raw, 512 + 40, size - 100)  # any other value: truncated or mis-written
     open(fn, "wb").write(bytes(raw))
     with pytest.raises(ValueError, match="end-of-file"):
         jldfile.load(fn)

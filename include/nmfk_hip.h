@@ -260,7 +260,9 @@ int nmfk_set_profiling(nmfk_ctx *ctx, int enabled);
 /* Launch schedule the LAST nmfk_mu_sweep on this context chose (tests assert that the schedule they mean to cover was
  * the one taken; bench.py reports it).  info[0] = phases of the sweep (2 = the split-operand MFMA group first, the
  * packed-VALU ranks afterwards), info[1] = units on the split-operand MFMA half-step, info[2] = mixed-rank packed-VALU
- * launch groups, info[3] = launch groups in all, info[4] = units on the all-MFMA half-step (k > 16), info[5..7] reserved. */
+ * launch groups, info[3] = launch groups in all, info[4] = units on the all-MFMA half-step (k > 16); the retire-aware schedule
+ * (one launch group on the matrix-pipe kernels; NMFK_REPLAN=0 switches it off): info[5] = re-plans executed, info[6] = tier
+ * of the last plan (tier j is planned for ceil(units / 2^j) units), info[7] = units in the work list of the last plan. */
 int nmfk_last_sweep_info(nmfk_ctx *ctx, int32_t info[8]);
 /* The objective the stop rule monitors -- sum((((X - W*H) .* weight)[.!inan]).^2) every 10th iteration (Mult:73-74) -- as
  * the device computed it, for every check of every restart of the NEXT sweeps (parity tests compare it with the oracle's

@@ -519,7 +519,7 @@ class Context:
         info = (C.c_int32 * 8)()
         _check(lib().nmfk_last_sweep_info(self._h, info))
         return dict(phases=info[0], mfma_group_units=info[1], merged_valu_groups=info[2], launch_groups=info[3],
-                    wide_mfma_units=info[4])
+                    wide_mfma_units=info[4], replans=info[5], last_tier=info[6], units_in_last_plan=info[7])
 
     def set_objective_trace(self, on=True):
         """nmfk_set_objective_trace: record the monitored objective (Mult:74) at every check of the next sweeps."""

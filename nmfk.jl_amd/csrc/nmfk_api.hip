@@ -13,6 +13,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
+#include <deque>
 #include <map>
 #include <new>
 #include <string>
@@ -112,11 +114,13 @@ struct Sampler {
 //   NMFK_WIDE2        0: ranks > 16 on the all-fp32 MFMA kernel only (default: split-operand first product where it pays)
 //   NMFK_HYB_RES      0: no resident form of the split-operand MFMA half-step (short loop dimension: the loop factor in LDS)
 //   NMFK_HYB_RES_TPW  pairs of lane tiles a wave of the resident form should walk (4)
+//   NMFK_REPLAN       0: no re-planning of the launch geometry as restarts retire (see "Retire-aware schedule" in nmfk_mu_sweep);
+//                     2: re-plan at every tier whatever the sweep's size (tests)
 //   NMFK_HYB_SMALL    0: ranks <= 8 keep the round-2 forms (packed-VALU / 16-signal MFMA) -- A/B switch for the 4x4x1 variants
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, hyb_groups = 1, merge = -1, phases = -1, max_wsplit = 8;
   int wide_sse = 1, hyb_sse = 1, streams = -1, host_timing = 0, merge_phased = 0, hyb_small = 1;
-  int hyb_res = 1, hyb_res_tpw = 4, wide2 = 1, sp_blk = 1;
+  int hyb_res = 1, hyb_res_tpw = 4, wide2 = 1, sp_blk = 1, replan = 1;
 };
 Tuning read_tuning() {
   Tuning t;
@@ -144,6 +148,7 @@ Tuning read_tuning() {
   geti("NMFK_WIDE2", t.wide2);
   geti("NMFK_SP_BLK", t.sp_blk);
   geti("NMFK_HYB_RES", t.hyb_res);
+  geti("NMFK_REPLAN", t.replan);
   geti("NMFK_HYB_RES_TPW", t.hyb_res_tpw);
   t.hyb_res_tpw = std::max(1, t.hyb_res_tpw);
   return t;
@@ -627,6 +632,36 @@ NMFK_EXPORT int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[6
 // --------------------------------------------------------------------------------------------------------
 // the sweep
 // --------------------------------------------------------------------------------------------------------
+namespace {
+// Retire-aware schedule: position p of the new work list takes the unit at position perm[p] of the old one.  runs[] and
+// state[] are copied into their other buffers (the old ones stay as they are: a snapshot copy may still read them), the
+// unit's slot counts become those of the new geometry and both sum tables are folded into slot 0 in the order the
+// consumers add the slots -- sum = ((s0 + s1) + ...) + 0 + ... is then bit for bit what it was.  One wave per unit.
+__global__ __launch_bounds__(64) void replan_kernel(char *arena, const NmfkRun *runs_old, const NmfkState *state_old,
+                                                    NmfkRun *runs_new, NmfkState *state_new, const int32_t *perm, int nsW,
+                                                    int nsH, int PW, int PH, int PWz, int PHz) {  // PW / PH: slots in use so far; PWz / PHz: slots to leave defined
+  const int p = blockIdx.x, q = perm[p], t = threadIdx.x;
+  NmfkRun rd = runs_old[q];
+  if (t == 0) {
+    state_new[p] = state_old[q];
+    rd.nsW = nsW;
+    rd.nsH = nsH;
+    runs_new[p] = rd;
+  }
+  const int kp = rd.kp;
+  if (t < kp) {
+    double *tabs[2] = {(double *)(arena + rd.osumW), (double *)(arena + rd.osumH)};
+    const int P[2] = {PW, PH}, Pz[2] = {PWz, PHz};
+    for (int f = 0; f < 2; ++f) {
+      double sd = 0;
+      for (int pp = 0; pp < P[f]; ++pp) sd += tabs[f][pp * kp + t];
+      tabs[f][t] = sd;
+      for (int pp = 1; pp < Pz[f]; ++pp) tabs[f][pp * kp + t] = 0.0;
+    }
+  }
+}
+}  // namespace
+
 NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nruns, const float *const *Winit,
                               const float *const *Hinit, const uint64_t *seeds, const nmfk_mu_params *params,
                               float *const *W_out, float *const *H_out, float *const *frob_out,
@@ -753,10 +788,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // Resident form of the split-operand MFMA half-step (nmfk_step_hyb.hip, hyb_res_kernel): when the loop dimension is
   // short enough for the whole loop factor to sit in LDS (the W half-step of a tall X), the units of the matrix-pipe
   // groups run it with res_wgs[which] workgroups of 16 waves per unit, each wave walking several pairs of lane tiles.
-  int res_wgs[2] = {0, 0};  // [0] H half-step (L = m, D = n), [1] W half-step (L = n, D = m)
-  if (hyb_on && T.hyb_res) {
-    int hyb_units = 0;
-    for (int q = 0; q < nk; ++q) hyb_units += use_hyb_k(ks[q]) ? nruns : 0;
+  auto plan_res = [&](int hyb_units, int (&res)[2]) {
+    res[0] = res[1] = 0;
+    if (!(hyb_on && T.hyb_res)) return;
     for (int which = 0; which < 2 && hyb_units > 0; ++which) {
       const int L = which == 0 ? m : n, D = which == 0 ? n : m;
       if (nmfk_hyb_resident_lds(hyb_vmax, D) == 0) continue;
@@ -779,14 +813,21 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           best = gq;
         }
       }
-      res_wgs[which] = best;
+      res[which] = best;
     }
+  };
+  int res_wgs[2] = {0, 0};  // [0] H half-step (L = m, D = n), [1] W half-step (L = n, D = m)
+  {
+    int hyb_units = 0;
+    for (int q = 0; q < nk; ++q) hyb_units += use_hyb_k(ks[q]) ? nruns : 0;
+    plan_res(hyb_units, res_wgs);
   }
   // workgroups (= lane tiles = sum-table slots) of one unit of rank k in the half-step `which`
-  auto tiles_of = [&](int k, int which, int L, int ws) {
-    if (use_hyb_k(k) && res_wgs[which] > 0) return res_wgs[which];
+  auto tiles_of_res = [&](int k, int which, int L, int ws, const int (&res)[2]) {
+    if (use_hyb_k(k) && res[which] > 0) return res[which];
     return (L + lane_tile(k, ws) - 1) / lane_tile(k, ws);
   };
+  auto tiles_of = [&](int k, int which, int L, int ws) { return tiles_of_res(k, which, L, ws, res_wgs); };
   const int max_ws = T.max_wsplit;
   // phases of a two-phase sweep run one after the other, so each gets the geometry that fills the chip with ITS units
   // NMFK_MERGE_PHASED=1 (A/B switch): a merged sweep runs its matrix-pipe groups first and the mixed-rank packed-VALU group
@@ -795,13 +836,16 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   for (int q = 0; q < nk; ++q) any_hyb_k = any_hyb_k || use_hyb_k(ks[q]);
   const bool phased = hyb_phases || (valu_merged && any_hyb_k && T.merge_phased);
   auto phase_of_k = [&](int k) { return phased && !use_hyb_k(k) && !(merge > 0 && use_wide_k(k)) ? 1 : 0; };
-  auto geometry = [&](int L, int D, int phase, int which) {
+  // units_of_rank < 0: the sweep as given (nruns units per rank); >= 0: that many units per rank (the tiers of the
+  // retire-aware schedule plan a sweep that has shrunk), with `res` the resident-form plan of that sweep
+  auto geometry_for = [&](int L, int D, int phase, int which, const int (&res)[2], double units_of_rank) {
     Geo g;
+    const double per_rank = units_of_rank >= 0 ? units_of_rank : (double)nruns;
     auto wgs = [&](int ws) {  // workgroups of one half-step over all units of the phase
-      int64_t t = 0;
+      double t = 0;
       for (int q = 0; q < nk; ++q)
-        if (phase_of_k(ks[q]) == phase) t += (int64_t)tiles_of(ks[q], which, L, ws) * nruns;
-      return std::max<int64_t>(t, 1);
+        if (phase_of_k(ks[q]) == phase) t += (double)tiles_of_res(ks[q], which, L, ws, res) * per_rank;
+      return std::max<int64_t>((int64_t)ceil(t - 1e-9), 1);
     };
     g.wsplit = 1;
     // the waves of a workgroup split the loop range (and stage for themselves) when whole workgroups would not fill the
@@ -828,7 +872,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     g.slots = 1;  // slots of the sum tables = the most lane tiles any rank's kernel uses
     for (int q = 0; q < nk; ++q)
       if (phase_of_k(ks[q]) == phase)
-        g.slots = std::max(g.slots, tiles_of(ks[q], which, L, g.wsplit));
+        g.slots = std::max(g.slots, tiles_of_res(ks[q], which, L, g.wsplit, res));
     // not fused: reduce_kernel finishes the half-step, one workgroup per (slot, unit) -- with the few lane tiles that made
     // the split necessary that was 8 workgroups per unit walking 16 K elements x S partials each (345 us per launch at
     // 65536 x 2048, k = 64, 8 units, against a 1.8 ms half-step): any partition of the lane range into slots is valid,
@@ -836,6 +880,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if (!g.fused) g.slots = std::max(g.slots, std::min(64, (L + 31) / 32));
     return g;
   };
+  auto geometry = [&](int L, int D, int phase, int which) { return geometry_for(L, D, phase, which, res_wgs, -1.0); };
   Geo ghp[2] = {geometry(m, n, 0, 0), geometry(m, n, phased ? 1 : 0, 0)};
   Geo gwp[2] = {geometry(n, m, 0, 1), geometry(n, m, phased ? 1 : 0, 1)};
   // sparse X, ranks up to 32: blocked form (a lane element per thread, the gathered factor through LDS) when the sliced ELL of
@@ -857,9 +902,57 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     ghp[0] = ghp[1] = Geo{1, 1, n, 1, slots_h};
     gwp[0] = gwp[1] = Geo{1, 1, m, 1, (n + NMFK_TILE - 1) / NMFK_TILE};
   }
-  const int Sh = std::max(ghp[0].S, ghp[1].S), Sw = std::max(gwp[0].S, gwp[1].S);  // (sizes the partial-numerator buffers)
+  // Retire-aware schedule (round 4).  The reference's loop guard (Mult:64) ends every restart on its own, and on structured
+  // data the restarts of a sweep stop anywhere between a few hundred iterations and maxiter; a launch geometry chosen for
+  // all units of the sweep then runs a shrinking set of them on a fraction of the chip (H half-step: two workgroups per
+  // unit, whatever is left).  When every unit of the sweep sits in ONE launch group on the matrix-pipe kernels (dense fp32,
+  // ranks 2..16 -- the bench and the usual `execute` call), the sweep is planned as TIERS: tier j is the geometry for
+  // ceil(units / 2^j) units.  At a check at which the units still active (as of the previous check's snapshot) fit the next
+  // tier, the host -- in stream order, without waiting for the GPU -- moves the active units to the front of the work list
+  // (replan_kernel: runs[] and state[] are copied in the new order into their second buffers, the sum tables folded into
+  // slot 0, which leaves every sum the next half-step forms bit for bit what it was) and switches to the tier's geometry.
+  // A unit's results are a deterministic function of the sweep as before (the decisions hang on the unit states at fixed
+  // iterations); they differ from a run without re-planning in the last bits only, as they do between launch geometries.
+  struct Tier {
+    int count;
+    Geo gh, gw;
+    int res[2];
+    int nsH, nsW;  // slots a unit's kernels write under the tier (NmfkRun::nsH / nsW)
+    int PH, PW;    // slots the tier's helper kernels (reduce, clamp) cover: written or zeroed
+  };
+  std::vector<Tier> tiers;
+  {
+    bool all_hyb = nk > 0;
+    for (int q = 0; q < nk; ++q) all_hyb = all_hyb && use_hyb_k(ks[q]) && ks[q] <= NMFK_MULTI_MAXK;
+    const bool one_group = all_hyb && !ctx->sparse && !f64 && (merge > 0 || hyb_phases) && hyb_groups == 1;
+    if (T.replan && one_group && (nunits >= 32 || T.replan >= 2)) {
+      tiers.push_back({nunits, ghp[0], gwp[0], {res_wgs[0], res_wgs[1]}, 0, 0, 0, 0});
+      for (int c = (nunits + 1) / 2; c >= 1 && c < tiers.back().count; c = (c + 1) / 2) {
+        Tier t;
+        t.count = c;
+        plan_res(c, t.res);
+        t.gh = geometry_for(m, n, 0, 0, t.res, (double)c / nk);
+        t.gw = geometry_for(n, m, 0, 1, t.res, (double)c / nk);
+        t.nsH = t.nsW = t.PH = t.PW = 0;
+        tiers.push_back(t);
+        if (c == 1) break;
+      }
+    }
+  }
+  int Sh = std::max(ghp[0].S, ghp[1].S), Sw = std::max(gwp[0].S, gwp[1].S);  // (sizes the partial-numerator buffers)
   // slots of the sum tables (rowsum(H) is produced by the H half-step): one table size for all units
   const int PH = std::max(ghp[0].slots, ghp[1].slots), PW = std::max(gwp[0].slots, gwp[1].slots);
+  int PHmax = PH, PWmax = PW;  // (the tables are allocated for the widest tier; a tier's kernels see its own PH / PW)
+  for (Tier &t : tiers) {  // (the resident form finishes itself: no partial numerators)
+    Sh = std::max(Sh, t.res[0] > 0 ? 1 : t.gh.S);
+    Sw = std::max(Sw, t.res[1] > 0 ? 1 : t.gw.S);
+    t.PH = &t == &tiers[0] ? PH : t.gh.slots;
+    t.PW = &t == &tiers[0] ? PW : t.gw.slots;
+    t.nsH = (t.gh.fused || t.res[0] > 0) ? tiles_of_res(ks[0], 0, m, t.gh.wsplit, t.res) : t.PH;
+    t.nsW = (t.gw.fused || t.res[1] > 0) ? tiles_of_res(ks[0], 1, n, t.gw.wsplit, t.res) : t.PW;
+    PHmax = std::max(PHmax, t.PH);
+    PWmax = std::max(PWmax, t.PW);
+  }
   const int tiles_n = (n + NMFK_TILE - 1) / NMFK_TILE;  // objective kernel tiles
 
   // arena layout
@@ -868,6 +961,12 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   const size_t o_state = B.take(sizeof(NmfkState) * nunits);
   const size_t o_flag = B.take(256);
   const size_t o_args = B.take(4 * sizeof(NmfkStepArgs));
+  // retire-aware schedule: the second buffers of runs[] / state[], the permutation and the argument blocks of every re-plan
+  const bool replanning = tiers.size() > 1;
+  const size_t o_runs2 = replanning ? B.take(sizeof(NmfkRun) * nunits) : 0;
+  const size_t o_state2 = replanning ? B.take(sizeof(NmfkState) * nunits) : 0;
+  const size_t o_perm = replanning ? B.take(sizeof(int32_t) * (size_t)nunits * tiers.size()) : 0;
+  const size_t o_args2 = replanning ? B.take(2 * sizeof(NmfkStepArgs) * tiers.size()) : 0;
   const size_t o_ptrs = B.take(sizeof(void *) * 7 * nk);
   const int trace_stride = ctx->trace_objective ? (int)std::max<int64_t>(1, P.maxiter / 10) : 0;
   const size_t o_trace = ctx->trace_objective ? B.take(sizeof(double) * (size_t)nunits * trace_stride) : 0;
@@ -935,8 +1034,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         rd.oH1 = P.Hfixed ? rd.oH0 : (int64_t)B.take(tsz * (size_t)kp * m);
         const size_t pe = std::max((size_t)Sh * kp * m, (size_t)Sw * kp * n);
         rd.opart = (int64_t)B.take(std::max(tsz * pe, sizeof(int32_t) * (size_t)m));
-        rd.osumW = (int64_t)B.take(sizeof(double) * (size_t)PW * kp);
-        rd.osumH = (int64_t)B.take(sizeof(double) * (size_t)PH * kp);
+        rd.osumW = (int64_t)B.take(sizeof(double) * (size_t)PWmax * kp);
+        rd.osumH = (int64_t)B.take(sizeof(double) * (size_t)PHmax * kp);
         rd.ossepart = (int64_t)B.take(sizeof(double) * (tiles_n + 1));  // sparse objective: slot 0 = <W'W, HH'>
         rd.ocanon = (int64_t)B.take(sizeof(int32_t) * (size_t)m);
         rd.ogram = ctx->sparse ? (int64_t)B.take(sizeof(double) * nmfk_gram_doubles(n, m, kp)) : 0;
@@ -949,7 +1048,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         rd.nsW = (gw.fused || (use_hyb_k(k) && res_wgs[1] > 0)) ? tiles_of(k, 1, n, gw.wsplit) : PW;
         if (ctx->sparse)  // (256 rows per slot in the gather form, 1024 in the blocked form)
           rd.nsW = sp_blk[1] && nmfk_sp_blk_rank(kp) ? (n + NMFK_SPB_ROWS - 1) / NMFK_SPB_ROWS : gw.slots;
-        rd.hyb = rd.pad0 = 0;
+        rd.hyb = 0;
+        rd.uid = u;
         if (use_hyb_k(k)) rd.hyb = hyb_variant_of(k);
       }
     }
@@ -993,8 +1093,10 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // the host vectors above must outlive the async copies
   HIPCHECK(hipStreamSynchronize(st));
 
-  const NmfkRun *d_runs = (const NmfkRun *)(A + o_runs);
-  NmfkState *d_state = (NmfkState *)(A + o_state);
+  NmfkRun *d_runs_buf[2] = {(NmfkRun *)(A + o_runs), replanning ? (NmfkRun *)(A + o_runs2) : nullptr};
+  NmfkState *d_state_buf[2] = {(NmfkState *)(A + o_state), replanning ? (NmfkState *)(A + o_state2) : nullptr};
+  const NmfkRun *d_runs = d_runs_buf[0];
+  NmfkState *d_state = d_state_buf[0];
   void **d_ptrs = (void **)(A + o_ptrs);
 
   Sampler prof(ctx);
@@ -1223,6 +1325,14 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     }
   }
   std::vector<char> in_phase(nunits);
+  // retire-aware schedule: state of the re-plans (see the tiers above)
+  const std::vector<Group> groups0 = groups;  // (the profile below counts over the launch groups as they started)
+  int cur_tier = 0, cur_buf = 0, nreplans = 0, snap_epoch[2] = {0, 0};
+  std::vector<std::vector<int32_t>> order_hist(1, std::vector<int32_t>((size_t)nunits));  // [re-plan][position] = NmfkRun::uid
+  for (int u = 0; u < nunits; ++u) order_hist[0][(size_t)u] = u;
+  std::deque<std::vector<int32_t>> perm_keep;             // host sources of the asynchronous uploads
+  std::deque<std::array<NmfkStepArgs, 2>> args_keep;
+  if (replanning && ngroups != 1) return fail(NMFK_ERR_HIP, "internal: the retire-aware schedule expects one launch group");
   for (int phase = 0; phase < nphases; ++phase) {
   // (units still active when a phase's loop ends ran all `maxiter` iterations, so one total_iters serves every phase)
   for (int u = 0; u < nunits; ++u) in_phase[u] = 0;
@@ -1332,6 +1442,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     total_iters = std::max(total_iters, it + 1);
     if (check) {
       const int slot = nchecks & 1;
+      int next_tier = cur_tier, act = 0;
       if (nchecks > 0) {  // inspect the PREVIOUS check while this one is still queued
         const auto w0 = std::chrono::steady_clock::now();
         HIPCHECK(hipEventSynchronize(snap_ev[slot ^ 1]));
@@ -1339,6 +1450,10 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         bool any = false;
         for (int u = 0; u < nunits; ++u) any = any || (in_phase[u] && snap[slot ^ 1][u].active);
         if (!any) all_done = true;
+        if (replanning && any) {  // units still active as of that check: do they fit a later tier?
+          for (int u = 0; u < nunits; ++u) act += snap[slot ^ 1][u].active ? 1 : 0;
+          while (next_tier + 1 < (int)tiers.size() && act <= tiers[next_tier + 1].count) ++next_tier;
+        }
       }
       for (int j = 0; j < NS; ++j) {
         HIPCHECK(hipEventRecord(gev[slot * NS + j], ctx->gstreams[j]));
@@ -1346,7 +1461,71 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       }
       HIPCHECK(hipMemcpyAsync(snap[slot], d_state, sizeof(NmfkState) * nunits, hipMemcpyDeviceToHost, poll));
       HIPCHECK(hipEventRecord(snap_ev[slot], poll));
+      snap_epoch[slot] = (int)order_hist.size() - 1;
       nchecks++;
+      if (next_tier != cur_tier && it + 1 < maxiter) {
+        // ---- re-plan (takes effect with the next iteration; everything below is queued behind this check on the group's
+        // stream, the host does not wait).  The snapshot just inspected may predate an earlier re-plan: unit ids translate.
+        hipStream_t gs = ctx->gstreams[0];
+        const std::vector<int32_t> &seen = order_hist[(size_t)snap_epoch[slot ^ 1]], &cur = order_hist.back();
+        std::vector<char> alive((size_t)nunits, 0);
+        for (int u = 0; u < nunits; ++u) alive[(size_t)seen[u]] = snap[slot ^ 1][u].active ? 1 : 0;
+        perm_keep.emplace_back((size_t)nunits);
+        std::vector<int32_t> &perm = perm_keep.back(), order((size_t)nunits);
+        int w = 0;
+        for (int pass = 1; pass >= 0; --pass)  // the units still active first, in their present order (k descending)
+          for (int u = 0; u < nunits; ++u)
+            if (alive[(size_t)cur[u]] == pass) {
+              perm[(size_t)w] = u;
+              order[(size_t)w++] = cur[u];
+            }
+        const Tier &tr = tiers[(size_t)next_tier];
+        int32_t *d_perm = (int32_t *)(A + o_perm) + (size_t)nreplans * nunits;
+        HIPCHECK(hipMemcpyAsync(d_perm, perm.data(), sizeof(int32_t) * nunits, hipMemcpyHostToDevice, gs));
+        hipLaunchKernelGGL(replan_kernel, dim3(nunits), dim3(64), 0, gs, A, d_runs_buf[cur_buf], d_state_buf[cur_buf],
+                           d_runs_buf[cur_buf ^ 1], d_state_buf[cur_buf ^ 1], d_perm, tr.nsW, tr.nsH, tiers[(size_t)cur_tier].PW,
+                           tiers[(size_t)cur_tier].PH, std::max(tiers[(size_t)cur_tier].PW, tr.PW), std::max(tiers[(size_t)cur_tier].PH, tr.PH));
+        cur_buf ^= 1;
+        d_runs = d_runs_buf[cur_buf];
+        d_state = d_state_buf[cur_buf];
+        {
+          std::vector<NmfkRun> moved((size_t)nunits);
+          for (int u = 0; u < nunits; ++u) {
+            moved[(size_t)u] = runs[(size_t)perm[(size_t)u]];
+            moved[(size_t)u].nsW = tr.nsW;
+            moved[(size_t)u].nsH = tr.nsH;
+          }
+          runs.swap(moved);
+        }
+        for (int ph = 0; ph < 2; ++ph) {
+          NmfkStepArgs *two[2] = {&hsP[ph], &wsP[ph]};
+          for (int f = 0; f < 2; ++f) {
+            const Geo &g = f == 0 ? tr.gh : tr.gw;
+            two[f]->S = g.S;
+            two[f]->dchunk = g.dchunk;
+            two[f]->wsplit = g.wsplit;
+            two[f]->fused = g.fused;
+            two[f]->res_wgs = tr.res[f];
+            two[f]->PW = tr.PW;
+            two[f]->PH = tr.PH;
+            two[f]->runs = d_runs;
+            two[f]->state = d_state;
+          }
+        }
+        args_keep.push_back({hsP[0], wsP[0]});
+        NmfkStepArgs *d_two = (NmfkStepArgs *)(A + o_args2) + 2 * (size_t)nreplans;
+        HIPCHECK(hipMemcpyAsync(d_two, args_keep.back().data(), 2 * sizeof(NmfkStepArgs), hipMemcpyHostToDevice, gs));
+        d_hsP[0] = d_hsP[1] = d_two;
+        d_wsP[0] = d_wsP[1] = d_two + 1;
+        sa.runs = ca.runs = d_runs;
+        sa.state = ca.state = d_state;
+        ca.PW = tr.PW;
+        ca.PH = tr.PH;
+        groups[0].count = act;
+        order_hist.push_back(order);
+        cur_tier = next_tier;
+        ++nreplans;
+      }
     }
   }
   if (phase + 1 < nphases) {  // the next phase starts on an empty GPU
@@ -1354,6 +1533,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     HIPCHECK(hipStreamSynchronize(poll));
   }
   }  // phases
+  ctx->sweep_info[5] = nreplans;
+  ctx->sweep_info[6] = cur_tier;
+  ctx->sweep_info[7] = ngroups == 1 ? groups[0].count : 0;
   if (T.host_timing)
     fprintf(stderr, "[nmfk] loop: %d iterations, %d groups, host %.3f s of which waiting for the GPU %.3f s\n", total_iters,
             ngroups, std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_w0).count(), host_wait_s);
@@ -1446,7 +1628,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     ctx->obj_trace_stride = trace_stride;
     ctx->obj_trace_nruns = nruns;
     ctx->obj_trace_unit.assign((size_t)nk * nruns, -1);
-    for (int u = 0; u < nunits; ++u) ctx->obj_trace_unit[(size_t)runs[u].kidx * nruns + runs[u].ridx] = u;
+    for (int u = 0; u < nunits; ++u) ctx->obj_trace_unit[(size_t)runs[u].kidx * nruns + runs[u].ridx] = runs[u].uid;
   }
 
   // sse_out (Mult:125); it may be device memory: stage through a host vector.  Unweighted: normnan(X - W*H)^2.
@@ -1481,7 +1663,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     for (const Sample &sm : prof.samples) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, ctx->events[sm.e0], ctx->events[sm.e1]) != hipSuccess) continue;
-      const Group &G = groups[sm.group];
+      const Group &G = groups0[sm.group];
       double active_k = 0;  // sum of the ranks of the units still iterating
       for (int u = G.begin; u < G.begin + G.count; ++u)
         active_k += sm.it < h_iters[runs[u].kidx][runs[u].ridx] ? runs[u].k : 0;

@@ -27,7 +27,7 @@ struct NmfkRun {
   int32_t nsW, nsH;  // slots of the sum tables this unit's kernels write (<= PW, PH); the others stay zero
   // split-operand MFMA half-step (nmfk_step_hyb.hip): hyb = split width KS (8 or 16; 0 = unit does not use it)
   int32_t hyb;
-  int32_t pad0;
+  int32_t uid;       // position of the unit in the work list the sweep started with (the retire-aware schedule reorders the list)
   int64_t ogram;     // sparse X: double[nmfk_gram_doubles()] partial Gram matrices of the factors (objective)
 };
 

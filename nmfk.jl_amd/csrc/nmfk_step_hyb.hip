@@ -541,7 +541,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
   constexpr bool AOLD_EARLY = NS == 0;  // (the 4x4x1 forms carry more accumulators: their old values are fetched behind the loop)
   if (fused) {
     const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
-    const int PB = which == 0 ? gp->PW : gp->PH;
+    const int PB = which == 0 ? rdp->nsW : rdp->nsH;  // (the slots behind the unit's own are zero)
     if (tid < k) {
       double sd = 0;
       for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * k + tid];
@@ -893,7 +893,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
   double ssum = 0.0;
   if (!OBJ) {
     const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
-    const int PB = which == 0 ? gp->PW : gp->PH;
+    const int PB = which == 0 ? rdp->nsW : rdp->nsH;  // (the slots behind the unit's own are zero)
     if (tid < k) {
       double sd = 0;
       for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * k + tid];

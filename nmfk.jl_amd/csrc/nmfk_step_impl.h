@@ -1683,14 +1683,14 @@ __global__ __launch_bounds__(NMFK_TILE) void reduce_kernel(NmfkStepArgs g, int u
     Anew = NMFK_PTR(T, g, NMFK_HOFF(rd, g.it + 1));
     sumB = NMFK_PTR(const double, g, rd.osumW);
     sumA = NMFK_PTR(double, g, rd.osumH);
-    PB = g.PW;
+    PB = rd.nsW;  // (the slots behind the unit's own are zero)
     PA = rd.nsH;
   } else {
     Aold = NMFK_PTR(const T, g, rd.oWt);
     Anew = NMFK_PTR(T, g, rd.oWt);
     sumB = NMFK_PTR(const double, g, rd.osumH);
     sumA = NMFK_PTR(double, g, rd.osumW);
-    PB = g.PH;
+    PB = rd.nsH;
     PA = rd.nsW;
   }
   const int k = rd.k, kp = rd.kp;
@@ -1852,7 +1852,7 @@ __global__ void check_a_kernel(NmfkCheckArgs g, int u0, int cnt) {
   double obj = 0;
   for (int t = 0; t < g.ntile_n; ++t) obj += NMFK_PTR(const double, g, rd.ossepart)[t];
   st->last_obj = obj;
-  if (g.trace && (g.it + 1) / 10 - 1 < g.trace_stride) g.trace[(int64_t)u * g.trace_stride + (g.it + 1) / 10 - 1] = obj;
+  if (g.trace && (g.it + 1) / 10 - 1 < g.trace_stride) g.trace[(int64_t)rd.uid * g.trace_stride + (g.it + 1) / 10 - 1] = obj;
   if (obj < g.tol) {  // Mult:75-78: leaves the loop before the clamp
     st->active = 0;
     st->reason = NMFK_STOP_TOL;

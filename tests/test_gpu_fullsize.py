@@ -190,7 +190,7 @@ def _stoprule_fixture(oracle):
     return fx, np.asfortranarray((W0 @ H0 + float(fx["noise"]) * U).astype(np.float32))
 
 
-@pytest.mark.parametrize("geometry", ["shared-staging", "per-wave-staging"])
+@pytest.mark.parametrize("geometry", ["shared-staging", "per-wave-staging", "static-schedule"])
 def test_default_stop_rule_against_the_oracle_fixture(NMFk, ctx, oracle, geometry, monkeypatch):
     """fp32 compute on the split-operand MFMA half-step (all ranks; objective monitored by the same kernel, OBJ = true) and
     fp64 compute, both against the oracle fixture:
@@ -199,13 +199,18 @@ def test_default_stop_rule_against_the_oracle_fixture(NMFk, ctx, oracle, geometr
       * fp32 compute: the monitored objective (Mult:74) of three restarts (k = 3, 8, 13: one per first-product form)
         within 2e-5 (relative) of the oracle's trace at every check both runs made.
     geometry: the H half-step with a workgroup's waves sharing the staged blocks (the bench's form, forced here through
-    NMFK_TARGET_WGS because 192 units x 1 lane tile would not fill the chip) and the default split of the loop range."""
+    NMFK_TARGET_WGS because 192 units x 1 lane tile would not fill the chip) and the default split of the loop range.
+    Round 4: the restarts of this matrix stop between 490 and 10000 iterations, so the retire-aware schedule re-plans the
+    sweep several times on the way (asserted); "static-schedule" is the same sweep with NMFK_REPLAN=0.  The traced restarts
+    are followed across the re-plans (NmfkRun::uid)."""
     fx, X = _stoprule_fixture(oracle)
     ks, R, seed = [int(k) for k in fx["ks"]], int(fx["nruns"]), int(fx["seed"])
     for key, val in dict(NMFK_HYB="1", NMFK_HYB_MINK="2", NMFK_HYB_PHASES="1").items():
         monkeypatch.setenv(key, val)
     if geometry == "shared-staging":
         monkeypatch.setenv("NMFK_TARGET_WGS", "64")
+    if geometry == "static-schedule":
+        monkeypatch.setenv("NMFK_REPLAN", "0")
     ctx.set_X(X)
     ctx.set_objective_trace(True)
     try:
@@ -213,6 +218,7 @@ def test_default_stop_rule_against_the_oracle_fixture(NMFk, ctx, oracle, geometr
                                                       return_details=True)
         info = ctx.last_sweep_info()
         assert info["mfma_group_units"] == len(ks) * R and info["merged_valu_groups"] == 0, info
+        assert (info["replans"] == 0) if geometry == "static-schedule" else (info["replans"] >= 2 and info["units_in_last_plan"] <= 96), info
         traces = {(k, r): ctx.objective_trace(ks.index(k), r) for k, r in [(3, 0), (8, 0), (13, 0)]}
     finally:
         ctx.set_objective_trace(False)

@@ -1152,7 +1152,8 @@ def test_robustkmeans_krange_and_cache(NMFk, ctx, oracle, tmp_path):
     from nmfk_jl_amd import resultio
 
     sc = resultio.load(str(tmp_path / "Hmatrix-3-5_60-10.jld"))["assignments"]
-    assert bool(sc["converged_"]) == r1["converged"] == r2["converged"] and r1["converged"] == oracle.robustkmeans_k(X, 3, 10)["converged"]
+    one = oracle.kmeans(X, 3, seed=0 + r1["best_repeat"])  # the winning repeat alone on the CPU
+    assert bool(sc["converged_"]) == r1["converged"] == r2["converged"] == one["converged"] and one["iterations"] == r1["iterations"]
     assert np.asarray(sc["centers_"]).shape == (5, 3) and len(sc["counts_"]) == len(sc["wcounts_"]) == 3
     capped = NMFk.robustkmeans(X, 3, 4, ctx=ctx, maxiter=1, save=True, resultdir=str(tmp_path), casefilename="cap")
     assert capped["iterations"] <= 1 and not capped["converged"]
@@ -1178,6 +1179,58 @@ def test_robustkmeans_rows_of_W_at_bench_size(NMFk, ctx, oracle):
         assert len(set(planted[r["assignments"] == c].tolist())) == 1
     one = oracle.kmeans(np.asfortranarray(Wt), k, seed=1 + r["best_repeat"])  # the winning repeat alone on the CPU
     assert one["totalcost"] == r["totalcost"]
+
+
+def test_retire_aware_schedule_on_a_small_sweep(NMFk, ctx, oracle, monkeypatch):
+    """Round 4: restarts retire at different iterations (Mult:64); the sweep is re-planned as they do --
+    the units still active move to the front of the work list and the launch geometry is re-derived for them
+    (nmfk_mu_sweep, "tiers"; NMFK_REPLAN=2 takes every tier whatever the sweep's size).  Planted rank-3 matrix 640 x 192,
+    k = 2:6 x 6 restarts, the reference's stop rule: against the static schedule (NMFK_REPLAN=0) the iteration counts are
+    equal for most restarts and the objectives agree to fp32 rounding; the monitored objective of a long restart follows
+    the static run's trace check by check ACROSS the re-plans; and the re-planned sweep reproduces itself bit for bit."""
+    n, m, k0 = 640, 192, 3
+    W0 = oracle.uniform_fill(9, 0, n * k0).reshape(n, k0)
+    H0 = oracle.uniform_fill(9, n * k0, k0 * m).reshape(k0, m)
+    X = np.asfortranarray((W0 @ H0 + 0.02 * oracle.uniform_fill(9, n * k0 + k0 * m, n * m).reshape(n, m)).astype(np.float32))
+    ctx.set_X(X)
+    ks, R = [2, 3, 4, 5, 6], 6
+    seeds = _seeds(NMFk, 4, ks, R)
+    out, info, trace = {}, {}, {}
+    ctx.set_objective_trace(True)
+    try:
+        for mode in ("0", "2", "2"):
+            monkeypatch.setenv("NMFK_REPLAN", mode)
+            res = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=3000)
+            if mode in out:  # the second re-planned sweep: the same bits
+                for k in ks:
+                    for key in ("W", "H", "objvalue", "iters", "reason"):
+                        assert (res[k][key] == out[mode][k][key]).all(), (k, key)
+                continue
+            out[mode], info[mode] = res, ctx.last_sweep_info()
+            trace[mode] = {(k, r): ctx.objective_trace(ks.index(k), r) for k in ks for r in range(R)}
+    finally:
+        ctx.set_objective_trace(False)
+    assert info["0"]["replans"] == 0 and info["0"]["launch_groups"] == 1, info["0"]
+    assert info["2"]["replans"] >= 2 and info["2"]["units_in_last_plan"] < len(ks) * R // 2, info["2"]
+    its0 = np.stack([out["0"][k]["iters"] for k in ks])
+    its2 = np.stack([out["2"][k]["iters"] for k in ks])
+    assert its0.min() < its0.max(), "the case must have restarts that retire at different iterations"
+    assert (its0 == its2).mean() >= 0.8, (its0, its2)
+    for k in ks:
+        np.testing.assert_allclose(out["2"][k]["objvalue"], out["0"][k]["objvalue"], rtol=2e-3)  # (different stop iterations: a few checks apart)
+        same = out["0"][k]["iters"] == out["2"][k]["iters"]
+        np.testing.assert_allclose(out["2"][k]["objvalue"][same], out["0"][k]["objvalue"][same], rtol=1e-5)
+    for key, t0 in trace["0"].items():  # every restart's monitored objective, check by check, across the re-plans
+        t2 = trace["2"][key]
+        nc = min(len(t0), len(t2))
+        assert nc >= 1 and abs(len(t0) - len(t2)) <= max(3, len(t0) // 5), (key, len(t0), len(t2))
+        np.testing.assert_allclose(t2[:nc], t0[:nc], rtol=2e-5, err_msg=str(key))
+    # and against the Float64 oracle under its own stop rule: a restart that ran long
+    k, r = max(((k, r) for k in ks for r in range(R)), key=lambda kr: out["2"][kr[0]]["iters"][kr[1]])
+    Wi, Hi = oracle.init_factors(int(seeds[ks.index(k), r]), n, m, k)
+    ref = oracle.singlerun(X, k, Wi, Hi, maxiter=3000)
+    assert abs(out["2"][k]["objvalue"][r] - ref["objvalue"]) <= 2e-3 * ref["objvalue"]
+    assert abs(int(out["2"][k]["iters"][r]) - ref["iters"]) <= max(50, ref["iters"] // 10)
 
 
 @pytest.mark.parametrize("forced_merged_kernel", [False, True])

@@ -29,7 +29,7 @@ PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 
 
-TRAFFIC_FILES = ("profiles/r03/traffic.json", "profiles/r02/traffic.json")
+TRAFFIC_FILES = ("profiles/r04/traffic.json", "profiles/r03/traffic.json", "profiles/r02/traffic.json")
 
 
 def _pmc_traffic():
@@ -103,6 +103,78 @@ def cpu_baseline(X, ks, nruns, iters_by_k, threads):
                 sec_per_iter={str(k): per_iter[k] for k in sample_ks}, extrapolated_sweep_seconds=total)
 
 
+def planted_matrix(ctx, n, m, k0=6, seed=2, noise=0.01, scale=1.0):
+    """X = scale * (W0 H0 + noise * U), W0 in U(0,1)^{n x k0}, H0 in U(0,1)^{k0 x m}."""
+    W0 = ctx.fill_uniform(seed, 0, n * k0).reshape(k0, n).T.astype(np.float64)
+    H0 = ctx.fill_uniform(seed, n * k0, k0 * m).reshape(m, k0).T.astype(np.float64)
+    U = ctx.fill_uniform(seed, n * k0 + k0 * m, n * m).reshape(m, n).T.astype(np.float64)
+    return np.asfortranarray((scale * (W0 @ H0 + noise * U)).astype(np.float32))
+
+
+def secondary_cfg4(NMFk, ctx, iters=100):
+    """BASELINE configs[3]: sparse 0.5 %-fill fp32 X 100000 x 4096, k = 2:32, nruns = 16 (496 factorizations), a fixed budget
+    of `iters` MU iterations with the check block every 10th.  Algorithmic bytes: 2*nnz*8 B + 4*(n+m)*k*4 B per
+    iteration and factorization; time = GPU time of the MU loop (HIP events)."""
+    import scipy.sparse as sp
+
+    n, m, fill, R = 100000, 4096, 0.005, 16
+    rng = np.random.default_rng(3)
+    nnz = int(n * m * fill)
+    Xs = sp.csc_matrix((rng.uniform(1, 5, nnz).astype(np.float32), (rng.integers(0, n, nnz), rng.integers(0, m, nnz))), shape=(n, m))
+    Xs.sum_duplicates()
+    ctx.set_profiling(False)
+    ctx.set_X_sparse(Xs)
+    ks = list(range(2, 33))
+    seeds = np.array([[NMFk.run_seed(1, k, r) for r in range(R)] for k in ks], dtype=np.uint64)
+    ctx.mu_sweep(ks, R, seeds=seeds, maxiter=10, maxbaditers=10 ** 9)
+    ctx.set_profiling(True)
+    ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, maxbaditers=10 ** 9)
+    loop = ctx.get_profile()["mu_loop"]
+    ctx.set_profiling(False)
+    ms = loop["ms"] / iters
+    bytes_iter = float(sum((2 * ctx.nnz * 8 + 4 * (n + m) * k * 4) * R for k in ks))
+    gbps = bytes_iter / (ms * 1e-3) / 1e9
+    return {"workload": f"sparse {fill:.1%}-fill fp32 X {n}x{m} ({ctx.nnz} non-zeros), k=2:32, nruns={R}: {len(ks) * R} factorizations, "
+                        f"{iters} MU iterations (fixed budget, objective + check block every 10th)",
+            "ms_per_iter": ms, "GBps_algorithmic": gbps, "frac_hbm": gbps / PEAK_HBM_GBPS, "bound": "hbm", "peak_GBps": PEAK_HBM_GBPS,
+            "algorithmic_bytes_per_iter": bytes_iter,
+            "kernel": "sp_blk_kernel<NC> (nmfk_step_impl.h; sliced ELL, one lane element per lane, the gathered factor through LDS) "
+                      "for both half-steps of every rank <= 32",
+            "profile": "profiles/r04/secondary_cfg4_cfg5_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/r4_secondary.py)"}
+
+
+def secondary_cfg5(NMFk, ctx, iters=40):
+    """BASELINE configs[4] shape: dense fp32 X 65536 x 2048, k = 64, 8 restarts (one GPU's share of the 64), fixed budget.
+    Algorithmic flops 8*n*m*k per iteration and factorization over the GPU time of the MU loop (objective + check block
+    every 10th iteration included)."""
+    n, m, k, R = 65536, 2048, 64, 8
+    X = ctx.fill_uniform(4, 0, n * m).reshape(m, n).T
+    ctx.set_profiling(False)
+    ctx.set_X(X)
+    del X
+    seeds = np.array([[NMFk.run_seed(1, k, r) for r in range(R)]], dtype=np.uint64)
+    ctx.mu_sweep([k], R, seeds=seeds, maxiter=2, maxbaditers=10 ** 9)
+    ctx.set_profiling(True)
+    ctx.mu_sweep([k], R, seeds=seeds, maxiter=iters, maxbaditers=10 ** 9)
+    prof = ctx.get_profile()
+    ctx.set_profiling(False)
+    loop = prof["mu_loop"]
+    ms = loop["ms"] / iters
+    tf = 8.0 * n * m * k * R / (ms * 1e-3) / 1e12
+    halves = {nm: {"avg_launch_ms": v["ms"] / v["launches"], "TFLOPs": v["flops"] / (v["ms"] * 1e-3) / 1e12}
+              for nm, v in prof.items() if nm.startswith(("h_step", "w_step")) and v["launches"]}
+    # the k = 64 kernel runs W*H as 12 bf16 MFMAs of 16 cycles and the numerators as 16 fp32 MFMAs of 32 per 16 x 16 tile and
+    # 16 loop steps: 704 matrix cycles where the all-fp32 formulation the peak is quoted for needs 1024
+    return {"workload": f"dense U(0,1) fp32 X {n}x{m}, k={k}, {R} restarts, {iters} MU iterations (fixed budget, objective + check block every 10th)",
+            "ms_per_iter": ms, "TFLOPs_algorithmic": tf, "frac_fp32_peak": tf / PEAK_FP32_TFLOPS, "bound": "mfma", "peak_TFLOPs": PEAK_FP32_TFLOPS,
+            "matrix_pipe_occupancy": tf / PEAK_FP32_TFLOPS * 704.0 / 1024.0,
+            "matrix_pipe_occupancy_note": "derived: algorithmic rate x (704 matrix cycles the split-operand form issues per tile / 1024 of "
+                                          "the all-fp32 form the peak is quoted for); counters: profiles/r04",
+            "half_steps": halves,
+            "kernel": "wide2_step_kernel<4,2,false> (nmfk_step_hyb.hip: W*H from three-term bf16 splits, numerators in fp32 MFMAs)",
+            "profile": "profiles/r04/secondary_cfg4_cfg5_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/r4_secondary.py)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +190,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-kopt-check", action="store_true", help="skip the planted-matrix 'same kopt' sweeps after the timed region")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the cfg4 (sparse) / cfg5 (k = 64) measurements after the timed region")
+    ap.add_argument("--loopback", action="store_true",
+                    help="REHEARSAL of the N > 1 path on ONE GPU: --gpus N logical ranks in this one process through libnmfk_hip's "
+                         "loopback transport (nmfk_multi_create_loopback): shard plan, padding, status agreement, all-gather layout "
+                         "and delivery are the code RCCL runs; the number is not a multi-GPU measurement")
     args = ap.parse_args()
 
     import torch
@@ -140,10 +217,15 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus or (args.loopback and world == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     ks = list(range(args.kmin, args.kmax + 1))
-    ctx = NMFk.Context(local)
+    multi = None
+    if args.loopback and args.gpus > 1:
+        multi = NMFk.Multi(args.gpus, loopback=True, device=local)
+        ctx = NMFk.parallel.attach_multi(multi)
+    else:
+        ctx = NMFk.Context(local)
     # synthetic X: U(0,1) from the library's portable generator (identical on every rank: the host copy only gives
     # execute() its shape); the DEVICE copy every rank computes on comes from rank 0 over RCCL
     X = np.asfortranarray(ctx.fill_uniform(1, 0, args.n * args.m).reshape(args.m, args.n).T)
@@ -160,6 +242,8 @@ def main():
     elif world > 1:  # CPU-side rehearsal of the sharding logic (gloo): torch.distributed carries the data
         X = np.asfortranarray(NMFk.parallel.broadcast_X(X if rank == 0 else None))
         ctx.set_X(X)
+    elif multi is not None:
+        multi.set_X(X)  # every logical rank's context holds X (nmfk_multi_set_X: the broadcast of the loopback transport)
     else:
         ctx.set_X(X)  # X resident in HBM (column-major + row-major copies) before the timed region
 
@@ -207,7 +291,9 @@ def main():
             "config": {"workload": f"dense U(0,1) fp32 X {args.n}x{args.m}, k={args.kmin}:{args.kmax}, nruns={args.nruns} "
                                    f"(BASELINE.json configs[2] / north-star 1-GPU target; {nfact} factorizations per step)",
                        "stop_rule": f"reference defaults: maxiter={args.maxiter}, tol=1e-19, tolOF=1e-3, maxbaditers=10, maxreattempts=2",
-                       "parallelism": f"restarts sharded over {world} rank(s)" + (" (C ABI: nmfk_comm_* / RCCL)" if comm else ""),
+                       "parallelism": (f"REHEARSAL: restarts sharded over {args.gpus} LOGICAL ranks on one GPU (loopback transport of "
+                                       f"libnmfk_hip, nmfk_multi_*); not a multi-GPU measurement" if multi is not None else
+                                       f"restarts sharded over {world} rank(s)" + (" (C ABI: nmfk_comm_* / RCCL)" if comm else "")),
                        "kopt": kopt,
                        "mean_iterations_per_factorization": total_iters / nfact},
         }
@@ -270,28 +356,72 @@ def main():
                     "x_GBps_note": "on-die figure (L2 / Infinity Cache), not HBM traffic",
                 }
             line["config"]["schedule"] = ctx.last_sweep_info()
-        if not args.no_kopt_check and world == 1 and (args.n, args.m, args.kmin, args.kmax, args.nruns) == (8192, 512, 2, 16, 32):
+        if not args.no_kopt_check and world == 1 and multi is None and (args.n, args.m, args.kmin, args.kmax, args.nruns) == (8192, 512, 2, 16, 32):
             # "same kopt" half of the metric, outside the timed region: SURVEY 8d's planted rank-6 matrix through the same
             # sweep in fp32 (the product) and in fp64 compute (the reference's arithmetic and stop decisions,
             # oracle-verified by tests/test_gpu_parity.py::test_stop_rule_fp64_identical_iterations)
             k0 = 6
-            W0 = ctx.fill_uniform(2, 0, args.n * k0).reshape(k0, args.n).T.astype(np.float64)
-            H0 = ctx.fill_uniform(2, args.n * k0, k0 * args.m).reshape(args.m, k0).T.astype(np.float64)
-            U = ctx.fill_uniform(2, args.n * k0 + k0 * args.m, args.n * args.m).reshape(args.m, args.n).T.astype(np.float64)
-            Xp = np.asfortranarray((W0 @ H0 + 0.01 * U).astype(np.float32))
             ctx.set_profiling(False)
+
+            def planted_sweep(Xp, nruns=args.nruns, **kw):
+                t = time.perf_counter()
+                o = NMFk.execute(Xp, ks, nruns, load=False, save=False, quiet=True, seed=2, ctx=ctx, return_details=True, **kw)
+                sec = time.perf_counter() - t
+                its = np.concatenate([o[6][k]["iters"] for k in ks]).astype(np.float64)
+                return dict(kopt=o[5], seconds=sec, factorizations_per_s=len(ks) * nruns / sec, mean_iterations=float(its.mean()),
+                            min_iterations=int(its.min()), max_iterations=int(its.max()),
+                            active_unit_fraction=float(its.sum() / (its.max() * len(its))), schedule=ctx.last_sweep_info())
+
+            Xp = planted_matrix(ctx, args.n, args.m, k0)
             ctx.set_X(Xp)
-            kp32 = NMFk.execute(Xp, ks, args.nruns, load=False, save=False, quiet=True, seed=2, ctx=ctx)[5]
-            kp64 = NMFk.execute(Xp, ks, args.nruns, load=False, save=False, quiet=True, seed=2, ctx=ctx, compute="f64")[5]
-            line["config"]["kopt_planted"] = kp32
-            line["config"]["kopt_planted_f64_mode"] = kp64
+            p32 = planted_sweep(Xp)
+            # (fp64 compute: 8 restarts per rank -- the packed-VALU fp64 kernels take 63 s for all 32, and the full-size agreement
+            #  of the two modes is tests/test_gpu_fullsize.py::test_planted_rank6_same_kopt_at_metric_size)
+            p64 = planted_sweep(Xp, compute="f64", nruns=8)
+            line["config"]["kopt_planted"] = p32["kopt"]
+            line["config"]["kopt_planted_f64_mode"] = p64["kopt"]
             line["config"]["kopt_planted_expected"] = k0
+            # Structured data on which the restarts RETIRE (the bench matrix and the matrix above run nearly every restart to
+            # maxiter): the stop rule's tolOF = 1e-3 is an absolute improvement of the sum of squares (Mult:24, 81), so the same
+            # planted matrix with its entries scaled to ~0.15 (X = 0.1 * (W0 H0 + 0.01 U)) stagnates between 1 000 and 10 000
+            # iterations.  Same sweep with the retire-aware schedule (default) and with the static one (NMFK_REPLAN=0).
+            Xs = planted_matrix(ctx, args.n, args.m, k0, scale=0.1)
+            ctx.set_X(Xs)
+            ps = planted_sweep(Xs)
+            os.environ["NMFK_REPLAN"] = "0"
+            try:
+                ps0 = planted_sweep(Xs)
+            finally:
+                del os.environ["NMFK_REPLAN"]
+            line["config"]["planted"] = {
+                "matrix": f"X = W0 H0 + 0.01 U (rank {k0}, {args.n}x{args.m}; SURVEY 8d), k={args.kmin}:{args.kmax}, nruns={args.nruns}, "
+                          "default stop rule, whole execute() incl. clustering",
+                **{k_: p32[k_] for k_ in ("kopt", "seconds", "factorizations_per_s", "mean_iterations", "min_iterations", "max_iterations",
+                                           "active_unit_fraction")},
+                "f64_mode": {"nruns": 8, "kopt": p64["kopt"], "seconds": p64["seconds"]},
+                "retiring": {"matrix": "X = 0.1 * (W0 H0 + 0.01 U): the same matrix scaled so that the ABSOLUTE tolOF = 1e-3 of the "
+                                       "reference's stop rule (Mult:24, 81) retires restarts between 1 000 and 10 000 iterations",
+                             **ps, "static_schedule_seconds": ps0["seconds"], "static_schedule_kopt": ps0["kopt"],
+                             "speedup_of_the_retire_aware_schedule": ps0["seconds"] / ps["seconds"]},
+            }
+            ctx.set_X(X)
+        if not args.no_secondary and world == 1 and multi is None:
+            # the other two single-GPU BASELINE workloads, outside the timed region: driver-visible numbers
+            sec = {}
+            for name, fn in (("cfg4", secondary_cfg4), ("cfg5", secondary_cfg5)):
+                try:
+                    sec[name] = fn(NMFk, ctx)
+                except Exception as e:  # noqa: BLE001  (the headline line must not be lost to a secondary measurement)
+                    sec[name] = {"error": repr(e)}
+            line["secondary"] = sec
             ctx.set_X(X)
         if not args.no_cpu_baseline:
             threads = min(32, len(os.sched_getaffinity(0)))
             line["cpu_baseline"] = cpu_baseline(X, ks, args.nruns, iters_by_k, threads)
             line["cpu_baseline"]["reference_julia"] = julia_reference_baseline(args.n, args.m, ks, args.nruns)
         print(json.dumps(line))
+    if multi is not None:
+        multi.close()
     if world > 1:
         dist.barrier()
         if comm is not None:

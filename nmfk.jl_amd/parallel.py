@@ -33,6 +33,27 @@ def attach(ctx):
     return comm
 
 
+class _MultiAdapter:
+    """`Comm.mu_sweep`'s interface on a _lib.Multi (one process, one host thread per rank inside libnmfk_hip)."""
+
+    def __init__(self, multi):
+        self.multi = multi
+
+    def mu_sweep(self, ks, nruns, seeds=None, Winit=None, Hinit=None, params=None, need_W=True, **kw):
+        return self.multi.mu_sweep(ks, nruns, seeds=seeds, Winit=Winit, Hinit=Hinit, params=params, **kw)
+
+    def close(self):
+        pass
+
+
+def attach_multi(multi):
+    """execute(..., ctx=multi.ctx0) then runs its sweeps through nmfk_multi_sweep: the restarts sharded over the ranks of the
+    Multi (GPUs, or the logical ranks of the loopback transport), results delivered to the caller, clustering on rank 0's
+    context.  The one-process form of the N > 1 path (`NMFkHIP.execute(...; ngpus = N)` on the Julia side)."""
+    _comms[id(multi.ctx0)] = _MultiAdapter(multi)
+    return multi.ctx0
+
+
 def comm_of(ctx):
     return _comms.get(id(ctx))
 

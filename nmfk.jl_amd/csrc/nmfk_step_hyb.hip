@@ -30,30 +30,6 @@
 #include <algorithm>
 #include <type_traits>
 
-// Timing ablations for scripts/r3_ablate.sh (WRONG results; never set in the product build): 1 = X entries loaded once, not
-// per chunk; 2 = the loop factor staged once (first block only); 4 = no reciprocal; 8 = no second product; 16 = no barriers;
-// resident form: 32 = no chunk loop (a tile pair's prologue and finish only), 64 = no prologue / finish work (constant operand
-// blocks, nothing loaded or stored per tile pair), 128 = no X loads inside the chunk loop
-#ifndef NMFK_HYB_PIPE
-#define NMFK_HYB_PIPE 1  // the resident form's chunk loop as a software pipeline (see hyb_res_body)
-#endif
-#ifndef NMFK_HYB_SKEW
-#define NMFK_HYB_SKEW 1  // the streaming form's chunk skewed by lane tile (see hyb_step_body's trip)
-#endif
-#ifndef NMFK_HYB_AOLD_EARLY
-#define NMFK_HYB_AOLD_EARLY 1
-#endif
-#ifndef NMFK_HYB_STAMP
-#define NMFK_HYB_STAMP 0  // 1: wave 0 of workgroup (0, 0) times the segments of the streaming chunk with s_memtime and prints them
-#endif
-#if NMFK_HYB_STAMP
-#define HYB_STAMP(i) do { const uint64_t t_ = __builtin_readcyclecounter(); stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } while (0)
-#else
-#define HYB_STAMP(i) do { } while (0)
-#endif
-#ifndef NMFK_HYB_ABLATE
-#define NMFK_HYB_ABLATE 0
-#endif
 #ifndef NMFK_HYB_CPB
 #define NMFK_HYB_CPB 4  // chunks of 16 loop steps per staged block of a workgroup (one barrier per block)
 #endif
@@ -66,11 +42,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
-#if NMFK_HYB_ABLATE & 16
-#define HYB_BARRIER() ((void)0)
-#else
 #define HYB_BARRIER() __syncthreads()
-#endif
 __device__ __forceinline__ float hyb_div(float x, float p) { return x * __builtin_amdgcn_rcpf(p); }
 
 // term blocks of the first product: MFMA j, k-lane group g -> split index (0 = h, 1 = m, 2 = l) of the loop factor
@@ -204,14 +176,6 @@ struct HybStage {
   // right behind the load made the compiler wait for vmcnt(0) on the spot, X prefetches included).
   __device__ __forceinline__ void load(int row0, float (&v)[NI][2], int &vrow0) const {
     vrow0 = row0;
-#if NMFK_HYB_ABLATE & 2048  // no loads: defined values instead (the conversion and the LDS writes stay whole)
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      v[i][0] = __builtin_bit_cast(float, 0x3f800000u + voff[i] + (uint32_t)row0);
-      v[i][1] = __builtin_bit_cast(float, 0x3f900000u + voff[i] + (uint32_t)row0);
-    }
-    return;
-#endif
 #pragma unroll
     for (int i = 0; i < NI; ++i) {  // (threads without an item load item 0 again and drop it)
       v[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[i], row0 * rowbytes, 0));
@@ -220,12 +184,6 @@ struct HybStage {
   }
   // rows past the factor's end and padding signals become zeros
   __device__ __forceinline__ void write(char *dst, const float (&vin)[NI][2], int vrow0) const {
-#if NMFK_HYB_ABLATE & 1024  // no conversion, no LDS writes -- but the loads stay alive: their values reach memory if they are NaN
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-      if (vin[i][0] != vin[i][0] || vin[i][1] != vin[i][1]) *(volatile float *)dst = vin[i][0];
-    return;
-#endif
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       if (NITEM % GT != 0 && !pv[i]) continue;
@@ -401,9 +359,6 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
   for (int t = 0; t < NT; ++t) xoff[t] = (uint32_t)(((int64_t)min((l0 >> 4) + t, nL16 - 1) * nD16 * 256 + lane * 4) * 4);
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)Xt, 0, -1, 0x00020000);
   auto xload = [&](int dch, f32x4_t (&xv)[NT]) __attribute__((always_inline)) {
-#if NMFK_HYB_ABLATE & 1
-    if (dch > d0 + 16) return;
-#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       xv[t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, xoff[t], dch * 64, 0));
@@ -452,11 +407,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; r += 2) {  // (pairs: one v_pk_mul_f32 for two ratios)
-#if NMFK_HYB_ABLATE & 4
-        const f32x2_t rc = {p[t][r], p[t][r + 1]};
-#else
         const f32x2_t rc = {__builtin_amdgcn_rcpf(p[t][r]), __builtin_amdgcn_rcpf(p[t][r + 1])};
-#endif
         const f32x2_t q2 = (f32x2_t){xcur[t][r], xcur[t][r + 1]} * rc;
         q[t][r] = q2.x;
         q[t][r + 1] = q2.y;
@@ -465,11 +416,6 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           q[t][r + 1] = (dch + 4 * g + r + 1 < d1) ? q[t][r + 1] : 0.0f;
         }
       }
-#if NMFK_HYB_ABLATE & 8
-#pragma unroll
-    for (int t = 0; t < NT; ++t) accs[t][0] += q[t];
-    return;
-#endif
     if (NS > 0) {
       // block (g, c16 >> 2) of the instruction: signals 4 sn + (lane & 3) of loop step 4g + r (A operand) x the ratios of
       // the block's four lane elements (B operand) -> accs[t][sn][i] += b[4g + r][4 sn + i] * q[4g + r][lane element]
@@ -555,6 +501,9 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
   // The loop.  TRIP chunks per trip of the (unrolled) body so that the LDS buffer of a block and the register set of
   // a chunk's X entries are compile-time constants; X runs two chunks ahead in four register sets, the next block of
   // the loop factor is fetched while a block is computed and written to the free LDS buffer at the block's end.
+  // (Round 4: the blocks ready-made from an operand IMAGE of the factor in HBM, staged by LDS-DMA with no registers, no
+  //  conversion and no LDS writes -- built, parity-green, and exactly as fast: H half-step of the bench sweep 0.684 vs 0.682 ms,
+  //  profiles/r04/operand_image_dma.txt.  The staging INSTRUCTIONS are not what the half-step waits for.)
   auto run = [&](auto stage, char *sb, auto barrier) __attribute__((always_inline)) {
     typedef decltype(stage) ST;
     constexpr int CPB = (ST::NITEM / (16 * ST::PPR));
@@ -579,15 +528,11 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     if (nchunks > CPB) stage.load(d0 + 16 * CPB, sv[1], svrow[1]);
     stage.write(sb, sv[0], svrow[0]);
     barrier();
-    // one trip; FULLT: every chunk of the trip exists, every block of it has a successor after next and no chunk touches
-    // the end of the loop range -> no guards in the unrolled body
-#if NMFK_HYB_STAMP
-    uint64_t stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_readcyclecounter();
-    uint32_t stamp_n = 0;
-#endif
     u32x4_t avn[NM];  // first-product operands of the next chunk, see trip()
 #pragma unroll
     for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(sb + fofs[j]);
+    // one trip; FULLT: every chunk of the trip exists, every block of it has a successor after next and no chunk touches
+    // the end of the loop range -> no guards in the unrolled body
     auto trip = [&](int c0, auto full_tag) __attribute__((always_inline)) {
       constexpr bool FULLT = decltype(full_tag)::value;
       // the first product's operands of the NEXT chunk of a block are read from LDS right behind this chunk's first
@@ -600,19 +545,16 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
         if (!FULLT && c >= nchunks) break;
         const int dch = d0 + 16 * c;
         const int buf = (ci / CPB) & 1, ch = ci % CPB;  // block parity (trips hold an even number of blocks)
-        HYB_STAMP(5);  // (loop overhead between chunks)
         const bool more = FULLT || (c - ch + CPB < nchunks);       // a block follows the one this chunk belongs to
         const bool more2 = FULLT || (c - ch + 2 * CPB < nchunks);  // and one after that
         xload(FULLT ? dch + 32 : min(dch + 32, dlast), xr[(ci + 2) & 3]);
         // (vmcnt retires in order: the staging requests go out AFTER this chunk's X prefetch)
-        if (ch == 0 && more2 && !(NMFK_HYB_ABLATE & (2 | 512))) stage.load(dch + 32 * CPB, sv[buf], svrow[buf]);
-        HYB_STAMP(6);  // X (and staging) requests issued
+        if (ch == 0 && more2) stage.load(dch + 32 * CPB, sv[buf], svrow[buf]);
         // the next block (requested a block ago) goes to the free LDS buffer BEFORE this block's last chunk: conversion
         // and LDS writes overlap with that chunk's matrix work instead of sitting in front of the barrier
         const bool last_of_block = ch == CPB - 1 || (!FULLT && c == nchunks - 1);
-        if (last_of_block && more && !(NMFK_HYB_ABLATE & (2 | 256))) stage.write(sb + (buf ^ 1) * ST::STB, sv[buf ^ 1], svrow[buf ^ 1]);
+        if (last_of_block && more) stage.write(sb + (buf ^ 1) * ST::STB, sv[buf ^ 1], svrow[buf ^ 1]);
         __builtin_amdgcn_sched_barrier(0);  // loads stay in front of the arithmetic they overlap with
-        HYB_STAMP(7);  // conversion + LDS writes of the next block (a block's last chunk only; waits for the staged rows)
         // The block's barrier sits HERE, in front of its last chunk's arithmetic: every wave has written its part of
         // the next block and has fetched its last operands of this one (the second product's block below; the first
         // product's came with the previous chunk), so this buffer is free for the block after next and the last chunk
@@ -624,10 +566,8 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           bn[sn] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
           if (!OBJ) bn[sn] = *(const f32x4_t *)(b + nofs + sn * 64 + ch * ST::CHT);
         }
-        HYB_STAMP(8);  // second product's operand requested
         if (last_of_block) barrier();
-        HYB_STAMP(0);  // X / staging requests, conversion + LDS writes of the next block, second product's operand, barrier
-        if (!OBJ && NMFK_HYB_SKEW) {
+        if (!OBJ) {
           // The chunk's work skewed by lane tile (no register more): P(t0) | P(t1) + ratios(t0) | second product(t0) +
           // ratios(t1) | second product(t1).  The reciprocals of a tile wait only for that tile's first product, so they
           // issue in the free vector slots of the other tile's matrix instructions instead of behind all of them.
@@ -638,7 +578,6 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           const bool mask = !FULLT && dch + 16 > d1;
           p_tile(0, av, p);
           __builtin_amdgcn_sched_barrier(0);
-          HYB_STAMP(1);  // first product of tile 0
 #pragma unroll
           for (int t = 1; t < NT; ++t) {
             __builtin_amdgcn_sched_barrier(0);
@@ -646,7 +585,6 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
             q_tile(t - 1, dch, xr[ci & 3], p, q, mask);
           }
           __builtin_amdgcn_sched_barrier(0);
-          HYB_STAMP(2);  // first product of tile 1 + ratios of tile 0
           if (FULLT || c + 1 < nchunks) {  // (a following chunk at a block's end means a following block: `more`)
             const char *bnx = ch + 1 < CPB ? b + (ch + 1) * ST::CHP : sb + (buf ^ 1) * ST::STB;
 #pragma unroll
@@ -655,17 +593,12 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           q_tile(NT - 1, dch, xr[ci & 3], p, q, mask);
           f_tile(0, bn, q);
           __builtin_amdgcn_sched_barrier(0);
-          HYB_STAMP(3);  // next operands, ratios of tile 1, second product of tile 0
 #pragma unroll
           for (int t = 1; t < NT; ++t) {
             __builtin_amdgcn_sched_barrier(0);
             f_tile(t, bn, q);
           }
           __builtin_amdgcn_sched_barrier(0);
-          HYB_STAMP(4);  // second product of tile 1
-#if NMFK_HYB_STAMP
-          ++stamp_n;
-#endif
         } else {
           u32x4_t av[NM];
 #pragma unroll
@@ -688,13 +621,6 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     int c0 = 0;
     for (; c0 + TRIP + AHEAD <= nchunks; c0 += TRIP) trip(c0, std::true_type());
     for (; c0 < nchunks; c0 += TRIP) trip(c0, std::false_type());
-#if NMFK_HYB_STAMP
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-      printf("stamp KS=%d chunks=%u ticks/chunk: requests %.1f | stage.write %.1f | bn %.1f | barrier %.1f | P(t0) %.1f | P(t1)+Q(t0) %.1f | avn+Q(t1)+F(t0) %.1f | F(t1) %.1f | loop %.1f\n", KS, stamp_n,
-             (double)stamp_acc[6] / stamp_n, (double)stamp_acc[7] / stamp_n, (double)stamp_acc[8] / stamp_n, (double)stamp_acc[0] / stamp_n,
-             (double)stamp_acc[1] / stamp_n, (double)stamp_acc[2] / stamp_n, (double)stamp_acc[3] / stamp_n, (double)stamp_acc[4] / stamp_n,
-             (double)stamp_acc[5] / stamp_n);
-#endif
   };
   if (OBJ) {
     HybStage<KS, NMFK_HYB_CPB, 64 * NW, 0> stage;
@@ -959,19 +885,9 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
       const int l = (tp * NT + t) * 16 + c16;
       lv[t] = l < L;
       lt[t] = lv[t] ? l : L - 1;
-#if !(NMFK_HYB_ABLATE & 64)
       nrow[t] = hyb_lane_rows<KS>(A, k, lt[t], g);
-#endif
     }
-#if NMFK_HYB_ABLATE & 64
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int j = 0; j < NM; ++j) bop[t][j] = __builtin_bit_cast(bf16x8_t, (u32x4_t){0x3f803f80u + (uint32_t)lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
-    if (false) {
-#else
     if (k == KS && (tp * NT + NT) * 16 <= L) {  // (wave-uniform) whole tiles of full-width rows: nothing to mask
-#endif
 #pragma unroll
       for (int t = 0; t < NT; ++t) hyb_lane_blocks_from<KS, NM>(nrow[t], k, true, g, bop[t], true);
     } else {
@@ -996,12 +912,10 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
 #pragma unroll
       for (int ci = 0; ci < 4; ++ci) {
         const int c = c0 + ci;
-#if !(NMFK_HYB_ABLATE & 128)
         if (TAIL && ci >= 2)
           xload(xn, ci - 2, xr[(ci + 2) & 3]);
         else
           xload(xo, c + 2, xr[(ci + 2) & 3]);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         f32x4_t bn[NSA];
         if (!OBJ) {
@@ -1071,7 +985,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
     // finished a trip earlier) issue in the free vector slots of those matrix instructions instead of behind them.
     // pc: W*H of the chunk whose ratios are due; avn: the operands of the chunk after it.
     f32x4_t pc[NT];
-    if (!OBJ && NMFK_HYB_PIPE) {
+    if (!OBJ) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) pc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1144,35 +1058,19 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-#if !(NMFK_HYB_ABLATE & 32)
-    if (!OBJ && NMFK_HYB_PIPE) {
+    if (!OBJ) {
       for (int c0 = 0; c0 + 4 < nch; c0 += 4) trip_pipe(c0, std::false_type());
-#if NMFK_HYB_AOLD_EARLY
       load_aold();  // the finish's old values: requested a trip ahead of their use
-#endif
       trip_pipe(nch - 4, std::true_type());
     } else {
       for (int c0 = 0; c0 + 4 < nch; c0 += 4) trip(c0, std::false_type());
       trip(nch - 4, std::true_type());
     }
-#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t) xo[t] = xn[t];
 
     if (OBJ) continue;
     // ---- the tile pair's finish: A_new = A .* numerator ./ sum(B) (Mult:67 / Mult:70), sums of A_new per lane
-#if NMFK_HYB_ABLATE & 64
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int sn = 0; sn < NSA; ++sn) vsf[0] += accs[t][sn][0] + accs[t][sn][1] + accs[t][sn][2] + accs[t][sn][3];
-    continue;
-#endif
-#if !NMFK_HYB_AOLD_EARLY
-    load_aold();
-#else
-    if (OBJ || !NMFK_HYB_PIPE) load_aold();
-#endif
     float vsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {

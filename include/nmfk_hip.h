@@ -272,6 +272,20 @@ int nmfk_get_objective_trace(nmfk_ctx *ctx, int kidx, int restart, double *out, 
 int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *total_ms, int64_t *launches,
                      double *flops, int *count);
 
+/* Environment variables the library reads (at the start of every sweep; tests and A/B measurements -- the defaults are the
+ * product and need none of them):
+ *   NMFK_HYB          0 / 1: split-operand MFMA half-step off / on for the ranks >= NMFK_HYB_MINK (default: automatic)
+ *   NMFK_HYB_PHASES   0 / 1: the matrix-pipe ranks as ONE launch group that runs first (default: by sweep size)
+ *   NMFK_HYB_RES      0: no resident form of that half-step (short loop dimension: the loop factor in LDS)
+ *   NMFK_MERGE        g: the ranks <= 16 share g mixed-rank packed-VALU launch groups (default: by restarts per rank)
+ *   NMFK_MFMA_WIDE    0: ranks > 16 on the packed-VALU kernel;  NMFK_WIDE2 0: on the all-fp32 MFMA kernel only;
+ *   NMFK_MFMA_SSE     0: their monitored objective on the packed-VALU objective kernel
+ *   NMFK_REPLAN       0: static launch schedule (no re-planning as restarts retire); 2: re-plan at every tier (tests)
+ *   NMFK_SP_BLK       0: sparse X in the gather form only (no sliced-ELL copies are built); 2: blocked form whatever the size
+ *   NMFK_TARGET_WGS   workgroups a half-step launch should have before loop ranges are split (default 2 x CUs)
+ *   NMFK_STREAMS      concurrent launch-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1: host / GPU wait times on stderr
+ *   NMFK_RCCL_LIB     the RCCL shared object nmfk_comm_* loads (default: librccl.so.1 ...) */
+
 #ifdef __cplusplus
 }
 #endif

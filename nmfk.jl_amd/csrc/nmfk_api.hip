@@ -98,29 +98,29 @@ struct Sampler {
   }
 };
 
-// Schedule overrides for A/B measurements and tests (the defaults are the product): environment variables, read in this
-// ONE place at the start of every sweep (a sweep runs seconds; tests flip them between sweeps).
+// Schedule overrides for tests and A/B measurements (the defaults are the product; documented in include/nmfk_hip.h):
+// environment variables, read in this ONE place at the start of every sweep (a sweep runs seconds; tests flip them between
+// sweeps).
 //   NMFK_TARGET_WGS   workgroups a half-step launch should have before loop ranges are split (default 2 x CUs)
 //   NMFK_MFMA_WIDE    0: ranks > 16 on the packed-VALU kernel instead of the all-MFMA one
-//   NMFK_HYB          0 / 1: split-operand MFMA half-step off / on for the ranks >= NMFK_HYB_MINK (default: automatic)
-//   NMFK_HYB_GROUPS   mixed-rank launch groups of that kernel in merged sweeps (1)
-//   NMFK_MERGE        g: the ranks <= 16 share g mixed-rank packed-VALU launch groups (default: by restarts per rank)
-//   NMFK_HYB_PHASES   0 / 1: force the one-phase / two-phase sweep
-//   NMFK_MAX_WSPLIT   4 / 8: waves of a workgroup that may split a loop range
-//   NMFK_MFMA_SSE, NMFK_HYB_SSE   0: monitored objective of the MFMA groups on the packed-VALU objective kernel
-//   NMFK_STREAMS      concurrent rank-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1 prints the host's share of the loop
-//   NMFK_MERGE_PHASED 1: merged sweeps run their matrix-pipe groups first and the packed-VALU group behind them (default: side by side)
-//   NMFK_SP_BLK       0: sparse X: the W half-step in the gather form (default: column blocks of H staged in LDS)
 //   NMFK_WIDE2        0: ranks > 16 on the all-fp32 MFMA kernel only (default: split-operand first product where it pays)
+//   NMFK_MFMA_SSE     0: monitored objective of the ranks > 16 on the packed-VALU objective kernel
+//   NMFK_HYB          0 / 1: split-operand MFMA half-step off / on for the ranks >= NMFK_HYB_MINK (default: automatic)
+//   NMFK_HYB_PHASES   0 / 1: force the matrix-pipe ranks into one launch group that runs first (default: by sweep size)
 //   NMFK_HYB_RES      0: no resident form of the split-operand MFMA half-step (short loop dimension: the loop factor in LDS)
-//   NMFK_HYB_RES_TPW  pairs of lane tiles a wave of the resident form should walk (4)
-//   NMFK_REPLAN       0: no re-planning of the launch geometry as restarts retire (see "Retire-aware schedule" in nmfk_mu_sweep);
+//   NMFK_MERGE        g: the ranks <= 16 share g mixed-rank packed-VALU launch groups (default: by restarts per rank)
+//   NMFK_REPLAN       0: no re-planning of the launch geometry as restarts retire ("Retire-aware schedule" in nmfk_mu_sweep);
 //                     2: re-plan at every tier whatever the sweep's size (tests)
-//   NMFK_HYB_SMALL    0: ranks <= 8 keep the round-2 forms (packed-VALU / 16-signal MFMA) -- A/B switch for the 4x4x1 variants
+//   NMFK_SP_BLK       0: sparse X in the gather form only (also: no sliced-ELL copies are built); 2: blocked form whatever the size
+//   NMFK_STREAMS      concurrent rank-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1 prints the host's share of the loop
 struct Tuning {
-  int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, hyb_groups = 1, merge = -1, phases = -1, max_wsplit = 8;
-  int wide_sse = 1, hyb_sse = 1, streams = -1, host_timing = 0, merge_phased = 0, hyb_small = 1;
-  int hyb_res = 1, hyb_res_tpw = 4, wide2 = 1, sp_blk = 1, replan = 1;
+  int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, merge = -1, phases = -1;
+  int wide_sse = 1, streams = -1, host_timing = 0;
+  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1;
+  // (not knobs any more -- round 3's A/B switches with their measured settings: one mixed-rank matrix-pipe group, the waves of
+  //  a workgroup may split a loop range 8 ways, the small ranks on their own kernel variants, four pairs of lane tiles per
+  //  wave of the resident form, merged sweeps side by side)
+  static constexpr int hyb_groups = 1, max_wsplit = 8, hyb_sse = 1, merge_phased = 0, hyb_small = 1, hyb_res_tpw = 4;
 };
 Tuning read_tuning() {
   Tuning t;
@@ -132,25 +132,16 @@ Tuning read_tuning() {
   geti("NMFK_HYB", t.hyb);
   if (t.hyb > 1) t.hyb = 1;
   geti("NMFK_HYB_MINK", t.hyb_mink);
-  geti("NMFK_HYB_GROUPS", t.hyb_groups);
-  t.hyb_groups = std::max(1, t.hyb_groups);
   geti("NMFK_MERGE", t.merge);
   geti("NMFK_HYB_PHASES", t.phases);
-  geti("NMFK_MAX_WSPLIT", t.max_wsplit);
-  t.max_wsplit = t.max_wsplit >= 8 ? 8 : 4;
   geti("NMFK_MFMA_SSE", t.wide_sse);
-  geti("NMFK_HYB_SSE", t.hyb_sse);
   geti("NMFK_STREAMS", t.streams);
   if (t.streams >= 0) t.streams = std::max(1, std::min(64, t.streams));
   geti("NMFK_HOST_TIMING", t.host_timing);
-  geti("NMFK_MERGE_PHASED", t.merge_phased);
-  geti("NMFK_HYB_SMALL", t.hyb_small);
   geti("NMFK_WIDE2", t.wide2);
   geti("NMFK_SP_BLK", t.sp_blk);
   geti("NMFK_HYB_RES", t.hyb_res);
   geti("NMFK_REPLAN", t.replan);
-  geti("NMFK_HYB_RES_TPW", t.hyb_res_tpw);
-  t.hyb_res_tpw = std::max(1, t.hyb_res_tpw);
   return t;
 }
 
@@ -739,7 +730,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     // Round 3: the matrix-pipe kernel no longer pads a rank to 16 signals (nmfk_step_hyb.hip: one bf16 MFMA and 4x4x1
     // numerator blocks for k <= 4, two and eight for k <= 8), which puts EVERY rank <= 16 below its packed-VALU cost
     // (k = 2: ~1.5 vs 2.1 us per factorization and iteration at the reference shape, k = 8: ~2.2 vs 4.0): first rank 2.
-    // NMFK_HYB_SMALL=0 restores round 2's rule (first rank = break-even against the 16-signal form; 2 / 6 in merged sweeps).
+    // (Tuning::hyb_small = 0 is round 2's rule: first rank = break-even against the 16-signal form; 2 / 6 in merged sweeps.)
     const int mk = hyb_mink >= 0 ? hyb_mink
                    : T.hyb_small ? 2
                                  : (nruns <= 4 ? 2 : nruns <= 8 ? 6 : std::min(16, (int)ceil(k0)));
@@ -830,7 +821,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   auto tiles_of = [&](int k, int which, int L, int ws) { return tiles_of_res(k, which, L, ws, res_wgs); };
   const int max_ws = T.max_wsplit;
   // phases of a two-phase sweep run one after the other, so each gets the geometry that fills the chip with ITS units
-  // NMFK_MERGE_PHASED=1 (A/B switch): a merged sweep runs its matrix-pipe groups first and the mixed-rank packed-VALU group
+  // (Tuning::merge_phased, measured and left off: a merged sweep runs its matrix-pipe groups first and the mixed-rank packed-VALU group
   // behind them instead of side by side (slower: 140 vs 117 ms per 400 iterations at 4 restarts per rank).
   bool any_hyb_k = false;
   for (int q = 0; q < nk; ++q) any_hyb_k = any_hyb_k || use_hyb_k(ks[q]);

@@ -179,6 +179,32 @@ def test_sparse_cfg4_full_size(NMFk, ctx, oracle, monkeypatch):
 # split-operand MFMA half-step), 16 restarts, reference defaults (Mult:24, Exec:729); per-restart iteration counts
 # 490..10000, stop reasons stagnation and maxiter, kopt = 5.
 # ---------------------------------------------------------------------------------------------------------------------
+def test_config5_full_size_against_the_oracle(NMFk, ctx, oracle):
+    """BASELINE configs[4] at its own size against the ORACLE (the full-size cfg5 test so far was
+    property-only): 65536 x 2048, planted rank 48 + noise, k = 64, one restart, 3 MU iterations from identical initial
+    factors -- oracle.singlerun in Float64 on 8 host threads (about a CPU-minute) -- W*H on 4096 sampled rows and the
+    objective within the fp32 tolerance of SURVEY 8d (1e-4).  The GPU side is the split-operand wide-rank kernel
+    (wide2_step_kernel<4, 2>: W*H from three-term bf16 splits, numerators in fp32 MFMAs)."""
+    n, m, k = 65536, 2048, 64
+    W0 = ctx.fill_uniform(4, 0, n * 48).reshape(48, n).T
+    H0 = ctx.fill_uniform(5, 0, 48 * m).reshape(m, 48).T
+    X = (W0 @ H0 + 0.01 * ctx.fill_uniform(6, 0, n * m).reshape(m, n).T).astype(np.float32)
+    del W0, H0
+    ctx.set_X(X)
+    seed = NMFk.run_seed(4, k, 0)
+    res = ctx.mu_sweep([k], 1, seeds=np.array([[seed]], dtype=np.uint64), maxiter=3, **NOSTOP)[k]
+    assert ctx.last_sweep_info()["wide_mfma_units"] == 1
+    Wi, Hi = oracle.init_factors(int(seed), n, m, k)
+    ref = oracle.singlerun(X, k, Wi, Hi, maxiter=3, nthreads=8, **NOSTOP)
+    assert res["iters"][0] == ref["iters"] == 3
+    rows = np.arange(0, n, 16)
+    P = res["W"][0][rows].astype(np.float64) @ res["H"][0].astype(np.float64)
+    Pr = ref["W"][rows] @ ref["H"]
+    assert np.linalg.norm(P - Pr) <= 1e-4 * np.linalg.norm(X[rows].astype(np.float64))
+    assert abs(res["objvalue"][0] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
+    np.testing.assert_allclose(res["H"][0].sum(axis=1), 1.0, atol=1e-4)
+
+
 def _stoprule_fixture(oracle):
     import os
 

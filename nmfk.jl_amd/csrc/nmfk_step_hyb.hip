@@ -1169,8 +1169,12 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
   constexpr int CHP = 3 * NH * 256, CHT = NB * 4 * 256;  // bytes of a chunk's split planes / transposed blocks
   constexpr int BFB = CPB * CHP, STB = BFB + CPB * CHT;
   constexpr int PPR = KS / 2, NITEM = 16 * CPB * PPR, NI = NITEM / 512;  // staging items (row, signal pair) per thread
-  constexpr int NSUB = NB / 2;  // blocks of eight signals of the lane factor a lane needs per term (sub = g + 4 i)
-  static_assert(NB == 2 || NB == 4, "KS = 32 or 64");
+  constexpr int NSUB = NB == 3 ? 1 : NB / 2;  // blocks of eight signals of the lane factor a lane needs per term (sub = g + 4 i)
+  static_assert(NB == 2 || NB == 3 || NB == 4, "KS = 32, 48 or 64");
+  // NB = 3 (KS = 48, round 4): six blocks of eight signals do not divide over the four k-lane groups, so the 36 (term pair,
+  // block) groups are laid out as  MFMA j < 6: pair j, block g;  MFMA 6 + q (q < 3): pair 2q + (g >> 1), block 4 + (g & 1).
+  // A lane then needs block g in the three terms and block 4 + (g & 1) in two (pairs 0, 2, 4 want the lane factor's terms
+  // h, h, l -- k-lane groups 0, 1 --, pairs 1, 3, 5 want m, m, h -- groups 2, 3): five operand registers of 128 bits per tile.
   static_assert(NITEM % 512 == 0, "items divide evenly");
   const int u = u0 + blockIdx.y, bx = blockIdx.x;
   if (!(gp->force && !OBJ) && !state[u].active) return;
@@ -1190,6 +1194,7 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
 
   // lane-factor operand blocks: bopt[t][term][i] = signals [8 (g + 4 i), + 8) of row l in term `term`
   bf16x8_t bopt[NT][3][NSUB];
+  bf16x8_t bq01[NT], bq2[NT];  // (NB = 3) block 4 + (g & 1): the term of the MFMAs 6, 7 and of the MFMA 8
   int lt[NT];
   bool lv[NT];
 #pragma unroll
@@ -1197,6 +1202,35 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
     const int l = l0 + 16 * t + c16;
     lv[t] = l < L;
     lt[t] = lv[t] ? l : L - 1;
+    if (NB == 3) {
+      const int s0 = 8 * (4 + (g & 1));
+      const float *rp = A + (int64_t)lt[t] * kp + (s0 < kp ? s0 : 0);
+      const f32x4_t r0 = *(const f32x4_u *)rp, r1 = *(const f32x4_u *)(rp + 4);
+      u32x4_t hh, mm, ll;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int c = 2 * w + e;
+          v[e] = (lv[t] && s0 + c < kp) ? (c < 4 ? r0[c & 3] : r1[c & 3]) : 0.0f;
+        }
+        uint32_t h, m, lo;
+        split3_pair(v[0], v[1], h, m, lo);
+        hh[w] = h;
+        mm[w] = m;
+        ll[w] = lo;
+      }
+      const bool up = g >= 2;
+      u32x4_t w01, w2;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        w01[w] = up ? mm[w] : hh[w];
+        w2[w] = up ? hh[w] : ll[w];
+      }
+      bq01[t] = __builtin_bit_cast(bf16x8_t, w01);
+      bq2[t] = __builtin_bit_cast(bf16x8_t, w2);
+    }
 #pragma unroll
     for (int i = 0; i < NSUB; ++i) {
       const int s0 = 8 * (g + 4 * i);
@@ -1300,12 +1334,28 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
         f32x4_t p[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (NB == 3) {
 #pragma unroll
-        for (int j = 0; j < NM; ++j) {
-          const int tp = NB == 4 ? (j >> 1) : j, i = NB == 4 ? (j & 1) : 0;  // group G = 4j + g: term pair, block sub = g + 4 i
-          const bf16x8_t av = *(const bf16x8_t *)(cur + ch * CHP + (tA[tp] * NH + 4 * i + g) * 256 + c16 * 16);
+          for (int j = 0; j < 6; ++j) {  // pair j, block g
+            const bf16x8_t av = *(const bf16x8_t *)(cur + ch * CHP + (tA[j] * NH + g) * 256 + c16 * 16);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bopt[t][tB[tp]][i], p[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bopt[t][tB[j]][0], p[t], 0, 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {  // pair 2q + (g >> 1), block 4 + (g & 1): the loop factor's term is 0, 1, (g >> 1 ? 2 : 0)
+            const int ta = q < 2 ? q : (g >= 2 ? 2 : 0);
+            const bf16x8_t av = *(const bf16x8_t *)(cur + ch * CHP + (ta * NH + 4 + (g & 1)) * 256 + c16 * 16);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, q < 2 ? bq01[t] : bq2[t], p[t], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < NM; ++j) {
+            const int tp = NB == 4 ? (j >> 1) : j, i = NB == 4 ? (j & 1) : 0;  // group G = 4j + g: term pair, block sub = g + 4 i
+            const bf16x8_t av = *(const bf16x8_t *)(cur + ch * CHP + (tA[tp] * NH + 4 * i + g) * 256 + c16 * 16);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bopt[t][tB[tp]][i], p[t], 0, 0, 0);
+          }
         }
         const bool edge = dch + 16 > d1;
         if (OBJ) {  // residuals: squares of a chunk in fp32 (packed), the chunk's partial into the fp64 sum (see hyb_step_body)
@@ -1544,21 +1594,26 @@ void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double w
   hipLaunchKernelGGL((hyb_step_kernel<NT, NW, true>), grid, blk, ldsb, s, w.arena, w.Xalt, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
 }
 
-// Wide ranks on the split-operand first product (wide2_step_kernel): kp <= 32 (KS = 32) and kp >= 56 (KS = 64); at kp = 40, 48
-// the padding to 64 signals costs more than the split saves (measured at 65536 x 2048, k = 48: 7.39 vs 5.68 ms per
-// iteration of 8 restarts), those widths stay on mfma_wide_kernel.
-int nmfk_wide2_ok(int kp) { return (kp > 16 && kp <= 32) || (kp >= 56 && kp <= 64); }
+// Wide ranks on the split-operand first product (wide2_step_kernel): kp <= 32 (KS = 32), kp = 40, 48 (KS = 48, round 4: padded to
+// 64 signals those widths lost against the all-fp32 kernel -- k = 48: 7.39 vs 5.68 ms per iteration of 8 restarts at
+// 65536 x 2048) and kp >= 56 (KS = 64).
+int nmfk_wide2_ok(int kp) { return kp > 16 && kp <= 64; }
+static int wide2_nb(int kp) { return kp <= 32 ? 2 : kp <= 48 ? 3 : 4; }
 int nmfk_wide2_lane_tile() { return 16 * NMFK_HYB_NT * 8; }
 
 void nmfk_launch_step_wide2_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s) {
   constexpr int NT = NMFK_HYB_NT;
   const int lpw = 16 * NT * 8, ntile = (a.L + lpw - 1) / lpw;
   const dim3 grid(ntile * a.S, cnt), blk(512);
-  const int nb = kp <= 32 ? 2 : 4;
+  const int nb = wide2_nb(kp);
   const size_t chunkb = 3 * (size_t)(2 * nb) * 256 + (size_t)nb * 1024;
   const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + 2 * 4 * chunkb;
   if (nb == 2) {
     hipLaunchKernelGGL((wide2_step_kernel<2, NT, false>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
+  } else if (nb == 3) {
+    static std::atomic<uint64_t> lds_ok3{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
+    nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<3, NT, false>, lds_ok3, 160 * 1024);
+    hipLaunchKernelGGL((wide2_step_kernel<3, NT, false>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
   } else {
     static std::atomic<uint64_t> lds_ok{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
     nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<4, NT, false>, lds_ok, 160 * 1024);
@@ -1572,11 +1627,15 @@ void nmfk_launch_wide2_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double
   constexpr int NT = NMFK_HYB_NT;
   const int lpw = 16 * NT * 8;  // = NMFK_TILE: the partials line up with sse_kernel's
   const dim3 grid((w.L + lpw - 1) / lpw, cnt), blk(512);
-  const int nb = kp <= 32 ? 2 : 4;
+  const int nb = wide2_nb(kp);
   const size_t chunkb = 3 * (size_t)(2 * nb) * 256 + (size_t)nb * 1024;
   const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + 2 * 4 * chunkb;
   if (nb == 2) {
     hipLaunchKernelGGL((wide2_step_kernel<2, NT, true>), grid, blk, ldsb, s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
+  } else if (nb == 3) {
+    static std::atomic<uint64_t> lds_ok3{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
+    nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<3, NT, true>, lds_ok3, 160 * 1024);
+    hipLaunchKernelGGL((wide2_step_kernel<3, NT, true>), grid, blk, ldsb, s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
   } else {
     static std::atomic<uint64_t> lds_ok{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
     nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<4, NT, true>, lds_ok, 160 * 1024);

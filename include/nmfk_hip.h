@@ -281,6 +281,8 @@ int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *
  *   NMFK_MFMA_WIDE    0: ranks > 16 on the packed-VALU kernel;  NMFK_WIDE2 0: on the all-fp32 MFMA kernel only;
  *   NMFK_MFMA_SSE     0: their monitored objective on the packed-VALU objective kernel
  *   NMFK_REPLAN       0: static launch schedule (no re-planning as restarts retire); 2: re-plan at every tier (tests)
+ *   NMFK_CLAMP_ALWAYS 1: the clamp pass of a check block (Mult:99-100) scans every unit (default: only units whose half-step kernels
+ *                     wrote a value below eps() in the check iteration; the same elements are clamped either way, the results agree to rounding)
  *   NMFK_SP_BLK       0: sparse X in the gather form only (no sliced-ELL copies are built); 2: blocked form whatever the size
  *   NMFK_TARGET_WGS   workgroups a half-step launch should have before loop ranges are split (default 2 x CUs)
  *   NMFK_STREAMS      concurrent launch-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1: host / GPU wait times on stderr

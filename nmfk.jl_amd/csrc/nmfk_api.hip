@@ -111,12 +111,13 @@ struct Sampler {
 //   NMFK_MERGE        g: the ranks <= 16 share g mixed-rank packed-VALU launch groups (default: by restarts per rank)
 //   NMFK_REPLAN       0: no re-planning of the launch geometry as restarts retire ("Retire-aware schedule" in nmfk_mu_sweep);
 //                     2: re-plan at every tier whatever the sweep's size (tests)
+//   NMFK_CLAMP_ALWAYS 1: the clamp pass of every check block looks at every unit (default: only where a fused finish wrote a value below eps())
 //   NMFK_SP_BLK       0: sparse X in the gather form only (also: no sliced-ELL copies are built); 2: blocked form whatever the size
 //   NMFK_STREAMS      concurrent rank-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1 prints the host's share of the loop
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, merge = -1, phases = -1;
   int wide_sse = 1, streams = -1, host_timing = 0;
-  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1;
+  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0;
   // (not knobs any more -- round 3's A/B switches with their measured settings: one mixed-rank matrix-pipe group, the waves of
   //  a workgroup may split a loop range 8 ways, the small ranks on their own kernel variants, four pairs of lane tiles per
   //  wave of the resident form, merged sweeps side by side)
@@ -142,6 +143,7 @@ Tuning read_tuning() {
   geti("NMFK_SP_BLK", t.sp_blk);
   geti("NMFK_HYB_RES", t.hyb_res);
   geti("NMFK_REPLAN", t.replan);
+  geti("NMFK_CLAMP_ALWAYS", t.clamp_always);
   return t;
 }
 
@@ -1217,6 +1219,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ca.nunits = nunits;
   ca.trace = trace_stride ? (double *)(A + o_trace) : nullptr;
   ca.trace_stride = trace_stride;
+  ca.track_low = 0;
 
   NmfkSparseArgs sph, spw;  // CSC view (H half-step), CSR view (W half-step, objective)
   sph.arena = A;
@@ -1424,6 +1427,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         } else {
           nmfk_launch_sse_f32(sa, G.begin, G.count, gs);
         }
+        // the clamp pass only where a value below eps() may exist: the matrix-pipe kernels' fused finishes watch what they write
+        // in a check iteration (both half-steps run and finish themselves; NmfkState::lowflag)
+        ca.track_low = !T.clamp_always && use_hyb(G) && !P.Hfixed && !P.Wfixed && (hs.fused || hs.res_wgs > 0) && (ws.fused || ws.res_wgs > 0);
         if (f64)
           nmfk_launch_check_f64(ca, G.begin, G.count, gs);
         else

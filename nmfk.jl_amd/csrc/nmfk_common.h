@@ -52,7 +52,9 @@ struct NmfkState {
   int32_t have_old;  // consold is not the initial falses(m,m)
   int32_t active;    // still inside the while loop
   int32_t reason;    // NMFK_STOP_*
-  int32_t pad;
+  int32_t lowflag;   // 1: the clamp of the next check block (Mult:99-100) has to look at the unit's factors.  Set by init; units whose
+                     // half-step kernels watch the values they write in a check iteration (NmfkCheckArgs::track_low) have it cleared
+                     // by check_b and set again by a fused finish that writes a value below eps()
 };
 
 // Arguments of one half-step over all units.  lane dimension L (contiguous in the X copy used), loop
@@ -163,6 +165,7 @@ struct NmfkCheckArgs {
   int32_t nunits;
   double *trace;         // optional (nmfk_set_objective_trace): monitored objective of unit u at check c -> trace[u * trace_stride + c]
   int32_t trace_stride;
+  int32_t track_low;     // the units' half-step kernels maintain NmfkState::lowflag: the clamp pass skips units whose flag is clear
 };
 
 struct NmfkFinishArgs {

@@ -44,6 +44,7 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 #define HYB_BARRIER() __syncthreads()
 __device__ __forceinline__ float hyb_div(float x, float p) { return x * __builtin_amdgcn_rcpf(p); }
+#define HYB_EPS 2.220446049250313e-16f  // eps(Float64) as the clamp of Mult:99-100 compares fp32 values with it
 
 // term blocks of the first product: MFMA j, k-lane group g -> split index (0 = h, 1 = m, 2 = l) of the loop factor
 // (A operand) and of the lane factor (B operand; -1 = zero block)
@@ -713,6 +714,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
   double *sumA = (double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)) + (int64_t)tile * k;
   double *red = den + 16;  // [16][16]
   float vs[4] = {0.f, 0.f, 0.f, 0.f};
+  bool low = false;  // a value below eps() written in a check iteration: the clamp (Mult:99-100) has work (NmfkState::lowflag)
   if (owner) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -724,6 +726,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           v[r] = 0.f;
           if (c < k) {
             v[r] = aold[t][r] * acc[t][r] / (float)den[c];  // Mult:67 / Mult:70 order
+            low = low || v[r] < HYB_EPS;
             if (!vec4) Anew[c + (int64_t)lt[t] * k] = v[r];
           }
           vs[r] += v[r];
@@ -731,6 +734,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
         if (vec4 && 4 * g < k) *(f32x4_t *)(Anew + 4 * g + (int64_t)lt[t] * k) = (f32x4_t){v[0], v[1], v[2], v[3]};
       }
   }
+  if ((it + 1) % 10 == 0 && __any(low) && lane == 0) atomicOr(&const_cast<NmfkState *>(state)[u].lowflag, 1);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int c = 4 * g + r;
@@ -846,6 +850,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
   float *__restrict__ Anew = which == 0 ? (float *)(arena + NMFK_HOFF(*rdp, it + 1)) : (float *)(arena + rdp->oWt);
   // sums of the new factor: fp32 per lane over this wave's tile pairs (<= a few dozen values), fp64 from there on
   float vsf[4] = {0.f, 0.f, 0.f, 0.f};
+  bool low = false;  // a value below eps() written in a check iteration (NmfkState::lowflag)
 
   // X: the 16 x 16 block (16-lane tile, chunk) is 1 KB in lane order; byte offset = wave-uniform block offset (SGPR) + 16 * lane
   const uint32_t xlane = (uint32_t)lane * 16u;
@@ -1096,6 +1101,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           v[r] = 4 * g + r < k ? (aold[r] * acc[r]) * rd4[r] : 0.0f;
+          low = low || (4 * g + r < k && v[r] < HYB_EPS);
           vsum[r] += v[r];
         }
         float *dst = Anew + 4 * g + (int64_t)lt[t] * k;
@@ -1127,6 +1133,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
       for (int t = G + tid; t < ntile; t += 64 * RW) part[t] = 0.0;
     return;
   }
+  if ((it + 1) % 10 == 0 && __any(low) && lane == 0) atomicOr(&const_cast<NmfkState *>(state)[u].lowflag, 1);
   // ---- sums of the new factor over the workgroup's lane elements -> slot b (fixed order: lanes, then waves)
   double *red = den + 16;  // [RW][16]
 #pragma unroll

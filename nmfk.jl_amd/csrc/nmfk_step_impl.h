@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NMFK_TILE) void init_kernel(NmfkInitArgs g) {  // g
     s.have_old = 0;
     s.active = 1;
     s.reason = 0;
-    s.pad = 0;
+    s.lowflag = 1;
     g.state[u] = s;
   }
 }
@@ -1884,6 +1884,9 @@ __global__ __launch_bounds__(NMFK_TILE) void clamp_kernel(NmfkCheckArgs g, int u
   __shared__ double sh[NMFK_TILE];
   const int u = u0 + blockIdx.y, b = blockIdx.x;
   if (!g.state[u].active) return;
+  // nothing below eps() was written since the last clamp (the fused finishes of the check iteration watch their values): the
+  // factors and their sum tables are already what this pass would leave
+  if (g.track_low && !g.state[u].lowflag) return;
   const NmfkRun rd = g.runs[u];
   const int tid = threadIdx.x, k = rd.k, kp = rd.kp;
   const T eps = (T)2.220446049250313e-16;
@@ -1952,6 +1955,7 @@ __global__ __launch_bounds__(NMFK_TILE) void check_b_kernel(NmfkCheckArgs g, int
   if (tid == 0) {
     int inc = (have_old && !sh_diff) ? st->inc + 1 : 0;  // Mult:106-111 (first check always differs)
     st->inc = inc;
+    if (g.track_low) st->lowflag = 0;  // (the clamp has run, or had nothing to do; the next check iteration's finishes set it again)
     st->have_old = 1;
     const int iters = g.it + 1;
     if (inc > g.stopconv) {  // Mult:112-115

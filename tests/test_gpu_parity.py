@@ -1225,6 +1225,24 @@ def test_retire_aware_schedule_on_a_small_sweep(NMFk, ctx, oracle, monkeypatch):
         nc = min(len(t0), len(t2))
         assert nc >= 1 and abs(len(t0) - len(t2)) <= max(3, len(t0) // 5), (key, len(t0), len(t2))
         np.testing.assert_allclose(t2[:nc], t0[:nc], rtol=2e-5, err_msg=str(key))
+    # Round 4: the clamp pass (Mult:99-100) runs only for units whose fused finishes wrote a value below eps() in the check
+    # iteration (NmfkState::lowflag); scanning every unit at every check (NMFK_CLAMP_ALWAYS=1) clamps the same elements -- the
+    # two differ only in where a unit's sum tables come from after a check without work (the finishes' own sums / the pass's
+    # recomputation: the same sums in another order), i.e. by rounding.  This matrix (rank 3, k up to 6) drives the surplus
+    # signals below eps(), so the clamp has work.
+    monkeypatch.setenv("NMFK_REPLAN", "0")
+    monkeypatch.setenv("NMFK_CLAMP_ALWAYS", "1")
+    every = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=3000)
+    monkeypatch.delenv("NMFK_CLAMP_ALWAYS")
+    ite = np.stack([every[k]["iters"] for k in ks])
+    assert (ite == its0).mean() >= 0.8, (ite, its0)
+    for k in ks:
+        same = every[k]["iters"] == out["0"][k]["iters"]
+        np.testing.assert_allclose(every[k]["objvalue"][same], out["0"][k]["objvalue"][same], rtol=1e-5)
+        for r in np.flatnonzero(same):
+            assert _rel(every[k]["W"][r] @ every[k]["H"][r], out["0"][k]["W"][r] @ out["0"][k]["H"][r], X) <= 1e-5, (k, r)
+    # (the outputs are rescaled by rowsum(H), Exec:801-803: an element at the clamp, eps(), shows as eps() times that sum)
+    assert min(float(out["0"][k]["W"].min()) for k in ks) <= 1e-12  # the surplus signals did reach the clamp
     # and against the Float64 oracle under its own stop rule: a restart that ran long
     k, r = max(((k, r) for k in ks for r in range(R)), key=lambda kr: out["2"][kr[0]]["iters"][kr[1]])
     Wi, Hi = oracle.init_factors(int(seeds[ks.index(k), r]), n, m, k)

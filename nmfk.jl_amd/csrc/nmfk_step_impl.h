@@ -83,6 +83,32 @@ __device__ __forceinline__ void range_signal_sums(const T *F, int kp, int k, int
   __syncthreads();
 }
 
+// the same with the clamp of Mult:99-100 in the one pass: F[c + l*kp] = max(F, eps) for the signals c < k (a NaN stays), then the sums of
+// the clamped values in the order range_signal_sums adds them (the same bits as clamping first and summing afterwards)
+__device__ __forceinline__ void range_clamp_sums(T *F, int kp, int k, int l0, int l1, T eps, double *out, double *sh) {
+  const int rows = NMFK_TILE / kp;
+  const int tid = threadIdx.x, c = tid % kp, r = tid / kp;
+  double s = 0;
+  if (r < rows)
+    for (int l = l0 + r; l < l1; l += rows) {
+      T v = F[c + (int64_t)l * kp];
+      if (c < k && v < eps) {
+        v = eps;
+        F[c + (int64_t)l * kp] = v;
+      }
+      s += (double)v;
+    }
+  __syncthreads();
+  if (r < rows) sh[tid] = s;
+  __syncthreads();
+  if (tid < kp) {
+    double t = 0;
+    for (int q = 0; q < rows; ++q) t += sh[q * kp + tid];
+    out[tid] = tid < k ? t : 0.0;
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------------
 // init: W = rand(n,k) then H = rand(k,m) (Mult:38,48) or the caller's Winit/Hinit (Mult:40-41,50-51);
 // state of Mult:57-63; colsum(W), rowsum(H).
@@ -1900,12 +1926,7 @@ __global__ __launch_bounds__(NMFK_TILE) void clamp_kernel(NmfkCheckArgs g, int u
     }
     int l0, l1;
     slot_range(len, P, b, l0, l1);
-    for (int64_t e = (int64_t)l0 * kp + tid; e < (int64_t)l1 * kp; e += NMFK_TILE) {
-      const T v = F[e];
-      if ((int)(e % kp) < k && v < eps) F[e] = eps;
-    }
-    __syncthreads();
-    range_signal_sums(F, kp, k, l0, l1, tab + (int64_t)b * kp, sh);
+    range_clamp_sums(F, kp, k, l0, l1, eps, tab + (int64_t)b * kp, sh);  // (one pass over the slot's rows; round 4)
   }
 }
 

@@ -207,6 +207,10 @@ int nmfk_comm_info(nmfk_comm *comm, int *rank, int *nranks);
  * learn n, m from the broadcast; every rank then runs NMFpreprocessing! (nmfk_set_X) on its device copy. */
 int nmfk_comm_bcast_X(nmfk_comm *comm, int root, const float *X, int64_t n, int64_t m, int64_t ldx, double lambda,
                       int64_t *n_out, int64_t *m_out, int64_t *nan_count, int64_t *zero_count);
+/* Collective.  `bytes` bytes at `buf` (host or device) of rank `root` arrive at `buf` of every other rank.  The host layer uses it
+ * for the lean result exchange of execute_run with best = true (Exec:655-658; SURVEY 8e: "send of the winning W"): after
+ * nmfk_mu_sweep_sharded(need_W = 0) the owner of the restart with the lowest objective broadcasts its W (n x k floats). */
+int nmfk_comm_bcast(nmfk_comm *comm, int root, void *buf, int64_t bytes);
 /* Collective nmfk_mu_sweep: identical arguments on every rank, describing ALL nruns restarts (seeds, optional inits,
  * outputs).  Each rank runs its shard and receives the results of every restart; pass H_out = NULL on a rank that
  * does not need them.  need_W = 0: the W matrices are not exchanged (W_out then receives this rank's own restarts

@@ -90,6 +90,7 @@ def lib():
     L.nmfk_last_sweep_info.argtypes = [vp, C.POINTER(C.c_int32)]
     i32p = C.POINTER(C.c_int32)
     L.nmfk_shard_plan.argtypes = [C.c_int, C.c_int, C.c_int, i32p, i32p]
+    L.nmfk_comm_bcast.argtypes = [vp, C.c_int, C.c_void_p, C.c_int64]
     L.nmfk_shard_owner.argtypes = [C.c_int, C.c_int, C.c_int, i32p, i32p]
     L.nmfk_loopback_group_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.nmfk_loopback_group_destroy.argtypes = [vp]
@@ -270,6 +271,12 @@ class Comm:
         self.ctx.n, self.ctx.m = no.value, mo.value
         self.ctx.nan_count, self.ctx.zero_count = nan.value, zero.value
         return self.ctx
+
+    def bcast(self, arr, root):
+        """nmfk_comm_bcast: the C-contiguous array `arr` of rank `root` arrives in `arr` of every other rank (in place)."""
+        assert arr.flags["C_CONTIGUOUS"] and arr.flags["WRITEABLE"]
+        _check(lib().nmfk_comm_bcast(self._h, int(root), arr.ctypes.data, int(arr.nbytes)))
+        return arr
 
     def mu_sweep(self, ks, nruns, seeds=None, Winit=None, Hinit=None, params=None, need_W=True, **kw):
         """nmfk_mu_sweep_sharded: same arguments on every rank (ALL restarts); every rank gets all results.  need_W=False:

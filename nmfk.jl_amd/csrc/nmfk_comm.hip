@@ -360,6 +360,30 @@ NMFK_EXPORT int nmfk_comm_bcast_X(nmfk_comm *c, int root, const float *X, int64_
   return rc;
 }
 
+// Collective: `bytes` bytes at `buf` (host or device memory) of rank `root` arrive in every other rank's `buf`.  The lean result
+// exchange of execute_run with best = true (Exec:655-658): after nmfk_mu_sweep_sharded with need_W = 0 every rank knows the
+// objective of every restart, and the owner of the best one hands its W (n x k floats) to the others -- SURVEY 8e's "send of the
+// winning W" -- instead of every W travelling.
+NMFK_EXPORT int nmfk_comm_bcast(nmfk_comm *c, int root, void *buf, int64_t bytes) {
+  if (!c) return fail(NMFK_ERR_BAD_ARG, "comm is null");
+  HIPCHECK(hipSetDevice(c->ctx->device));
+  hipStream_t st = c->ctx->stream;
+  auto local_stage = [&]() -> int {
+    if (root < 0 || root >= c->nranks || bytes < 0 || (bytes > 0 && !buf)) return fail(NMFK_ERR_BAD_ARG, "bad broadcast arguments");
+    if (bytes == 0) return NMFK_OK;
+    if (c->xbuf.ensure((size_t)bytes)) return fail(NMFK_ERR_HIP, "out of device memory (broadcast buffer)");
+    if (c->rank == root) HIPCHECK(hipMemcpyAsync(c->xbuf.p, buf, (size_t)bytes, hipMemcpyDefault, st));
+    return NMFK_OK;
+  };
+  int rc = agree(c, local_stage(), "nmfk_comm_bcast (staging)");
+  if (rc != NMFK_OK || bytes == 0) return rc;
+  rc = coll_bcast(c, c->xbuf.p, (size_t)bytes, root, "ncclBroadcast(bytes)");
+  if (rc != NMFK_OK) return rc;
+  if (c->rank != root) HIPCHECK(hipMemcpyAsync(buf, c->xbuf.p, (size_t)bytes, hipMemcpyDefault, st));
+  HIPCHECK(hipStreamSynchronize(st));
+  return NMFK_OK;
+}
+
 NMFK_EXPORT int nmfk_shard_owner(int nruns, int nranks, int r, int32_t *rank, int32_t *slot) {
   if (nruns <= 0 || nranks <= 0 || r < 0 || r >= nruns) return fail(NMFK_ERR_BAD_ARG, "bad shard arguments");
   if (rank) *rank = r % nranks;  // restart r = rank + slot * nranks

@@ -226,8 +226,20 @@ def _sweep(ctx, X, ks, nNMF, kw, need_all_W=True):
         ctx.set_X((np.asarray(X, dtype=np.float32) / v[:, None]).astype(np.float32), mu.get("lambda_", 1e-32))
     ctx.set_weight(weight_array)
     comm = parallel.comm_of(ctx)
-    if comm is not None:  # ranks joined through the C ABI: shard, RCCL all-gather of the device buffers (all W included)
-        res = comm.mu_sweep(ks, nNMF, seeds=seeds, Winit=wi, Hinit=hi, params=params, need_W=True)
+    if comm is not None:  # ranks joined through the C ABI: shard, RCCL all-gather of the device buffers
+        lean = not (need_all_W or normalizevector is not None) and hasattr(comm, "bcast")
+        res = comm.mu_sweep(ks, nNMF, seeds=seeds, Winit=wi, Hinit=hi, params=params, need_W=not lean)
+        if lean:
+            # best = true (Exec:655-658) needs ONE W per rank k besides the H of every restart: every rank knows every objective,
+            # the owner of the best restart (Exec:545-546) broadcasts its W (nmfk_comm_bcast), the others stay local or absent
+            for k in ks:
+                best = int(np.argsort(res[k]["objvalue"], kind="stable")[0])
+                owner, _slot = _lib.shard_owner(nNMF, comm.nranks, best)
+                Wb = np.ascontiguousarray(res[k]["W"][best], dtype=np.float32)
+                comm.bcast(Wb, owner)
+                W = [np.asarray(res[k]["W"][r]) if r % comm.nranks == comm.rank else None for r in range(nNMF)]
+                W[best] = Wb
+                res[k]["W"] = W
     else:
         res = parallel.sharded_sweep(ctx.mu_sweep, ks, nNMF, seeds, wi, hi, params, n, m,
                                      need_all_W=need_all_W or normalizevector is not None)

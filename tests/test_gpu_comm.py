@@ -247,6 +247,60 @@ def test_loopback_given_inits_travel_through_the_shard_buffers(NMFk, oracle):
     ref_ctx.close()
 
 
+def test_loopback_execute_with_the_lean_W_exchange(NMFk, oracle):
+    """execute() on a communicator with best = true (the default): the sharded sweep runs with need_W = 0 -- H, objective,
+    iterations of every restart travel, W only stays with its owner -- and the owner of the restart with the lowest objective
+    (Exec:545-546) hands its W to the others (nmfk_comm_bcast; SURVEY 8e "send of the winning W").  Three logical ranks on
+    the loopback transport, one Python thread each: every rank returns the same sweep result, equal to the one-context
+    execute() up to the shards' summation order; best = false takes the full exchange and agrees as well."""
+    from nmfk_jl_amd import _lib, parallel
+
+    n, m, k0, N, R = 150, 40, 3, 3, 5
+    W0 = oracle.uniform_fill(81, 0, n * k0).reshape(n, k0)
+    H0 = oracle.uniform_fill(82, 0, k0 * m).reshape(k0, m)
+    X = np.asfortranarray((W0 @ H0 + 0.01 * oracle.uniform_fill(83, 0, n * m).reshape(n, m)).astype(np.float32))
+    ks = [2, 3, 4]
+    ref_ctx = NMFk.Context(0)
+    ref_ctx.set_X(X)
+    kw = dict(load=False, save=False, quiet=True, seed=7, maxiter=300)
+    refs = {best: NMFk.execute(X, ks, R, ctx=ref_ctx, best=best, **kw) for best in (True, False)}
+    mh = _lib.Multi(N, loopback=True)
+    mh.set_X(X)
+    for best in (True, False):
+        ref = refs[best]
+        bcasts = [0] * N
+
+        def work(g, comm):
+            parallel._comms[id(comm.ctx)] = comm
+            inner = comm.bcast
+
+            def counting(arr, root):
+                bcasts[g] += 1
+                return inner(arr, root)
+
+            comm.bcast = counting
+            try:
+                return NMFk.execute(X, ks, R, ctx=comm.ctx, best=best, **kw)
+            finally:
+                parallel._comms.pop(id(comm.ctx), None)
+
+        out, err = _ranks_in_threads(mh, work)
+        assert err == [None] * N, err
+        assert bcasts == ([len(ks)] * N if best else [0] * N), bcasts  # one winning W per rank k, or the full exchange
+        for g in range(N):
+            W, H, fit, rob, aic, kopt = out[g]
+            assert kopt == ref[5] == 3
+            for k in ks:
+                if best:
+                    assert (W[k - 1] == out[0][0][k - 1]).all() and (H[k - 1] == out[0][1][k - 1]).all()  # every rank the same bits
+                    assert np.linalg.norm(W[k - 1] @ H[k - 1] - ref[0][k - 1] @ ref[1][k - 1]) <= 1e-4 * np.linalg.norm(X)
+                np.testing.assert_allclose(fit[k - 1], ref[2][k - 1], rtol=1e-3)  # (best = false: the fit of the cluster MEANS)
+                np.testing.assert_allclose(rob[k - 1], out[0][3][k - 1], atol=1e-6)
+            np.testing.assert_allclose(np.array(rob)[[k - 1 for k in ks]], np.array(ref[3])[[k - 1 for k in ks]], atol=2e-3)
+    mh.close()
+    ref_ctx.close()
+
+
 def test_loopback_failing_rank_fails_every_rank_without_a_hang(NMFk, oracle):
     """A NaN initial factor in ONE shard (restart 1 -> rank 1 of 3): that rank's local sweep returns NMFK_ERR_NAN_INIT; the
     status agreement makes every rank (and nmfk_multi_sweep) return it instead of blocking in the all-gather."""

@@ -183,6 +183,51 @@ def test_julia_shim_binds_the_declared_c_abi():
                 assert jt in ("Cint", "Int32"), (name, jt, ca)
 
 
+def test_julia_shim_calls_only_functions_that_exist():
+    """No Julia here, so a misspelt function name in julia/NMFkHIP.jl would only show at a user's first call.  Static name
+    resolution: every unqualified `name(` in the shim (comments and strings stripped) is a function or type the file defines, or
+    a name from Julia's Base / Core listed here by hand; every qualified `Mod.name(` names a module the file imports."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jl = open(os.path.join(root, "julia", "NMFkHIP.jl")).read()
+    out, i, n = [], 0, len(jl)
+    while i < n:  # strip comments and string literals
+        c = jl[i]
+        if c == "#":
+            j = jl.index("=#", i) + 2 if jl.startswith("#=", i) else (jl.find("\n", i) if jl.find("\n", i) >= 0 else n)
+            i = j
+            continue
+        if c == '"':
+            if jl.startswith('"""', i):
+                i = jl.index('"""', i + 3) + 3
+            else:
+                j = i + 1
+                while jl[j] != '"' or jl[j - 1] == "\\":
+                    j += 1
+                i = j + 1
+            out.append('""')
+            continue
+        out.append(c)
+        i += 1
+    code = "".join(out)
+    defs = set(re.findall(r"\bfunction\s+(?:\w+\.)?(\w+!?)", code)) | set(re.findall(r"^\s*(\w+!?)\([^)\n]*\)\s*=", code, flags=re.M)) \
+        | set(re.findall(r"\b(?:mutable\s+)?struct\s+(\w+)", code))
+    assert {"execute", "execute_run", "getk", "signalorder", "input_checks", "robustkmeans", "Context", "ExecuteOptions"} <= defs
+    base = set("""ArgumentError ErrorException IOBuffer Int Int32 Int64 UInt64 Float32 Float64 abs abspath all any bytes2hex ccall ceil
+        collect convert copy count dirname enumerate eps error falses finalizer findfirst findlast findmax get haskey isfile isnan
+        isnothing join joinpath length log map max maximum min minimum mkpath new ones permutedims pointer println push! rand read
+        setproperty! similar size sizeof sortperm sqrt stride strip sum take! throw trues typeof unsafe_string vec write zeros
+        floor round isempty isinf filter first last reshape hcat vcat string repr get! pop! keys values pairs zip range iszero""".split())
+    calls = {mm.group(1) for mm in re.finditer(r"(?<![\.\w:@])([A-Za-z_]\w*!?)\(", code)}
+    unknown = sorted(calls - defs - base)
+    assert not unknown, f"julia/NMFkHIP.jl calls names that are neither defined in the file nor known Base functions: {unknown}"
+    imported = set(re.findall(r"^\s*(?:import|using)\s+([\w\.]+)", code, flags=re.M)) | {"Base", "Core", "NMFkHIP"}
+    imported |= {q.split(".")[0] for q in imported}
+    for mm in re.finditer(r"(?<![\.\w])([A-Z]\w*)\.(\w+!?)\(", code):
+        assert mm.group(1) in imported, f"{mm.group(1)}.{mm.group(2)}(...) but {mm.group(1)} is not imported in julia/NMFkHIP.jl"
+
+
 def _julia_function_kwargs(jl, head):
     """keyword names of the Julia method whose definition starts with `head` (text up to the closing parenthesis)"""
     import re

@@ -261,10 +261,12 @@ def test_default_stop_rule_against_the_oracle_fixture(NMFk, ctx, oracle, geometr
         worst = max(worst, err)
         assert err <= 2e-5, (k, r, err, int(np.argmax(np.abs(tr[:nc] - ref[:nc]) / ref[:nc])))
     # fp32 iteration counts: the tolOF = 1e-3 test on an objective of ~1e3..1e6 sits below fp32 resolution of the factors'
-    # trajectory, so the counts are not expected to be equal -- but they must be the oracle's within a few checks for most
+    # trajectory, so the counts cannot all be equal -- measured (round 4, all three geometries): EQUAL to the Float64 oracle's on
+    # 91-92 % of the 192 restarts, within one check on 98-99 %, all of them within max(50, 5 %)
     it32 = np.stack([det[k]["iters"] for k in ks])
-    close = np.abs(it32 - fx["iters"]) <= np.maximum(50, fx["iters"] // 20)
-    assert close.mean() >= 0.6, (close.mean(), worst)
+    diff = np.abs(it32 - fx["iters"])
+    assert (diff <= np.maximum(50, fx["iters"] // 20)).mean() >= 0.97, (diff.max(), worst)
+    assert (diff <= 10).mean() >= 0.93 and (diff == 0).mean() >= 0.85, ((diff <= 10).mean(), (diff == 0).mean())
     # fp64 compute (the reference's arithmetic, packed-VALU fp64 kernels)
     W, H, fit64, rob64, aic64, kopt64, det64 = NMFk.execute(X, ks, R, load=False, save=False, quiet=True, seed=seed, ctx=ctx,
                                                              compute="f64", return_details=True)

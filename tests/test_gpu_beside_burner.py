@@ -15,6 +15,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.skipif(not os.environ.get("NMFK_TEST_BURNER"), reason="opt-in: NMFK_TEST_BURNER=1 (starts a second GPU process)")
 def test_shipped_paths_reproduce_beside_a_wide_operand_mfma_neighbour():
     env = dict(os.environ, REPS_SCALE=os.environ.get("REPS_SCALE", "0.5"), LIMIT="400")
-    r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "soak_beside_burner.sh"), "0", "300"], capture_output=True, text=True,
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "hazard", "soak_beside_burner.sh"), "0", "300"], capture_output=True, text=True,
                        timeout=600, env=env)
     assert "TOTAL differing: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -68,6 +68,26 @@ def execute_case():
     cases.append((f"execute: sweep, clustering, silhouettes, kopt  {n}x{m} k=2:7 R=8", run, 40))
 execute_case()
 
+def retiring_case():
+    """Round 4: the default stop rule on a planted matrix (restarts stop at different iterations), every tier of the
+    retire-aware schedule taken (NMFK_REPLAN=2): replan_kernel, the one-walk clamp and the lowflag of the fused finishes beside the burner."""
+    n, m, k0 = 640, 192, 3
+    W0 = ctx.fill_uniform(2, 0, n * k0).reshape(k0, n).T.astype(np.float64); H0 = ctx.fill_uniform(2, n * k0, k0 * m).reshape(m, k0).T.astype(np.float64)
+    X = np.asfortranarray((W0 @ H0 + 0.01 * ctx.fill_uniform(2, n * k0 + k0 * m, n * m).reshape(m, n).T).astype(np.float32))
+    kss = [2, 3, 4, 5, 6]
+    seeds = np.array([[NMFk.run_seed(11, k, r) for r in range(6)] for k in kss], dtype=np.uint64)
+    def run():
+        os.environ["NMFK_REPLAN"] = "2"
+        try:
+            ctx.set_X(X)
+            res = ctx.mu_sweep(kss, 6, seeds=seeds, maxiter=3000)
+            assert ctx.last_sweep_info()["replans"] >= 2
+        finally:
+            del os.environ["NMFK_REPLAN"]
+        return {k: {f: res[k][f] for f in ("W", "H", "objvalue", "iters", "reason")} for k in kss}
+    cases.append((f"retire-aware schedule, every tier  {n}x{m} k=2:6 R=6 default stop rule", run, 30))
+retiring_case()
+
 def kmeans_case():
     W = np.ascontiguousarray(ctx.fill_uniform(9, 0, 2048 * 6).reshape(2048, 6).astype(np.float32).T)  # 6 x 2048 samples
     def run():

@@ -268,6 +268,12 @@ int nmfk_set_profiling(nmfk_ctx *ctx, int enabled);
  * (one launch group on the matrix-pipe kernels; NMFK_REPLAN=0 switches it off): info[5] = re-plans executed, info[6] = tier
  * of the last plan (tier j is planned for ceil(units / 2^j) units), info[7] = units in the work list of the last plan. */
 int nmfk_last_sweep_info(nmfk_ctx *ctx, int32_t info[8]);
+/* Test hook, pure host arithmetic (no device): the tiers of the retire-aware schedule for a sweep of `units` units of ranks 2..16
+ * (widest kernel variant 4 / 8 / 16) in one launch group on the matrix-pipe kernels, on a GPU of `cus` CUs -- tier j is the launch
+ * geometry for ceil(units / 2^j) units; the sweep switches to it when the units still active fit.  Row j of `out` (16 ints per
+ * row, <= cap rows): units; then for the H and for the W half-step: workgroups per unit of the resident form (0 = streaming form),
+ * wsplit, S, dchunk, fused, table slots, slots a unit writes.  *count = rows written. */
+int nmfk_plan_hyb_tiers(int64_t n, int64_t m, int variant, int units, int cus, int32_t *out, int cap, int *count);
 /* The objective the stop rule monitors -- sum((((X - W*H) .* weight)[.!inan]).^2) every 10th iteration (Mult:73-74) -- as
  * the device computed it, for every check of every restart of the NEXT sweeps (parity tests compare it with the oracle's
  * trace check by check).  nmfk_get_objective_trace: restart `restart` of rank ks[kidx] of the last sweep; *count = checks made. */

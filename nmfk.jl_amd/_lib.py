@@ -92,6 +92,7 @@ def lib():
     L.nmfk_shard_plan.argtypes = [C.c_int, C.c_int, C.c_int, i32p, i32p]
     L.nmfk_comm_bcast.argtypes = [vp, C.c_int, C.c_void_p, C.c_int64]
     L.nmfk_shard_owner.argtypes = [C.c_int, C.c_int, C.c_int, i32p, i32p]
+    L.nmfk_plan_hyb_tiers.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.POINTER(C.c_int)]
     L.nmfk_loopback_group_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.nmfk_loopback_group_destroy.argtypes = [vp]
     L.nmfk_comm_create_loopback.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
@@ -215,6 +216,21 @@ def shard_owner(nruns, nranks, r):
     g, j = C.c_int32(), C.c_int32()
     _check(lib().nmfk_shard_owner(int(nruns), int(nranks), int(r), C.byref(g), C.byref(j)))
     return g.value, j.value
+
+
+def plan_hyb_tiers(n, m, variant, units, cus=256):
+    """nmfk_plan_hyb_tiers (host arithmetic, no device) -> one dict per tier of the retire-aware schedule: units and, for the
+    H and the W half-step, {res, wsplit, S, dchunk, fused, slots, ns}."""
+    cap = 40
+    out = (C.c_int32 * (16 * cap))()
+    cnt = C.c_int()
+    _check(lib().nmfk_plan_hyb_tiers(int(n), int(m), int(variant), int(units), int(cus), out, cap, C.byref(cnt)))
+    names = ("res", "wsplit", "S", "dchunk", "fused", "slots", "ns")
+    rows = []
+    for j in range(cnt.value):
+        o = out[16 * j:16 * j + 16]
+        rows.append({"units": o[0], "H": dict(zip(names, o[1:8])), "W": dict(zip(names, o[8:15]))})
+    return rows
 
 
 def _pin_rccl():

@@ -626,6 +626,89 @@ NMFK_EXPORT int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[6
 // the sweep
 // --------------------------------------------------------------------------------------------------------
 namespace {
+// Launch geometry of a launch group of `units` units on the matrix-pipe kernels (ranks 2..16, dense fp32) at an n x m matrix on a GPU
+// of `cus` CUs: pure host arithmetic, the rule nmfk_mu_sweep applies to such a group (its tier 0) and to every later tier of the
+// retire-aware schedule.  [0] = H half-step (lanes = m columns, loop = n rows), [1] = W half-step.
+struct HybPlan {
+  int units;
+  int res[2];     // workgroups per unit of the resident form (0: streaming form)
+  int wsplit[2];  // waves of a workgroup that split the loop range (1: they share staged blocks)
+  int S[2];       // splits of the loop range over workgroups (> 1: partial numerators + reduce_kernel)
+  int dchunk[2], fused[2];
+  int slots[2];   // sum-table slots the half-step's helper kernels cover
+  int ns[2];      // sum-table slots a unit's own kernels write
+};
+HybPlan plan_hyb_group(int n, int m, int cus, int vmax, int units, int target_wgs, bool hyb_res) {
+  HybPlan p;
+  p.units = units;
+  const int target = target_wgs > 0 ? target_wgs : 2 * cus;
+  const int target_ws = target_wgs > 0 ? target : 3 * cus / 2;
+  const int res_tpw = Tuning::hyb_res_tpw, max_ws = Tuning::max_wsplit;
+  for (int which = 0; which < 2; ++which) {
+    const int L = which == 0 ? m : n, D = which == 0 ? n : m;
+    p.res[which] = 0;
+    if (hyb_res && units > 0 && nmfk_hyb_resident_lds(vmax, D) != 0) {
+      const int ntp = (L + 31) / 32, rw = nmfk_hyb_resident_waves();
+      const int fill = (4 * cus + units - 1) / units;
+      const int gmax = std::max(1, ntp / (2 * rw)), gmin = std::min(gmax, std::max(std::max(1, ntp / (rw * res_tpw)), fill));
+      int best = gmin;
+      double waste = 1e30;
+      for (int gq = gmin; gq <= gmax; ++gq) {
+        const int rounds = (ntp + rw * gq - 1) / (rw * gq);
+        const double wq = (double)rounds * rw * gq / ntp;
+        if (wq < waste - 1e-9) {
+          waste = wq;
+          best = gq;
+        }
+      }
+      p.res[which] = best;
+    }
+    auto tiles = [&](int ws) { return p.res[which] > 0 ? p.res[which] : (L + nmfk_hyb_lane_tile(ws) - 1) / nmfk_hyb_lane_tile(ws); };
+    auto wgs = [&](int ws) { return std::max<int64_t>((int64_t)tiles(ws) * units, 1); };
+    p.wsplit[which] = 1;
+    if (wgs(1) < target_ws) p.wsplit[which] = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
+    const int64_t have = wgs(p.wsplit[which]);
+    const int S0 = (int)((target + have - 1) / have), maxS = std::max(1, D / (64 * p.wsplit[which]));
+    p.S[which] = std::max(1, std::min(S0, maxS));
+    p.dchunk[which] = (D + p.S[which] - 1) / p.S[which];
+    if (p.S[which] > 1) {
+      p.dchunk[which] = (p.dchunk[which] + 15) & ~15;
+      p.S[which] = (D + p.dchunk[which] - 1) / p.dchunk[which];
+    }
+    p.fused[which] = p.S[which] == 1;
+    p.slots[which] = tiles(p.wsplit[which]);
+    if (!p.fused[which]) p.slots[which] = std::max(p.slots[which], std::min(64, (L + 31) / 32));
+    p.ns[which] = (p.fused[which] || p.res[which] > 0) ? tiles(p.wsplit[which]) : p.slots[which];
+  }
+  return p;
+}
+}  // namespace
+
+// Test hook (no device needed): the tiers nmfk_mu_sweep plans for a sweep of `units` units whose ranks (all in 2..16, widest kernel
+// variant `variant` = 4 / 8 / 16) run in one launch group on the matrix-pipe kernels: tier j for ceil(units / 2^j) units.  Row j of
+// `out` (16 ints per row, at most `cap` rows): units, then for the H and the W half-step: res, wsplit, S, dchunk, fused, slots, ns;
+// out[15] = 0.  *count = tiers.  The retire-aware schedule switches to tier j when the units still active are <= its `units`.
+NMFK_EXPORT int nmfk_plan_hyb_tiers(int64_t n, int64_t m, int variant, int units, int cus, int32_t *out, int cap, int *count) {
+  if (!out || !count || cap < 1 || n < 16 || m < 16 || units < 1 || cus < 1) return fail(NMFK_ERR_BAD_ARG, "bad argument");
+  const Tuning T = read_tuning();
+  int rows = 0;
+  for (int c = units;; c = (c + 1) / 2) {
+    if (rows >= cap) break;
+    const HybPlan p = plan_hyb_group((int)n, (int)m, cus, variant, c, T.target_wgs, T.hyb_res != 0);
+    int32_t *o = out + 16 * rows++;
+    o[0] = p.units;
+    for (int w = 0; w < 2; ++w) {
+      int32_t *q = o + 1 + 7 * w;
+      q[0] = p.res[w], q[1] = p.wsplit[w], q[2] = p.S[w], q[3] = p.dchunk[w], q[4] = p.fused[w], q[5] = p.slots[w], q[6] = p.ns[w];
+    }
+    o[15] = 0;
+    if (c == 1) break;
+  }
+  *count = rows;
+  return NMFK_OK;
+}
+
+namespace {
 // Retire-aware schedule: position p of the new work list takes the unit at position perm[p] of the old one.  runs[] and
 // state[] are copied into their other buffers (the old ones stay as they are: a snapshot copy may still read them), the
 // unit's slot counts become those of the new geometry and both sum tables are folded into slot 0 in the order the
@@ -920,12 +1003,21 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     const bool one_group = all_hyb && !ctx->sparse && !f64 && (merge > 0 || hyb_phases) && hyb_groups == 1;
     if (T.replan && one_group && (nunits >= 32 || T.replan >= 2)) {
       tiers.push_back({nunits, ghp[0], gwp[0], {res_wgs[0], res_wgs[1]}, 0, 0, 0, 0});
+      {  // the standalone rule (plan_hyb_group: what the later tiers and the CPU tests use) is the general one for such a sweep
+        const HybPlan p0 = plan_hyb_group(n, m, cus, hyb_vmax, nunits, T.target_wgs, T.hyb_res != 0);
+        const Geo g0[2] = {ghp[0], gwp[0]};
+        for (int w = 0; w < 2; ++w)
+          if (p0.res[w] != res_wgs[w] || p0.wsplit[w] != g0[w].wsplit || p0.S[w] != g0[w].S || p0.dchunk[w] != g0[w].dchunk ||
+              p0.fused[w] != g0[w].fused || p0.slots[w] != g0[w].slots)
+            return fail(NMFK_ERR_HIP, "internal: the tier planner disagrees with the sweep's launch geometry");
+      }
       for (int c = (nunits + 1) / 2; c >= 1 && c < tiers.back().count; c = (c + 1) / 2) {
+        const HybPlan p = plan_hyb_group(n, m, cus, hyb_vmax, c, T.target_wgs, T.hyb_res != 0);
         Tier t;
         t.count = c;
-        plan_res(c, t.res);
-        t.gh = geometry_for(m, n, 0, 0, t.res, (double)c / nk);
-        t.gw = geometry_for(n, m, 0, 1, t.res, (double)c / nk);
+        t.res[0] = p.res[0], t.res[1] = p.res[1];
+        t.gh = Geo{p.wsplit[0], p.S[0], p.dchunk[0], p.fused[0], p.slots[0]};
+        t.gw = Geo{p.wsplit[1], p.S[1], p.dchunk[1], p.fused[1], p.slots[1]};
         t.nsH = t.nsW = t.PH = t.PW = 0;
         tiers.push_back(t);
         if (c == 1) break;

@@ -433,6 +433,48 @@ def test_shard_plan_matches_the_python_plan():
         _lib.shard_plan(4, 2, 2)
 
 
+def test_retire_aware_tiers_are_consistent_launch_geometries(monkeypatch):
+    """nmfk_plan_hyb_tiers (the planner nmfk_mu_sweep uses for the retire-aware schedule, host arithmetic): tier j plans
+    ceil(units / 2^j) units; every tier's splits cover the loop range in 16-aligned chunks no shorter than a wave's 64;
+    a unit writes no more table slots than the helpers cover; fewer units never get fewer workgroups per unit; and each
+    tier has an independent stream of work for each of the 256 CUs as long as the matrix allows it."""
+    from nmfk_jl_amd import _lib
+
+    for v in ("NMFK_TARGET_WGS", "NMFK_HYB_RES"):
+        monkeypatch.delenv(v, raising=False)
+    for n, m in ((8192, 512), (1024, 256), (20000, 96), (64, 4096), (16, 16)):
+        for units, variant in ((480, 16), (480, 4), (33, 8), (1, 16)):
+            tiers = _lib.plan_hyb_tiers(n, m, variant, units)
+            assert [t["units"] for t in tiers][0] == units and tiers[-1]["units"] == 1
+            for a, b in zip(tiers, tiers[1:]):
+                assert b["units"] == (a["units"] + 1) // 2
+            prev = None
+            for t in tiers:
+                per_unit = []
+                for half, L, D in (("H", m, n), ("W", n, m)):
+                    g = t[half]
+                    assert g["wsplit"] in (1, 4, 8) and g["S"] >= 1 and g["fused"] == (g["S"] == 1)
+                    assert g["S"] * g["dchunk"] >= D and (g["S"] - 1) * g["dchunk"] < D
+                    if g["S"] > 1:
+                        assert g["dchunk"] % 16 == 0 and g["dchunk"] >= 64 * g["wsplit"]
+                    assert 1 <= g["ns"] <= g["slots"] <= max(64, (L + 31) // 32)
+                    if g["res"]:
+                        assert g["ns"] == g["res"] and 8 * g["res"] <= max(8, (L + 31) // 32)
+                    wgs = g["ns"] * g["S"] * t["units"]
+                    per_unit.append(g["ns"] * g["S"] * g["wsplit"])
+                    room = (L + 31) // 32 * max(1, D // 512) * t["units"]  # 32 lanes x 512 of the loop is the least a workgroup takes
+                    assert wgs * g["wsplit"] >= min(256, room // 8), (n, m, units, variant, t)  # wsplit waves work on separate ranges
+                if prev:
+                    assert per_unit[0] >= prev[0] or per_unit[1] >= prev[1]
+                prev = per_unit
+    # the bench sweep (8192 x 512, 480 units): full list is fused both ways; a quarter of it is not starved
+    t0, t2 = _lib.plan_hyb_tiers(8192, 512, 16, 480)[0], _lib.plan_hyb_tiers(8192, 512, 16, 480)[2]
+    assert t0["H"]["fused"] == 1 and t0["W"]["fused"] == 1 and t0["W"]["res"] > 0
+    assert t2["units"] == 120 and t2["W"]["ns"] * t2["W"]["S"] * 120 >= 512
+    with pytest.raises(Exception):
+        _lib.plan_hyb_tiers(8, 8, 16, 4)
+
+
 def test_shard_delivery_index_math_for_several_ranks():
     """The delivery of nmfk_mu_sweep_sharded (nmfk_comm.hip) replayed on the host for N > 1: rank h contributes `padded`
     slots (short lists repeat their last restart), the gathered buffer is rank-major, and slot j of rank h is delivered to

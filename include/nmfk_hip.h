@@ -268,6 +268,9 @@ int nmfk_set_profiling(nmfk_ctx *ctx, int enabled);
  * (one launch group on the matrix-pipe kernels; NMFK_REPLAN=0 switches it off): info[5] = re-plans executed, info[6] = tier
  * of the last plan (tier j is planned for ceil(units / 2^j) units), info[7] = units in the work list of the last plan. */
 int nmfk_last_sweep_info(nmfk_ctx *ctx, int32_t info[8]);
+/* The same with `count` <= 16 entries: info[8] = checks (per launch group) whose objective came out of the following H half-step
+ * (the deferred check, see NMFK_DEFER_OBJ below), info[9] = checks with an objective launch of their own; the rest 0. */
+int nmfk_last_sweep_info_ex(nmfk_ctx *ctx, int32_t *info, int count);
 /* Test hook, pure host arithmetic (no device): the tiers of the retire-aware schedule for a sweep of `units` units of ranks 2..16
  * (widest kernel variant 4 / 8 / 16) in one launch group on the matrix-pipe kernels, on a GPU of `cus` CUs -- tier j is the launch
  * geometry for ceil(units / 2^j) units; the sweep switches to it when the units still active fit.  Row j of `out` (16 ints per
@@ -293,6 +296,10 @@ int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *
  *   NMFK_REPLAN       0: static launch schedule (no re-planning as restarts retire); 2: re-plan at every tier (tests)
  *   NMFK_CLAMP_ALWAYS 1: the clamp pass of a check block (Mult:99-100) scans every unit (default: only units whose half-step kernels
  *                     wrote a value below eps() in the check iteration; the same elements are clamped either way, the results agree to rounding)
+ *   NMFK_DEFER_OBJ    0: every check block computes its monitored objective (Mult:74) in a launch of its own (default on the
+ *                     matrix-pipe kernels: the H half-step that follows a check iteration leaves it as a by-product and the check's
+ *                     tests run behind that half-step; same stop decisions, the objective taken after the clamp instead of before:
+ *                     <= 1e-13 of its value)
  *   NMFK_SP_BLK       0: sparse X in the gather form only (no sliced-ELL copies are built); 2: blocked form whatever the size
  *   NMFK_TARGET_WGS   workgroups a half-step launch should have before loop ranges are split (default 2 x CUs)
  *   NMFK_STREAMS      concurrent launch-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1: host / GPU wait times on stderr

@@ -88,6 +88,7 @@ def lib():
     L.nmfk_set_objective_trace.argtypes = [vp, C.c_int]
     L.nmfk_get_objective_trace.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
     L.nmfk_last_sweep_info.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.nmfk_last_sweep_info_ex.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
     i32p = C.POINTER(C.c_int32)
     L.nmfk_shard_plan.argtypes = [C.c_int, C.c_int, C.c_int, i32p, i32p]
     L.nmfk_comm_bcast.argtypes = [vp, C.c_int, C.c_void_p, C.c_int64]
@@ -539,10 +540,11 @@ class Context:
 
     def last_sweep_info(self):
         """nmfk_last_sweep_info: the launch schedule the last mu_sweep on this context took."""
-        info = (C.c_int32 * 8)()
-        _check(lib().nmfk_last_sweep_info(self._h, info))
+        info = (C.c_int32 * 16)()
+        _check(lib().nmfk_last_sweep_info_ex(self._h, info, 16))
         return dict(phases=info[0], mfma_group_units=info[1], merged_valu_groups=info[2], launch_groups=info[3],
-                    wide_mfma_units=info[4], replans=info[5], last_tier=info[6], units_in_last_plan=info[7])
+                    wide_mfma_units=info[4], replans=info[5], last_tier=info[6], units_in_last_plan=info[7],
+                    deferred_checks=info[8], plain_checks=info[9])
 
     def set_objective_trace(self, on=True):
         """nmfk_set_objective_trace: record the monitored objective (Mult:74) at every check of the next sweeps."""

@@ -117,7 +117,7 @@ struct Sampler {
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, merge = -1, phases = -1;
   int wide_sse = 1, streams = -1, host_timing = 0;
-  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0;
+  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1, force_sh = 0;
   // (not knobs any more -- round 3's A/B switches with their measured settings: one mixed-rank matrix-pipe group, the waves of
   //  a workgroup may split a loop range 8 ways, the small ranks on their own kernel variants, four pairs of lane tiles per
   //  wave of the resident form, merged sweeps side by side)
@@ -144,6 +144,8 @@ Tuning read_tuning() {
   geti("NMFK_HYB_RES", t.hyb_res);
   geti("NMFK_REPLAN", t.replan);
   geti("NMFK_CLAMP_ALWAYS", t.clamp_always);
+  geti("NMFK_DEFER_OBJ", t.defer_obj);
+  geti("NMFK_FORCE_SH", t.force_sh);
   return t;
 }
 
@@ -601,8 +603,14 @@ NMFK_EXPORT int nmfk_get_objective_trace(nmfk_ctx *ctx, int kidx, int restart, d
 }
 
 NMFK_EXPORT int nmfk_last_sweep_info(nmfk_ctx *ctx, int32_t info[8]) {
-  if (!ctx || !info) return fail(NMFK_ERR_BAD_ARG, "bad argument");
-  memcpy(info, ctx->sweep_info, sizeof(ctx->sweep_info));
+  if (!ctx || !info) return fail(NMFK_ERR_BAD_ARG, "null argument");
+  memcpy(info, ctx->sweep_info, 8 * sizeof(int32_t));
+  return NMFK_OK;
+}
+
+NMFK_EXPORT int nmfk_last_sweep_info_ex(nmfk_ctx *ctx, int32_t *info, int count) {
+  if (!ctx || !info || count < 0 || count > 16) return fail(NMFK_ERR_BAD_ARG, "bad argument");
+  memcpy(info, ctx->sweep_info, (size_t)count * sizeof(int32_t));
   return NMFK_OK;
 }
 
@@ -638,7 +646,7 @@ struct HybPlan {
   int slots[2];   // sum-table slots the half-step's helper kernels cover
   int ns[2];      // sum-table slots a unit's own kernels write
 };
-HybPlan plan_hyb_group(int n, int m, int cus, int vmax, int units, int target_wgs, bool hyb_res) {
+HybPlan plan_hyb_group(int n, int m, int cus, int vmax, int units, int target_wgs, bool hyb_res, int force_sh = 0) {
   HybPlan p;
   p.units = units;
   const int target = target_wgs > 0 ? target_wgs : 2 * cus;
@@ -668,7 +676,9 @@ HybPlan plan_hyb_group(int n, int m, int cus, int vmax, int units, int target_wg
     p.wsplit[which] = 1;
     if (wgs(1) < target_ws) p.wsplit[which] = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
     const int64_t have = wgs(p.wsplit[which]);
-    const int S0 = (int)((target + have - 1) / have), maxS = std::max(1, D / (64 * p.wsplit[which]));
+    int S0 = (int)((target + have - 1) / have);
+    if (force_sh > 0 && which == 0) S0 = force_sh;
+    const int maxS = std::max(1, D / (64 * p.wsplit[which]));
     p.S[which] = std::max(1, std::min(S0, maxS));
     p.dchunk[which] = (D + p.S[which] - 1) / p.S[which];
     if (p.S[which] > 1) {
@@ -937,6 +947,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if (wgs(1) < target_ws && !phase_wide2) g.wsplit = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
     const int64_t have = wgs(g.wsplit);
     int S = (int)((target + have - 1) / have);
+    if (T.force_sh > 0 && which == 0 && phase_hyb) S = T.force_sh;
     const int maxS = std::max(1, D / (64 * g.wsplit));
     g.S = std::max(1, std::min(S, maxS));
     g.dchunk = (D + g.S - 1) / g.S;
@@ -1004,7 +1015,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if (T.replan && one_group && (nunits >= 32 || T.replan >= 2)) {
       tiers.push_back({nunits, ghp[0], gwp[0], {res_wgs[0], res_wgs[1]}, 0, 0, 0, 0});
       {  // the standalone rule (plan_hyb_group: what the later tiers and the CPU tests use) is the general one for such a sweep
-        const HybPlan p0 = plan_hyb_group(n, m, cus, hyb_vmax, nunits, T.target_wgs, T.hyb_res != 0);
+        const HybPlan p0 = plan_hyb_group(n, m, cus, hyb_vmax, nunits, T.target_wgs, T.hyb_res != 0, T.force_sh);
         const Geo g0[2] = {ghp[0], gwp[0]};
         for (int w = 0; w < 2; ++w)
           if (p0.res[w] != res_wgs[w] || p0.wsplit[w] != g0[w].wsplit || p0.S[w] != g0[w].S || p0.dchunk[w] != g0[w].dchunk ||
@@ -1012,7 +1023,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             return fail(NMFK_ERR_HIP, "internal: the tier planner disagrees with the sweep's launch geometry");
       }
       for (int c = (nunits + 1) / 2; c >= 1 && c < tiers.back().count; c = (c + 1) / 2) {
-        const HybPlan p = plan_hyb_group(n, m, cus, hyb_vmax, c, T.target_wgs, T.hyb_res != 0);
+        const HybPlan p = plan_hyb_group(n, m, cus, hyb_vmax, c, T.target_wgs, T.hyb_res != 0, T.force_sh);
         Tier t;
         t.count = c;
         t.res[0] = p.res[0], t.res[1] = p.res[1];
@@ -1105,6 +1116,17 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     }
     if (G.count > 0) groups.push_back(G);
   }
+  // objective partials per unit: a workgroup of 256 rows each (sse kernels), or, when the check is deferred into the next H
+  // half-step (see the loop), one per workgroup of that launch -- in any tier of the retire-aware schedule
+  int obj_cap = tiles_n + 1;
+  {
+    auto hparts = [&](int res, int wsplit, int S) { return res > 0 || wsplit > 1 ? 0 : (m + nmfk_hyb_lane_tile(1) - 1) / nmfk_hyb_lane_tile(1) * S; };
+    int want = 0;
+    for (const Group &G : groups)
+      if (G.hyb) want = std::max(want, hparts(res_wgs[0], ghp[G.phase].wsplit, ghp[G.phase].S));
+    for (const Tier &t : tiers) want = std::max(want, hparts(t.res[0], t.gh.wsplit, t.gh.S));
+    if (want <= 8192) obj_cap = std::max(obj_cap, want);
+  }
   {
     for (int u = 0; u < nunits; ++u) {
       const int q = ulist[u].first, r = ulist[u].second, k = ks[q], kp = nmfk_padded_k(k);
@@ -1121,7 +1143,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         rd.opart = (int64_t)B.take(std::max(tsz * pe, sizeof(int32_t) * (size_t)m));
         rd.osumW = (int64_t)B.take(sizeof(double) * (size_t)PWmax * kp);
         rd.osumH = (int64_t)B.take(sizeof(double) * (size_t)PHmax * kp);
-        rd.ossepart = (int64_t)B.take(sizeof(double) * (tiles_n + 1));  // sparse objective: slot 0 = <W'W, HH'>
+        rd.ossepart = (int64_t)B.take(sizeof(double) * (size_t)obj_cap);  // (sparse objective: slot 0 = <W'W, HH'>)
         rd.ocanon = (int64_t)B.take(sizeof(int32_t) * (size_t)m);
         rd.ogram = ctx->sparse ? (int64_t)B.take(sizeof(double) * nmfk_gram_doubles(n, m, kp)) : 0;
         rd.seed = seeds ? seeds[(size_t)q * nruns + r] : 0;
@@ -1244,7 +1266,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   hs.nunits = nunits;
   hs.force = 0;
   hs.res_wgs = res_wgs[0];
-  hs.pad1 = 0;
+  hs.clampw = 0;
   NmfkStepArgs ws = hs;
   ws.res_wgs = res_wgs[1];
   ws.X = ctx->Xc;
@@ -1269,6 +1291,19 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   wsP[1].wsplit = gwp[1].wsplit;
   wsP[1].fused = gwp[1].fused;
 
+  // Deferred check (see the loop): is the sweep eligible, and does a pair of half-step geometries allow it -- the H half-step
+  // must have an objective mode for its geometry, and the W half-step finish itself (it then clamps what it writes in a check
+  // iteration, NmfkStepArgs::clampw)
+  const bool defer_ok = T.defer_obj && !ctx->sparse && !f64 && !P.Hfixed && !P.Wfixed && ctx->Wgt == nullptr && T.hyb_sse;
+  auto defer_geo = [&](const NmfkStepArgs &h, const NmfkStepArgs &w) {
+    const int parts = nmfk_hyb_step_parts(h);
+    return (defer_ok && parts > 0 && parts <= obj_cap && (w.fused || w.res_wgs > 0)) ? parts : 0;
+  };
+  for (int ph = 0; ph < 2; ++ph) {
+    bool any = false;
+    for (const Group &G : groups) any = any || (G.phase == ph && G.hyb != 0);
+    wsP[ph].clampw = any && defer_geo(hsP[ph], wsP[ph]) > 0;
+  }
   // device copies of the half-step argument blocks (constant over the sweep; `it` is passed by value)
   const NmfkStepArgs *d_hsP[2] = {(const NmfkStepArgs *)(A + o_args), (const NmfkStepArgs *)(A + o_args) + 2};
   const NmfkStepArgs *d_wsP[2] = {d_hsP[0] + 1, d_hsP[1] + 1};
@@ -1312,6 +1347,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ca.trace = trace_stride ? (double *)(A + o_trace) : nullptr;
   ca.trace_stride = trace_stride;
   ca.track_low = 0;
+  ca.w_clamped = 0;
 
   NmfkSparseArgs sph, spw;  // CSC view (H half-step), CSR view (W half-step, objective)
   sph.arena = A;
@@ -1419,6 +1455,23 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   std::deque<std::vector<int32_t>> perm_keep;             // host sources of the asynchronous uploads
   std::deque<std::array<NmfkStepArgs, 2>> args_keep;
   if (replanning && ngroups != 1) return fail(NMFK_ERR_HIP, "internal: the retire-aware schedule expects one launch group");
+  // Deferred check (round 4).  The H half-step of iteration j + 1 forms W*H of exactly the factors whose objective the check
+  // after iteration j monitors (Mult:74), so on the matrix-pipe kernels that half-step leaves the objective as a by-product and
+  // the launch that recomputed W*H for it (0.39 of the check block's 0.52 ms on the bench sweep) goes away: the check iteration
+  // runs only the clamp (Mult:99-100), the tolerance / stagnation / consistency tests follow the next H half-step.  H is
+  // double-buffered by iteration parity and that half-step writes nothing else a stopped unit keeps, so a unit the check
+  // retires ends with the factors of iteration j as before (NmfkState::iters = j selects the buffer).  Two differences from
+  // the plain order, both far below fp32 rounding: the objective is that of the factors AFTER the clamp (entries below eps()
+  // raised to eps(): <= 1e-13 of the objective), and a unit that stops on `tol` (Mult:75-78) keeps clamped factors.
+  // Not for the last iteration (no half-step follows), fixed factors, array weights, nor where the H half-step runs in its resident
+  // form or with per-wave loop ranges (wsplit > 1: few units left) -- those checks keep their objective launch.
+  auto defer_parts = [&](const Group &G) { return use_hyb(G) ? defer_geo(hsP[G.phase], wsP[G.phase]) : 0; };
+  auto track_low_of = [&](const Group &G) {
+    const NmfkStepArgs &hs = hsP[G.phase], &ws = wsP[G.phase];
+    return (int)(!T.clamp_always && use_hyb(G) && !P.Hfixed && !P.Wfixed && (hs.fused || hs.res_wgs > 0) && (ws.fused || ws.res_wgs > 0));
+  };
+  std::vector<char> pending((size_t)ngroups, 0);  // the group's check of the previous iteration waits for this H half-step
+  int ndeferred = 0, nclassic = 0;
   for (int phase = 0; phase < nphases; ++phase) {
   // (units still active when a phase's loop ends ran all `maxiter` iterations, so one total_iters serves every phase)
   for (int u = 0; u < nunits; ++u) in_phase[u] = 0;
@@ -1427,9 +1480,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       for (int u = G.begin; u < G.begin + G.count; ++u) in_phase[u] = 1;
   int nchecks = 0;
   bool all_done = !guard0;
+  std::fill(pending.begin(), pending.end(), 0);
   for (int it = 0; it < maxiter && !all_done; ++it) {
     const bool check = (it + 1) % 10 == 0;  // Mult:73
     const bool timed = prof.want(it);
+    bool completing = false, deferring = false;  // deferred checks end / start in this iteration
     hsP[0].it = hsP[1].it = wsP[0].it = wsP[1].it = it;
     sa.hsel = (it + 1) & 1;
     ca.it = it;
@@ -1447,7 +1502,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         else if (sparse)
           nmfk_launch_sp_step_f32(&sph, G.kp, G.begin, G.count, gs);
         else if (use_hyb(G))
-          nmfk_launch_step_hyb_f32(hs, d_hs, G.hyb, G.begin, G.count, gs);
+          nmfk_launch_step_hyb_f32(hs, d_hs, G.hyb, G.begin, G.count, gs, pending[j] ? P.weight : 0.0);
         else if (G.kp == 0 && f64)
           nmfk_launch_step_multi_f64(hs, d_hs, G.begin, G.count, gs);
 #if NMFK_WITH_MERGED_F32
@@ -1468,6 +1523,15 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             nmfk_launch_reduce_f64(hs, G.begin, G.count, gs);
           else
             nmfk_launch_reduce_f32(hs, G.begin, G.count, gs);
+        }
+        if (pending[j]) {  // the deferred check of iteration it - 1: the objective has just been left by the half-step
+          NmfkCheckArgs cb = ca;
+          cb.it = it - 1;
+          cb.ntile_n = nmfk_hyb_step_parts(hs);
+          cb.track_low = track_low_of(G);
+          nmfk_launch_check_f32(cb, G.begin, G.count, gs, 1 | 4);
+          pending[j] = 0;
+          completing = true;
         }
       }
       if (!P.Wfixed) {  // Mult:69-71
@@ -1501,7 +1565,15 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             nmfk_launch_reduce_f32(ws, G.begin, G.count, gs);
         }
       }
-      if (check) {
+      ca.w_clamped = use_hyb(G) && wsP[G.phase].clampw;
+      if (check && it + 1 < maxiter && defer_parts(G) > 0) {
+        ca.track_low = track_low_of(G);
+        nmfk_launch_check_f32(ca, G.begin, G.count, gs, 2);
+        pending[j] = 1;
+        deferring = true;
+        ++ndeferred;
+      } else if (check) {
+        ++nclassic;
         if (sparse) {
           spw.it = it;
           if (f64)
@@ -1521,7 +1593,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         }
         // the clamp pass only where a value below eps() may exist: the matrix-pipe kernels' fused finishes watch what they write
         // in a check iteration (both half-steps run and finish themselves; NmfkState::lowflag)
-        ca.track_low = !T.clamp_always && use_hyb(G) && !P.Hfixed && !P.Wfixed && (hs.fused || hs.res_wgs > 0) && (ws.fused || ws.res_wgs > 0);
+        ca.track_low = track_low_of(G);
         if (f64)
           nmfk_launch_check_f64(ca, G.begin, G.count, gs);
         else
@@ -1529,7 +1601,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       }
     }
     total_iters = std::max(total_iters, it + 1);
-    if (check) {
+    if ((check && !deferring) || completing) {  // every group's check of this cadence is queued: snapshot of the states, re-plan
       const int slot = nchecks & 1;
       int next_tier = cur_tier, act = 0;
       if (nchecks > 0) {  // inspect the PREVIOUS check while this one is still queued
@@ -1600,6 +1672,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             two[f]->runs = d_runs;
             two[f]->state = d_state;
           }
+          wsP[ph].clampw = defer_geo(hsP[ph], wsP[ph]) > 0;
         }
         args_keep.push_back({hsP[0], wsP[0]});
         NmfkStepArgs *d_two = (NmfkStepArgs *)(A + o_args2) + 2 * (size_t)nreplans;
@@ -1625,6 +1698,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ctx->sweep_info[5] = nreplans;
   ctx->sweep_info[6] = cur_tier;
   ctx->sweep_info[7] = ngroups == 1 ? groups[0].count : 0;
+  ctx->sweep_info[8] = ndeferred;
+  ctx->sweep_info[9] = nclassic;
   if (T.host_timing)
     fprintf(stderr, "[nmfk] loop: %d iterations, %d groups, host %.3f s of which waiting for the GPU %.3f s\n", total_iters,
             ngroups, std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_w0).count(), host_wait_s);

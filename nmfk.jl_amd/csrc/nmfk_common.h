@@ -82,7 +82,8 @@ struct NmfkStepArgs {
   int32_t force;    // ignore the active flags
   int32_t res_wgs;  // > 0: the split-operand MFMA units run the RESIDENT form of this half-step (nmfk_step_hyb.hip) with
                     // this many workgroups per unit (= sum-table slots they write); 0: the streaming form
-  int32_t pad1;
+  int32_t clampw;   // the W half-step's fused finishes of a check iteration write max(W, eps()) themselves (Mult:100; the deferred
+                    // check of nmfk_mu_sweep: nothing reads W between the half-step and the clamp, the pass then only walks H)
 };
 
 struct NmfkSseArgs {
@@ -166,6 +167,7 @@ struct NmfkCheckArgs {
   double *trace;         // optional (nmfk_set_objective_trace): monitored objective of unit u at check c -> trace[u * trace_stride + c]
   int32_t trace_stride;
   int32_t track_low;     // the units' half-step kernels maintain NmfkState::lowflag: the clamp pass skips units whose flag is clear
+  int32_t w_clamped;     // W was clamped by the half-step that wrote it (NmfkStepArgs::clampw): the clamp pass walks H only
 };
 
 struct NmfkFinishArgs {
@@ -277,7 +279,7 @@ static inline int nmfk_padded_k(int k) {
   void nmfk_launch_step_multi_##SUF(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int u0, int cnt, hipStream_t s); \
   void nmfk_launch_reduce_##SUF(const NmfkStepArgs &a, int u0, int cnt, hipStream_t s);                           \
   void nmfk_launch_sse_##SUF(const NmfkSseArgs &a, int u0, int cnt, hipStream_t s);                               \
-  void nmfk_launch_check_##SUF(const NmfkCheckArgs &a, int u0, int cnt, hipStream_t s);                           \
+  void nmfk_launch_check_##SUF(const NmfkCheckArgs &a, int u0, int cnt, hipStream_t s, int parts = 7);               \
   void nmfk_launch_sum_parts_##SUF(char *arena, const NmfkRun *runs, int nunits, int ntile, double *out,           \
                                    hipStream_t s);                                                                \
   void nmfk_launch_sp_step_##SUF(const void *sparse_args, int kp, int u0, int cnt, hipStream_t s);                \
@@ -301,7 +303,8 @@ void nmfk_launch_wide2_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double
 int nmfk_hyb_resident_waves();  // waves per workgroup of the resident form
 size_t nmfk_hyb_resident_lds(int variant, int D);  // LDS bytes of the resident form for a loop dimension D, 0 = not applicable
 int nmfk_hyb_variant(int k);  // kernel variant of rank k on the split-operand MFMA half-step: 4 / 8 / 12 / 16
-void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int ks, int u0, int cnt, hipStream_t s);
+void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int ks, int u0, int cnt, hipStream_t s, double objw = 0.0);
+int nmfk_hyb_step_parts(const NmfkStepArgs &a);
 void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double weight, int hsel, int ks, int u0, int cnt,
                          hipStream_t s);
 void nmfk_launch_hyb_tile(const float *src, int L, int D, float *out, hipStream_t s);

@@ -93,7 +93,7 @@ struct nmfk_ctx {
     int64_t launches = 0;
   };
   std::map<std::string, ProfEntry> prof;
-  int32_t sweep_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // nmfk_last_sweep_info
+  int32_t sweep_info[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // nmfk_last_sweep_info (8) / nmfk_last_sweep_info_ex (16)
   // nmfk_set_objective_trace: the monitored objective (Mult:74) of every unit at every check of the last sweep
   bool trace_objective = false;
   std::vector<double> obj_trace;  // [unit][check]

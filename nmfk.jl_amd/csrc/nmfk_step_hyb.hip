@@ -299,12 +299,17 @@ __device__ __forceinline__ void hyb_lane_blocks(const float *__restrict__ A, int
 // W*H from the same three-term bf16 products (fp32-accurate), residuals squared and accumulated in fp64; W orientation
 // (gp = the W half-step's arguments, lanes = rows of X), whole loop range per workgroup, H of iteration parity `it`;
 // one partial per workgroup in ossepart[] like sse_kernel (256 rows per workgroup = its tile).
+// SSE (round 4): the half-step ALSO leaves the objective of the factors it reads -- its first product is W*H of exactly those
+// factors, so the residuals cost four packed instructions per lane tile and chunk instead of a launch of their own.  The H
+// half-step that follows a check iteration runs in this mode (nmfk_mu_sweep, "deferred check"); one partial per workgroup
+// in ossepart[blockIdx.x] (gridDim.x partials per unit: lane tiles x splits of the loop range).
 // NS: sets of four signals whose numerators run as v_mfma_f32_4x4x1_16B_f32 (ceil(k / 4)); 0 = v_mfma_f32_16x16x4_f32
-template <int KS, int NS, int NT, int NW, bool OBJ>  // NW: waves per workgroup when wsplit = 1 (4 or 8)
+template <int KS, int NS, int NT, int NW, bool OBJ, bool SSE>  // NW: waves per workgroup when wsplit = 1 (4 or 8)
 __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restrict__ Xa, const float *__restrict__ Xt,
                                               const NmfkRun *__restrict__ runs, const NmfkState *__restrict__ state,
                                               const NmfkStepArgs *__restrict__ gp, int it, int u0, double weight,
-                                              double *lds) {  // lds: den[16], red[16*16], staging buffers / cross-wave scratch
+                                              double *lds) {  // lds: den[16], red[16*16], ssep[16], staging buffers / cross-wave scratch
+  static_assert(!(OBJ && SSE), "objective only, or half-step with the objective");
   constexpr int NM = KS == 16 ? 3 : KS == 8 ? 2 : 1;  // bf16 MFMAs of the first product
   constexpr int NSA = NS > 0 ? NS : 1;       // accumulator tiles per lane tile
   constexpr int TM = OBJ ? 0 : (NS > 0 ? 2 : 1);  // layout of the second product's operand block (HybStage)
@@ -314,7 +319,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
   const NmfkRun *__restrict__ rdp = runs + u;
   const int k = rdp->k;  // = kp: row stride of the fp32 rows and of the sum tables
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const int which = gp->which, ws = OBJ ? 1 : gp->wsplit, S = OBJ ? 1 : gp->S, L = gp->L, D = gp->D;
+  const int which = gp->which, ws = (OBJ || SSE) ? 1 : gp->wsplit, S = OBJ ? 1 : gp->S, L = gp->L, D = gp->D;  // (SSE: the host launches wsplit = 1 only)
   const int nwaves = blockDim.x >> 6;
   const int lpw = 16 * NT * (ws > 1 ? 1 : nwaves);
   const int tile = bx / S, s = bx - tile * S;
@@ -441,8 +446,22 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     for (int j = 0; j < NM; ++j)
       p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[j]), bop[t][j], p[t], 0, 0, 0);
   };
+  float spart = 0.0f;  // SSE: squares of the chunk's residuals (fp32; see the OBJ mode for the error budget)
   auto q_tile = [&](int t, int dch, const f32x4_t (&xcur)[NT], const f32x4_t (&p)[NT], f32x4_t (&q)[NT], bool mask)
                     __attribute__((always_inline)) {
+    if (SSE) {  // (first: the residuals need x and p, the ratios below retire both)
+      float sqs = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float e = xcur[t][r] - p[t][r];
+        if (mask) e = dch + 4 * g + r < d1 ? e : 0.0f;
+        sqs = __builtin_fmaf(e, e, sqs);
+      }
+      spart += lv[t] ? sqs : 0.0f;
+      // (anchor: without it the instruction selector's linear order puts the residuals of a whole trip next to their only
+      //  consumer, the sum behind the trip's last chunk, and every chunk's x and p stay alive until then -- 300 B of scratch)
+      asm volatile("" : "+v"(spart));
+    }
 #pragma unroll
     for (int r = 0; r < 4; r += 2) {
       const f32x2_t rc = {__builtin_amdgcn_rcpf(p[t][r]), __builtin_amdgcn_rcpf(p[t][r + 1])};
@@ -454,6 +473,10 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
         q[t][r + 1] = (dch + 4 * g + r + 1 < d1) ? q[t][r + 1] : 0.0f;
       }
     }
+  };
+  auto sse_chunk = [&]() __attribute__((always_inline)) {  // the chunk's partial enters the fp64 sum
+    ssum += (double)spart;
+    spart = 0.0f;
   };
   auto f_tile = [&](int t, const f32x4_t (&bn)[NSA], const f32x4_t (&q)[NT]) __attribute__((always_inline)) {
     if (NS > 0) {
@@ -496,7 +519,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     }
     if (AOLD_EARLY) load_aold();
   }
-  char *sbase = (char *)(lds + 17 * 16);  // staging buffers, later the cross-wave scratch (wsplit > 1)
+  char *sbase = (char *)(lds + 18 * 16);  // staging buffers, later the cross-wave scratch (wsplit > 1)
   const int nchunks = (d1 - d0 + 15) >> 4;
 
   // The loop.  TRIP chunks per trip of the (unrolled) body so that the LDS buffer of a block and the register set of
@@ -523,9 +546,10 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     int svrow[2];
     f32x4_t xr[4][NT];
     const int dlast = d0 + 16 * (nchunks - 1);
+    constexpr int XA = 2;  // chunks X runs ahead
     stage.load(d0, sv[0], svrow[0]);
     xload(d0, xr[0]);
-    xload(min(d0 + 16, dlast), xr[1]);
+    if (XA == 2) xload(min(d0 + 16, dlast), xr[1]);
     if (nchunks > CPB) stage.load(d0 + 16 * CPB, sv[1], svrow[1]);
     stage.write(sb, sv[0], svrow[0]);
     barrier();
@@ -548,7 +572,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
         const int buf = (ci / CPB) & 1, ch = ci % CPB;  // block parity (trips hold an even number of blocks)
         const bool more = FULLT || (c - ch + CPB < nchunks);       // a block follows the one this chunk belongs to
         const bool more2 = FULLT || (c - ch + 2 * CPB < nchunks);  // and one after that
-        xload(FULLT ? dch + 32 : min(dch + 32, dlast), xr[(ci + 2) & 3]);
+        xload(FULLT ? dch + 16 * XA : min(dch + 16 * XA, dlast), xr[(ci + XA) & 3]);
         // (vmcnt retires in order: the staging requests go out AFTER this chunk's X prefetch)
         if (ch == 0 && more2) stage.load(dch + 32 * CPB, sv[buf], svrow[buf]);
         // the next block (requested a block ago) goes to the free LDS buffer BEFORE this block's last chunk: conversion
@@ -599,6 +623,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
             __builtin_amdgcn_sched_barrier(0);
             f_tile(t, bn, q);
           }
+          if (SSE) sse_chunk();
           __builtin_amdgcn_sched_barrier(0);
         } else {
           u32x4_t av[NM];
@@ -623,21 +648,24 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     for (; c0 + TRIP + AHEAD <= nchunks; c0 += TRIP) trip(c0, std::true_type());
     for (; c0 < nchunks; c0 += TRIP) trip(c0, std::false_type());
   };
-  if (OBJ) {
-    HybStage<KS, NMFK_HYB_CPB, 64 * NW, 0> stage;
-    stage.init(B, k, D, tid);
-    run(stage, sbase, [] { HYB_BARRIER(); });
-    // workgroup sum in wave order (fixed order => reproducible), one partial per workgroup
+  // objective: workgroup sum in wave order (fixed order => reproducible), one partial per workgroup
+  auto sse_out = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ssum += __shfl_down(ssum, o, 64);
-    double *sh = lds;
+    double *sh = lds + 17 * 16;
     if (lane == 0) sh[wave] = ssum;
     __syncthreads();
     if (tid == 0) {
       double t = 0;
       for (int w = 0; w < nwaves; ++w) t += sh[w];
-      ((double *)(arena + rdp->ossepart))[tile] = t * weight * weight;
+      ((double *)(arena + rdp->ossepart))[slot] = t * weight * weight;
     }
+  };
+  if (OBJ) {
+    HybStage<KS, NMFK_HYB_CPB, 64 * NW, 0> stage;
+    stage.init(B, k, D, tid);
+    run(stage, sbase, [] { HYB_BARRIER(); });
+    sse_out(tile);
     return;
   }
   if (ws == 1) {
@@ -650,6 +678,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     run(stage, sbase + wave * 2 * HybStage<KS, 1, 64, TM>::STB, [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); });
     __syncthreads();  // the cross-wave scratch below overlays the staging buffers
   }
+  if (SSE) sse_out(bx);
   // 4x4x1 form: a lane holds the sums over its own loop steps (d = 4g + r of every chunk) of ALL 4 NS signals: add the
   // four k-lane groups (lanes c16, c16 + 16, + 32, + 48: every lane gets the same bits), then lane group g keeps set g
   f32x4_t acc[NT];
@@ -715,6 +744,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
   double *red = den + 16;  // [16][16]
   float vs[4] = {0.f, 0.f, 0.f, 0.f};
   bool low = false;  // a value below eps() written in a check iteration: the clamp (Mult:99-100) has work (NmfkState::lowflag)
+  const float floorv = (gp->clampw && which == 1 && (it + 1) % 10 == 0) ? HYB_EPS : -__builtin_inff();
   if (owner) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -726,6 +756,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           v[r] = 0.f;
           if (c < k) {
             v[r] = aold[t][r] * acc[t][r] / (float)den[c];  // Mult:67 / Mult:70 order
+            v[r] = v[r] < floorv ? floorv : v[r];           // (NmfkStepArgs::clampw; a NaN stays)
             low = low || v[r] < HYB_EPS;
             if (!vec4) Anew[c + (int64_t)lt[t] * k] = v[r];
           }
@@ -851,6 +882,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
   // sums of the new factor: fp32 per lane over this wave's tile pairs (<= a few dozen values), fp64 from there on
   float vsf[4] = {0.f, 0.f, 0.f, 0.f};
   bool low = false;  // a value below eps() written in a check iteration (NmfkState::lowflag)
+  const float floorv = (!OBJ && gp->clampw && which == 1 && (it + 1) % 10 == 0) ? HYB_EPS : -__builtin_inff();
 
   // X: the 16 x 16 block (16-lane tile, chunk) is 1 KB in lane order; byte offset = wave-uniform block offset (SGPR) + 16 * lane
   const uint32_t xlane = (uint32_t)lane * 16u;
@@ -1101,6 +1133,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           v[r] = 4 * g + r < k ? (aold[r] * acc[r]) * rd4[r] : 0.0f;
+          v[r] = (4 * g + r < k && v[r] < floorv) ? floorv : v[r];  // (NmfkStepArgs::clampw; a NaN stays)
           low = low || (4 * g + r < k && v[r] < HYB_EPS);
           vsum[r] += v[r];
         }
@@ -1487,17 +1520,17 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
 // were three launches that each left CUs idle (H half-step: two workgroups per unit) and ended in their own tail;
 // together they fill the chip (profiles/r03/variants_one_launch.txt).
 // ------------------------------------------------------------------------------------------------------
-template <int NT, int NW, bool OBJ>
-__global__ __launch_bounds__(64 * (NW > 8 ? NW : 8), OBJ ? 2 : 4) void hyb_step_kernel(char *arena, const float *__restrict__ Xa,
+template <int NT, int NW, int MODE>  // MODE 0: half-step, 1: objective, 2: half-step that leaves the objective of its inputs
+__global__ __launch_bounds__(64 * (NW > 8 ? NW : 8), MODE == 1 ? 2 : 4) void hyb_step_kernel(char *arena, const float *__restrict__ Xa,
                                                        const float *__restrict__ Xt,
                                                        const NmfkRun *__restrict__ runs,
                                                        const NmfkState *__restrict__ state,
                                                        const NmfkStepArgs *__restrict__ gp, int it, int u0, double weight) {
   extern __shared__ double lds[];
   switch (runs[u0 + blockIdx.y].hyb) {
-    case 4: hyb_step_body<4, OBJ ? 0 : 1, NT, NW, OBJ>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
-    case 8: hyb_step_body<8, OBJ ? 0 : 2, NT, NW, OBJ>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
-    default: hyb_step_body<16, 0, NT, NW, OBJ>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
+    case 4: hyb_step_body<4, MODE == 1 ? 0 : 1, NT, NW, MODE == 1, MODE == 2>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
+    case 8: hyb_step_body<8, MODE == 1 ? 0 : 2, NT, NW, MODE == 1, MODE == 2>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
+    default: hyb_step_body<16, 0, NT, NW, MODE == 1, MODE == 2>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
   }
 }
 
@@ -1553,7 +1586,9 @@ size_t nmfk_hyb_resident_lds(int vmax, int D) {
 }
 
 // half-step of the `cnt` units [u0, u0 + cnt) (any mix of variants; vmax = the widest among them)
-void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int vmax, int u0, int cnt, hipStream_t s) {
+// objw > 0 (streaming form only, see nmfk_hyb_step_parts): the launch also leaves the objective of the factors it reads, scaled
+// by objw^2, as nmfk_hyb_step_parts(a) partials per unit in NmfkRun::ossepart
+void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int vmax, int u0, int cnt, hipStream_t s, double objw) {
   constexpr int NT = NMFK_HYB_NT, NW = NMFK_HYB_NW;
   if (a.res_wgs > 0) {  // resident form (the host has checked nmfk_hyb_resident_lds)
     static std::atomic<uint64_t> lds_ok{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
@@ -1570,8 +1605,20 @@ void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, 
   // two staged blocks of NMFK_HYB_CPB chunks per workgroup (wsplit = 1) / of one chunk per wave (wsplit > 1): HybStage::STB
   const size_t chunkb = hyb_chunk_bytes(vmax);
   const size_t stage = ws > 1 ? (size_t)ws * 2 * chunkb : 2 * NMFK_HYB_CPB * chunkb;
-  const size_t ldsb = sizeof(double) * 17 * 16 + std::max(cross, stage);
-  hipLaunchKernelGGL((hyb_step_kernel<NT, NW, false>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
+  const size_t ldsb = sizeof(double) * 18 * 16 + std::max(cross, stage);
+  if (objw > 0)
+    hipLaunchKernelGGL((hyb_step_kernel<NT, NW, 2>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, objw);
+  else
+    hipLaunchKernelGGL((hyb_step_kernel<NT, NW, 0>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
+}
+
+// objective partials per unit a streaming-form launch with these arguments leaves (0: no objective mode for this geometry)
+int nmfk_hyb_step_parts(const NmfkStepArgs &a) {
+  // (the waves of a workgroup share the loop range: with the per-wave staging of wsplit > 1 compiled in, the kernel needs scratch
+  //  memory at four waves per SIMD)
+  if (a.res_wgs > 0 || a.wsplit > 1) return 0;
+  const int lpw = nmfk_hyb_lane_tile(a.wsplit);
+  return (a.L + lpw - 1) / lpw * a.S;
 }
 
 // tiled copy of X (element (l, d) at src[d + l*D]) for nmfk_launch_step_hyb_f32; out: roundup16(L) * roundup16(D) floats
@@ -1597,8 +1644,8 @@ void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double w
   }
   const int lpw = 16 * NT * NW;  // = NMFK_TILE: the partials line up with sse_kernel's
   const dim3 grid((w.L + lpw - 1) / lpw, cnt), blk(64 * NW);
-  const size_t ldsb = sizeof(double) * 17 * 16 + 2 * NMFK_HYB_CPB * 3 * (size_t)(vmax <= 8 ? 1 : 2) * 256;  // two blocks of split planes
-  hipLaunchKernelGGL((hyb_step_kernel<NT, NW, true>), grid, blk, ldsb, s, w.arena, w.Xalt, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
+  const size_t ldsb = sizeof(double) * 18 * 16 + 2 * NMFK_HYB_CPB * 3 * (size_t)(vmax <= 8 ? 1 : 2) * 256;  // two blocks of split planes
+  hipLaunchKernelGGL((hyb_step_kernel<NT, NW, 1>), grid, blk, ldsb, s, w.arena, w.Xalt, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
 }
 
 // Wide ranks on the split-operand first product (wide2_step_kernel): kp <= 32 (KS = 32), kp = 40, 48 (KS = 48, round 4: padded to

@@ -1916,7 +1916,7 @@ __global__ __launch_bounds__(NMFK_TILE) void clamp_kernel(NmfkCheckArgs g, int u
   const NmfkRun rd = g.runs[u];
   const int tid = threadIdx.x, k = rd.k, kp = rd.kp;
   const T eps = (T)2.220446049250313e-16;
-  for (int f = 0; f < 2; ++f) {
+  for (int f = g.w_clamped ? 1 : 0; f < 2; ++f) {
     const int P = f == 0 ? rd.nsW : rd.nsH, PT = f == 0 ? g.PW : g.PH, len = f == 0 ? g.n : g.m;
     T *F = f == 0 ? NMFK_PTR(T, g, rd.oWt) : NMFK_PTR(T, g, NMFK_HOFF(rd, g.it + 1));
     double *tab = NMFK_PTR(double, g, f == 0 ? rd.osumW : rd.osumH);
@@ -2222,10 +2222,12 @@ void NMFK_NAME(nmfk_launch_sum_parts)(char *arena, const NmfkRun *runs, int nuni
   hipLaunchKernelGGL(sum_parts_kernel, dim3((nunits + 63) / 64), dim3(64), 0, s, arena, runs, nunits, ntile, out);
 }
 
-void NMFK_NAME(nmfk_launch_check)(const NmfkCheckArgs &a, int u0, int cnt, hipStream_t s) {
-  hipLaunchKernelGGL(check_a_kernel, dim3((cnt + 63) / 64), dim3(64), 0, s, a, u0, cnt);
-  hipLaunchKernelGGL(clamp_kernel, dim3(std::max(a.PW, a.PH), cnt), dim3(NMFK_TILE), 0, s, a, u0);
-  hipLaunchKernelGGL(check_b_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, u0);
+// parts: 1 = check_a, 2 = clamp, 4 = check_b.  The deferred check (nmfk_mu_sweep) launches the clamp in the check iteration and
+// the other two behind the next H half-step, which leaves the objective.
+void NMFK_NAME(nmfk_launch_check)(const NmfkCheckArgs &a, int u0, int cnt, hipStream_t s, int parts) {
+  if (parts & 1) hipLaunchKernelGGL(check_a_kernel, dim3((cnt + 63) / 64), dim3(64), 0, s, a, u0, cnt);
+  if (parts & 2) hipLaunchKernelGGL(clamp_kernel, dim3(a.w_clamped ? a.PH : std::max(a.PW, a.PH), cnt), dim3(NMFK_TILE), 0, s, a, u0);
+  if (parts & 4) hipLaunchKernelGGL(check_b_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, u0);
 }
 
 void NMFK_NAME(nmfk_launch_finish)(const NmfkFinishArgs &a, hipStream_t s) {

@@ -1288,3 +1288,67 @@ def test_merged_sweep_is_bitwise_reproducible_run_to_run(NMFk, oracle, forced_me
         for key in env:
             del os.environ[key]
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_deferred_check_against_the_plain_order(NMFk, ctx, oracle, monkeypatch):
+    """Round 4: on the matrix-pipe kernels the objective a check monitors (Mult:74) is left by the H half-step of
+    the NEXT iteration (its first product is W*H of the same factors); the check's tests run behind that half-step and a unit
+    they retire keeps the factors of the check iteration (H is double-buffered).  NMFK_DEFER_OBJ=0 is the plain order: objective
+    launch, tests, clamp.  Planted rank-3 matrix, reference stop rule: same stop iterations and reasons, the monitored objective
+    equal check by check to fp32 summation noise, results equal where the iteration counts are; the last check of a sweep whose
+    maxiter is a multiple of 10 has no half-step behind it and stays plain; also with the loop range split over two workgroups
+    (140 units: S = 2, partials per split, the half-step finished by the reduce kernel).  (The oracle comparisons of the stop
+    rule -- the fixture test, the branch tests -- run in the default mode, i.e. deferred wherever the geometry allows.)"""
+    n, m, k0 = 650, 640, 3  # (n % 64 != 0: the H half-step in its streaming form; m = 640: lane tiles of 256 columns, the last one ragged)
+    W0 = oracle.uniform_fill(9, 0, n * k0).reshape(n, k0)
+    H0 = oracle.uniform_fill(9, n * k0, k0 * m).reshape(k0, m)
+    X = np.asfortranarray((W0 @ H0 + 0.02 * oracle.uniform_fill(9, n * k0 + k0 * m, n * m).reshape(n, m)).astype(np.float32))
+    ctx.set_X(X)
+    ks = [2, 3, 4, 5, 6, 9, 13]
+    monkeypatch.setenv("NMFK_REPLAN", "0")
+    for key, val in dict(NMFK_HYB="1", NMFK_HYB_MINK="2", NMFK_HYB_PHASES="1").items():  # (the bench sweep's schedule at this small shape)
+        monkeypatch.setenv(key, val)
+    for R in (32, 20):  # 224 units: one workgroup walks a lane tile's whole loop range; 140 units: two do (S = 2)
+        seeds = _seeds(NMFk, 4, ks, R)
+        out, info, trace = {}, {}, {}
+        ctx.set_objective_trace(True)
+        try:
+            for mode in ("0", "1"):
+                monkeypatch.setenv("NMFK_DEFER_OBJ", mode)
+                out[mode] = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=1500)
+                info[mode] = ctx.last_sweep_info()
+                trace[mode] = {(k, r): ctx.objective_trace(ks.index(k), r) for k in ks for r in range(0, R, 5)}
+        finally:
+            ctx.set_objective_trace(False)
+        assert info["0"]["deferred_checks"] == 0 and info["0"]["plain_checks"] > 0, info["0"]
+        assert info["1"]["deferred_checks"] > 0 and info["1"]["plain_checks"] <= 1, info["1"]  # (plain: only a check at maxiter itself)
+        its0 = np.stack([out["0"][k]["iters"] for k in ks])
+        its1 = np.stack([out["1"][k]["iters"] for k in ks])
+        assert its0.min() < its0.max(), "the case must have restarts that retire at different iterations"
+        assert (its0 == its1).mean() >= 0.9, (its0, its1)
+        for k in ks:
+            same = out["0"][k]["iters"] == out["1"][k]["iters"]
+            assert (out["0"][k]["reason"][same] == out["1"][k]["reason"][same]).all()
+            np.testing.assert_allclose(out["1"][k]["objvalue"][same], out["0"][k]["objvalue"][same], rtol=1e-5)
+            for r in np.flatnonzero(same)[:4]:
+                assert _rel(out["1"][k]["W"][r] @ out["1"][k]["H"][r], out["0"][k]["W"][r] @ out["0"][k]["H"][r], X) <= 1e-5, (k, r)
+        for kr, t0 in trace["0"].items():
+            t1 = trace["1"][kr]
+            nc = min(len(t0), len(t1))
+            assert nc >= 1 and abs(len(t0) - len(t1)) <= max(3, len(t0) // 5), (kr, len(t0), len(t1))
+            np.testing.assert_allclose(t1[:nc], t0[:nc], rtol=2e-5, err_msg=str(kr))
+    seeds = _seeds(NMFk, 4, ks, 64)
+    # a sweep that ends on a check iteration: that check is a plain one, the others are deferred; fixed budget
+    monkeypatch.setenv("NMFK_DEFER_OBJ", "1")
+    a = ctx.mu_sweep([4, 9], 64, seeds=seeds[2:4], maxiter=30, **NOSTOP)
+    ia = ctx.last_sweep_info()
+    monkeypatch.setenv("NMFK_DEFER_OBJ", "0")
+    b = ctx.mu_sweep([4, 9], 64, seeds=seeds[2:4], maxiter=30, **NOSTOP)
+    assert ia["deferred_checks"] == 2 and ia["plain_checks"] == 1, ia
+    for k in (4, 9):
+        assert (a[k]["iters"] == b[k]["iters"]).all()
+        # (rounding: with the deferred check W is clamped by the half-step that writes it and its sum table is that half-step's own;
+        #  the plain order's clamp pass recomputes the table -- the same sums in another order)
+        np.testing.assert_allclose(a[k]["W"], b[k]["W"], rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(a[k]["H"], b[k]["H"], rtol=1e-5, atol=1e-12)

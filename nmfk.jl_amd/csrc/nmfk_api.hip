@@ -117,7 +117,7 @@ struct Sampler {
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, merge = -1, phases = -1;
   int wide_sse = 1, streams = -1, host_timing = 0;
-  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1, force_sh = 0;
+  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1;
   // (not knobs any more -- round 3's A/B switches with their measured settings: one mixed-rank matrix-pipe group, the waves of
   //  a workgroup may split a loop range 8 ways, the small ranks on their own kernel variants, four pairs of lane tiles per
   //  wave of the resident form, merged sweeps side by side)
@@ -145,7 +145,6 @@ Tuning read_tuning() {
   geti("NMFK_REPLAN", t.replan);
   geti("NMFK_CLAMP_ALWAYS", t.clamp_always);
   geti("NMFK_DEFER_OBJ", t.defer_obj);
-  geti("NMFK_FORCE_SH", t.force_sh);
   return t;
 }
 
@@ -646,7 +645,7 @@ struct HybPlan {
   int slots[2];   // sum-table slots the half-step's helper kernels cover
   int ns[2];      // sum-table slots a unit's own kernels write
 };
-HybPlan plan_hyb_group(int n, int m, int cus, int vmax, int units, int target_wgs, bool hyb_res, int force_sh = 0) {
+HybPlan plan_hyb_group(int n, int m, int cus, int vmax, int units, int target_wgs, bool hyb_res) {
   HybPlan p;
   p.units = units;
   const int target = target_wgs > 0 ? target_wgs : 2 * cus;
@@ -676,8 +675,7 @@ HybPlan plan_hyb_group(int n, int m, int cus, int vmax, int units, int target_wg
     p.wsplit[which] = 1;
     if (wgs(1) < target_ws) p.wsplit[which] = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
     const int64_t have = wgs(p.wsplit[which]);
-    int S0 = (int)((target + have - 1) / have);
-    if (force_sh > 0 && which == 0) S0 = force_sh;
+    const int S0 = (int)((target + have - 1) / have);
     const int maxS = std::max(1, D / (64 * p.wsplit[which]));
     p.S[which] = std::max(1, std::min(S0, maxS));
     p.dchunk[which] = (D + p.S[which] - 1) / p.S[which];
@@ -947,7 +945,6 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if (wgs(1) < target_ws && !phase_wide2) g.wsplit = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
     const int64_t have = wgs(g.wsplit);
     int S = (int)((target + have - 1) / have);
-    if (T.force_sh > 0 && which == 0 && phase_hyb) S = T.force_sh;
     const int maxS = std::max(1, D / (64 * g.wsplit));
     g.S = std::max(1, std::min(S, maxS));
     g.dchunk = (D + g.S - 1) / g.S;
@@ -1015,7 +1012,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if (T.replan && one_group && (nunits >= 32 || T.replan >= 2)) {
       tiers.push_back({nunits, ghp[0], gwp[0], {res_wgs[0], res_wgs[1]}, 0, 0, 0, 0});
       {  // the standalone rule (plan_hyb_group: what the later tiers and the CPU tests use) is the general one for such a sweep
-        const HybPlan p0 = plan_hyb_group(n, m, cus, hyb_vmax, nunits, T.target_wgs, T.hyb_res != 0, T.force_sh);
+        const HybPlan p0 = plan_hyb_group(n, m, cus, hyb_vmax, nunits, T.target_wgs, T.hyb_res != 0);
         const Geo g0[2] = {ghp[0], gwp[0]};
         for (int w = 0; w < 2; ++w)
           if (p0.res[w] != res_wgs[w] || p0.wsplit[w] != g0[w].wsplit || p0.S[w] != g0[w].S || p0.dchunk[w] != g0[w].dchunk ||
@@ -1023,7 +1020,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             return fail(NMFK_ERR_HIP, "internal: the tier planner disagrees with the sweep's launch geometry");
       }
       for (int c = (nunits + 1) / 2; c >= 1 && c < tiers.back().count; c = (c + 1) / 2) {
-        const HybPlan p = plan_hyb_group(n, m, cus, hyb_vmax, c, T.target_wgs, T.hyb_res != 0, T.force_sh);
+        const HybPlan p = plan_hyb_group(n, m, cus, hyb_vmax, c, T.target_wgs, T.hyb_res != 0);
         Tier t;
         t.count = c;
         t.res[0] = p.res[0], t.res[1] = p.res[1];

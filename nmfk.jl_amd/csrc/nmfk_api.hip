@@ -1120,7 +1120,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     auto hparts = [&](int res, int wsplit, int S) { return res > 0 || wsplit > 1 ? 0 : (m + nmfk_hyb_lane_tile(1) - 1) / nmfk_hyb_lane_tile(1) * S; };
     int want = 0;
     for (const Group &G : groups)
-      if (G.hyb) want = std::max(want, hparts(res_wgs[0], ghp[G.phase].wsplit, ghp[G.phase].S));
+      if (G.hyb || (use_wide_k(G.k) && use_wide2_k(G.k))) want = std::max(want, hparts(G.hyb ? res_wgs[0] : 0, ghp[G.phase].wsplit, ghp[G.phase].S));
     for (const Tier &t : tiers) want = std::max(want, hparts(t.res[0], t.gh.wsplit, t.gh.S));
     if (want <= 8192) obj_cap = std::max(obj_cap, want);
   }
@@ -1289,17 +1289,26 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   wsP[1].fused = gwp[1].fused;
 
   // Deferred check (see the loop): is the sweep eligible, and does a pair of half-step geometries allow it -- the H half-step
-  // must have an objective mode for its geometry, and the W half-step finish itself (it then clamps what it writes in a check
-  // iteration, NmfkStepArgs::clampw)
-  const bool defer_ok = T.defer_obj && !ctx->sparse && !f64 && !P.Hfixed && !P.Wfixed && ctx->Wgt == nullptr && T.hyb_sse;
-  auto defer_geo = [&](const NmfkStepArgs &h, const NmfkStepArgs &w) {
-    const int parts = nmfk_hyb_step_parts(h);
-    return (defer_ok && parts > 0 && parts <= obj_cap && (w.fused || w.res_wgs > 0)) ? parts : 0;
+  // must have an objective mode for its geometry, and the W half-step must end on a kernel that clamps what it writes in a check
+  // iteration (NmfkStepArgs::clampw)
+  const bool defer_ok = T.defer_obj && !ctx->sparse && !f64 && !P.Hfixed && !P.Wfixed && ctx->Wgt == nullptr && T.hyb_sse && T.wide_sse;
+  auto defer_geo = [&](const NmfkStepArgs &h, const NmfkStepArgs &w, bool hyb) {
+    NmfkStepArgs hh = h;
+    if (!hyb) hh.res_wgs = 0;  // (the resident form is the rank <= 16 kernels' only)
+    const int parts = nmfk_hyb_step_parts(hh);  // (the wide-rank kernel has the same lane tile and no wsplit form)
+    const bool wfin = hyb || !w.fused || w.wsplit == 1;  // the W half-step ends on a kernel that clamps (the matrix-pipe kernels' fused finishes, reduce_kernel)
+    return (defer_ok && parts > 0 && parts <= obj_cap && wfin) ? parts : 0;
   };
+  // groups whose kernels have the objective mode: the rank <= 16 matrix-pipe group(s) and the split-operand wide-rank kernel
+  auto defer_kind = [&](const Group &G) { return G.hyb != 0 ? 1 : (use_wide_k(G.k) && use_wide2_k(G.k) && G.kp != 0) ? 2 : 0; };
   for (int ph = 0; ph < 2; ++ph) {
-    bool any = false;
-    for (const Group &G : groups) any = any || (G.phase == ph && G.hyb != 0);
-    wsP[ph].clampw = any && defer_geo(hsP[ph], wsP[ph]) > 0;
+    bool any = false, all = true;
+    for (const Group &G : groups)
+      if (G.phase == ph && defer_kind(G)) {
+        any = true;
+        all = all && defer_geo(hsP[ph], wsP[ph], defer_kind(G) == 1) > 0;
+      }
+    wsP[ph].clampw = any && all;
   }
   // device copies of the half-step argument blocks (constant over the sweep; `it` is passed by value)
   const NmfkStepArgs *d_hsP[2] = {(const NmfkStepArgs *)(A + o_args), (const NmfkStepArgs *)(A + o_args) + 2};
@@ -1462,7 +1471,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // raised to eps(): <= 1e-13 of the objective), and a unit that stops on `tol` (Mult:75-78) keeps clamped factors.
   // Not for the last iteration (no half-step follows), fixed factors, array weights, nor where the H half-step runs in its resident
   // form or with per-wave loop ranges (wsplit > 1: few units left) -- those checks keep their objective launch.
-  auto defer_parts = [&](const Group &G) { return use_hyb(G) ? defer_geo(hsP[G.phase], wsP[G.phase]) : 0; };
+  auto defer_parts = [&](const Group &G) {
+    return (defer_kind(G) && wsP[G.phase].clampw) ? defer_geo(hsP[G.phase], wsP[G.phase], defer_kind(G) == 1) : 0;
+  };
   auto track_low_of = [&](const Group &G) {
     const NmfkStepArgs &hs = hsP[G.phase], &ws = wsP[G.phase];
     return (int)(!T.clamp_always && use_hyb(G) && !P.Hfixed && !P.Wfixed && (hs.fused || hs.res_wgs > 0) && (ws.fused || ws.res_wgs > 0));
@@ -1509,7 +1520,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         else if (f64)
           nmfk_launch_step_f64(hs, d_hs, G.kp, G.begin, G.count, gs);
         else if (use_wide(G) && use_wide2_k(G.k) && hs.wsplit == 1)
-          nmfk_launch_step_wide2_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
+          nmfk_launch_step_wide2_f32(hs, d_hs, G.kp, G.begin, G.count, gs, pending[j] ? P.weight : 0.0);
         else if (use_wide(G))
           nmfk_launch_step_mfma_wide_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
         else
@@ -1556,13 +1567,15 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           nmfk_launch_step_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
         if (timed) prof.end(e0, PK_WSTEP, j, it, gs);
         if (!ws.fused && !(use_hyb(G) && ws.res_wgs > 0)) {
+          NmfkStepArgs wr = ws;  // (the phase's argument block serves groups on other kernels too: only this group's choice counts)
+          wr.clampw = defer_kind(G) != 0 && ws.clampw;
           if (f64)
-            nmfk_launch_reduce_f64(ws, G.begin, G.count, gs);
+            nmfk_launch_reduce_f64(wr, G.begin, G.count, gs);
           else
-            nmfk_launch_reduce_f32(ws, G.begin, G.count, gs);
+            nmfk_launch_reduce_f32(wr, G.begin, G.count, gs);
         }
       }
-      ca.w_clamped = use_hyb(G) && wsP[G.phase].clampw;
+      ca.w_clamped = defer_kind(G) != 0 && wsP[G.phase].clampw;
       if (check && it + 1 < maxiter && defer_parts(G) > 0) {
         ca.track_low = track_low_of(G);
         nmfk_launch_check_f32(ca, G.begin, G.count, gs, 2);
@@ -1669,7 +1682,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             two[f]->runs = d_runs;
             two[f]->state = d_state;
           }
-          wsP[ph].clampw = defer_geo(hsP[ph], wsP[ph]) > 0;
+          wsP[ph].clampw = defer_geo(hsP[ph], wsP[ph], true) > 0;
         }
         args_keep.push_back({hsP[0], wsP[0]});
         NmfkStepArgs *d_two = (NmfkStepArgs *)(A + o_args2) + 2 * (size_t)nreplans;

@@ -298,11 +298,29 @@ int nmfk_mfma_wide_lane_tile(int wsplit);
 int nmfk_hyb_lane_tile(int wsplit);
 int nmfk_wide2_ok(int kp);  // wide rank width served by the split-operand form of the all-MFMA half-step (wide2_step_kernel)
 int nmfk_wide2_lane_tile();
-void nmfk_launch_step_wide2_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s);
+void nmfk_launch_step_wide2_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s, double objw = 0.0);
 void nmfk_launch_wide2_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double weight, int hsel, int kp, int u0, int cnt, hipStream_t s);
 int nmfk_hyb_resident_waves();  // waves per workgroup of the resident form
 size_t nmfk_hyb_resident_lds(int variant, int D);  // LDS bytes of the resident form for a loop dimension D, 0 = not applicable
 int nmfk_hyb_variant(int k);  // kernel variant of rank k on the split-operand MFMA half-step: 4 / 8 / 12 / 16
+#if defined(__HIPCC__)
+// sum over the P slots of a sum table of signal `idx` (entry pp * stride + idx), in slot order, NB loads in flight: one load at a
+// time is a chain of P memory round trips in front of every fused finish (wide2_step_kernel's note has the measurement).
+template <int NB>
+__device__ __forceinline__ double nmfk_slot_sum(const double *__restrict__ tab, int stride, int P, int idx) {
+  double sd = 0;
+  for (int p0 = 0; p0 < P; p0 += NB) {
+    double sv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) sv[j] = p0 + j < P ? tab[(p0 + j) * stride + idx] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (p0 + j < P) sd += sv[j];
+  }
+  return sd;
+}
+#endif
+
 void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int ks, int u0, int cnt, hipStream_t s, double objw = 0.0);
 int nmfk_hyb_step_parts(const NmfkStepArgs &a);
 void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double weight, int hsel, int ks, int u0, int cnt,

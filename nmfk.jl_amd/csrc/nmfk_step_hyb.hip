@@ -512,11 +512,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
   if (fused) {
     const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
     const int PB = which == 0 ? rdp->nsW : rdp->nsH;  // (the slots behind the unit's own are zero)
-    if (tid < k) {
-      double sd = 0;
-      for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * k + tid];
-      den[tid] = sd;
-    }
+    if (tid < k) den[tid] = nmfk_slot_sum<4>(sumB, k, PB, tid);
     if (AOLD_EARLY) load_aold();
   }
   char *sbase = (char *)(lds + 18 * 16);  // staging buffers, later the cross-wave scratch (wsplit > 1)
@@ -855,11 +851,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
   if (!OBJ) {
     const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
     const int PB = which == 0 ? rdp->nsW : rdp->nsH;  // (the slots behind the unit's own are zero)
-    if (tid < k) {
-      double sd = 0;
-      for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * k + tid];
-      den[tid] = sd;
-    }
+    if (tid < k) den[tid] = nmfk_slot_sum<4>(sumB, k, PB, tid);
   }
   __syncthreads();
   // 1 / sum(B) as fp32, once per workgroup (den[] is re-used for it: the finish of every tile pair reads it from LDS
@@ -1199,12 +1191,14 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
 // ------------------------------------------------------------------------------------------------------
 // OBJ: the monitored objective (Mult:74) instead of a half-step -- gp = the W half-step's arguments, `it` = parity of the H
 // buffer that holds the current H, whole loop range, first product only, one partial per workgroup (256 rows of X) in
-// ossepart[tile] like sse_kernel.
-template <int NB, int NT, bool OBJ>
+// ossepart[tile] like sse_kernel.  MODE 2: the half-step, and the objective of the factors it reads as a by-product (one partial
+// per workgroup in ossepart[blockIdx.x]; see hyb_step_body's SSE mode and the deferred check of nmfk_mu_sweep).
+template <int NB, int NT, int MODE>
 __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const float *__restrict__ Xt, const NmfkRun *__restrict__ runs,
                                                             const NmfkState *__restrict__ state, const NmfkStepArgs *__restrict__ gp,
                                                             int it, int u0, double weight) {
   extern __shared__ double lds[];  // den[64], red[8][64], then two staged blocks
+  constexpr bool OBJ = MODE == 1, SSE = MODE == 2;
   constexpr int KS = 16 * NB, NM = 3 * NB, NH = 2 * NB, CPB = 4;
   constexpr int CHP = 3 * NH * 256, CHT = NB * 4 * 256;  // bytes of a chunk's split planes / transposed blocks
   constexpr int BFB = CPB * CHP, STB = BFB + CPB * CHT;
@@ -1350,6 +1344,21 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
     }
   };
 
+  // inputs of the fused finish, requested before the loop: the other factor's sum table (denominators of Mult:67 / Mult:70).
+  // Up to 4096 entries (slots x kp; 2048 for KS = 32) travel in eight (four) registers per thread and go through LDS behind the loop, where thread c adds
+  // the slots of signal c in slot order; one thread loading its 64 slots one after the other there -- a chain of L2 round trips
+  // with nothing else on the CU to hide it (one workgroup per CU) -- was a sixth of the W half-step at k = 64.
+  const bool fusedf = !OBJ && gp->fused != 0;
+  const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
+  const int PB = which == 0 ? gp->PW : gp->PH;
+  const int ntab = PB * kp;
+  constexpr int NTAB = NB == 2 ? 4 : 8;  // (KS = 32: 64 slots x 32 signals; four more registers would cost that form its second workgroup per CU)
+  const bool tabpre = fusedf && ntab <= 512 * NTAB;
+  double tabv[NTAB];
+  if (tabpre) {
+#pragma unroll
+    for (int i = 0; i < NTAB; ++i) tabv[i] = tid + 512 * i < ntab ? sumB[tid + 512 * i] : 0.0;
+  }
   f32x4_t xr[4][NT];
   if (nchunks > 0) {
     const int dlast = d0 + 16 * (nchunks - 1);
@@ -1416,6 +1425,22 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
           __builtin_amdgcn_sched_barrier(0);
           continue;
         }
+        if (SSE) {  // the residuals of the chunk (fp32 squares, the chunk's partial into the fp64 sum: the OBJ mode's error budget)
+          float part = 0.0f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            float sqs = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float e = xr[ch & 3][t][r] - p[t][r];
+              e = (!edge || dch + 4 * g + r < d1) ? e : 0.0f;
+              sqs = __builtin_fmaf(e, e, sqs);
+            }
+            part += lv[t] ? sqs : 0.0f;
+          }
+          asm volatile("" : "+v"(part));  // (anchor: see hyb_step_body)
+          ssum += (double)part;
+        }
         // ratios; loop steps beyond the range give zero
         f32x4_t q[NT];
 #pragma unroll
@@ -1443,7 +1468,7 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
   }
   // acc[t][nb][r] = numerator of signal c = 16 nb + 4g + r at lane element l0 + 16t + c16
 
-  if (OBJ) {  // workgroup sum in wave order (fixed order => reproducible)
+  if (OBJ || SSE) {  // workgroup sum in wave order (fixed order => reproducible)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ssum += __shfl_down(ssum, o, 64);
     __syncthreads();
@@ -1452,9 +1477,9 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
     if (tid == 0) {
       double t = 0;
       for (int w = 0; w < 8; ++w) t += lds[w];
-      ((double *)(arena + rdp->ossepart))[tile] = t * weight * weight;
+      ((double *)(arena + rdp->ossepart))[OBJ ? tile : bx] = t * weight * weight;
     }
-    return;
+    if (OBJ) return;
   }
   if (!gp->fused) {
     float *__restrict__ part = (float *)(arena + rdp->opart);
@@ -1471,19 +1496,27 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
       }
     return;
   }
-  const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
-  const int PB = which == 0 ? gp->PW : gp->PH;
   double *den = lds;
-  __syncthreads();  // (the staging buffers are not touched below, but den/red live in front of them: keep the phases apart)
-  if (tid < kp) {
-    double sd = 0;
-    for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * kp + tid];
-    den[tid] = sd;
+  __syncthreads();  // (every wave has left the staging buffers: the table goes there)
+  if (tabpre) {
+    double *tab = (double *)sb;
+#pragma unroll
+    for (int i = 0; i < NTAB; ++i)
+      if (tid + 512 * i < ntab) tab[tid + 512 * i] = tabv[i];
+    __syncthreads();
+    if (tid < kp) {
+      double sd = 0;
+      for (int pp = 0; pp < PB; ++pp) sd += tab[pp * kp + tid];
+      den[tid] = sd;
+    }
+  } else if (tid < kp) {
+    den[tid] = nmfk_slot_sum<16>(sumB, kp, PB, tid);
   }
   __syncthreads();
   float *__restrict__ Anew = which == 0 ? (float *)(arena + NMFK_HOFF(*rdp, it + 1)) : (float *)(arena + rdp->oWt);
   double *sumA = (double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)) + (int64_t)tile * kp;
   double *red = den + NMFK_MAX_K;  // [8][kp]
+  const float floorv = (gp->clampw && which == 1 && (it + 1) % 10 == 0) ? HYB_EPS : -__builtin_inff();
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -1495,7 +1528,10 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
         for (int t = 0; t < NT; ++t)
           if (lv[t]) {
             float v = 0.f;
-            if (c < k) v = A[c + (int64_t)lt[t] * kp] * acc[t][nb][r] / (float)den[c];  // Mult:67 / Mult:70 order
+            if (c < k) {
+              v = A[c + (int64_t)lt[t] * kp] * acc[t][nb][r] / (float)den[c];  // Mult:67 / Mult:70 order
+              v = v < floorv ? floorv : v;                                       // (NmfkStepArgs::clampw; a NaN stays)
+            }
             Anew[c + (int64_t)lt[t] * kp] = v;
             vs += v;
           }
@@ -1655,24 +1691,41 @@ int nmfk_wide2_ok(int kp) { return kp > 16 && kp <= 64; }
 static int wide2_nb(int kp) { return kp <= 32 ? 2 : kp <= 48 ? 3 : 4; }
 int nmfk_wide2_lane_tile() { return 16 * NMFK_HYB_NT * 8; }
 
-void nmfk_launch_step_wide2_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s) {
+void nmfk_launch_step_wide2_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int kp, int u0, int cnt, hipStream_t s, double objw) {
   constexpr int NT = NMFK_HYB_NT;
   const int lpw = 16 * NT * 8, ntile = (a.L + lpw - 1) / lpw;
   const dim3 grid(ntile * a.S, cnt), blk(512);
   const int nb = wide2_nb(kp);
   const size_t chunkb = 3 * (size_t)(2 * nb) * 256 + (size_t)nb * 1024;
   const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + 2 * 4 * chunkb;
+  // objw > 0: the launch also leaves the objective of the factors it reads (scaled by objw^2; grid.x partials per unit)
+#define NMFK_WIDE2_LAUNCH(NBV, MODE, W) \
+  hipLaunchKernelGGL((wide2_step_kernel<NBV, NT, MODE>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, W)
   if (nb == 2) {
-    hipLaunchKernelGGL((wide2_step_kernel<2, NT, false>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
+    if (objw > 0)
+      NMFK_WIDE2_LAUNCH(2, 2, objw);
+    else
+      NMFK_WIDE2_LAUNCH(2, 0, 1.0);
   } else if (nb == 3) {
-    static std::atomic<uint64_t> lds_ok3{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
-    nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<3, NT, false>, lds_ok3, 160 * 1024);
-    hipLaunchKernelGGL((wide2_step_kernel<3, NT, false>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
+    static std::atomic<uint64_t> lds_ok3{0}, lds_ok3s{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
+    if (objw > 0) {
+      nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<3, NT, 2>, lds_ok3s, 160 * 1024);
+      NMFK_WIDE2_LAUNCH(3, 2, objw);
+    } else {
+      nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<3, NT, 0>, lds_ok3, 160 * 1024);
+      NMFK_WIDE2_LAUNCH(3, 0, 1.0);
+    }
   } else {
-    static std::atomic<uint64_t> lds_ok{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
-    nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<4, NT, false>, lds_ok, 160 * 1024);
-    hipLaunchKernelGGL((wide2_step_kernel<4, NT, false>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
+    static std::atomic<uint64_t> lds_ok{0}, lds_oks{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
+    if (objw > 0) {
+      nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<4, NT, 2>, lds_oks, 160 * 1024);
+      NMFK_WIDE2_LAUNCH(4, 2, objw);
+    } else {
+      nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<4, NT, 0>, lds_ok, 160 * 1024);
+      NMFK_WIDE2_LAUNCH(4, 0, 1.0);
+    }
   }
+#undef NMFK_WIDE2_LAUNCH
 }
 
 // monitored objective of wide-rank units (scalar weight, no missing data): the kernel above in its objective mode.
@@ -1685,14 +1738,14 @@ void nmfk_launch_wide2_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double
   const size_t chunkb = 3 * (size_t)(2 * nb) * 256 + (size_t)nb * 1024;
   const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + 2 * 4 * chunkb;
   if (nb == 2) {
-    hipLaunchKernelGGL((wide2_step_kernel<2, NT, true>), grid, blk, ldsb, s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
+    hipLaunchKernelGGL((wide2_step_kernel<2, NT, 1>), grid, blk, ldsb, s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
   } else if (nb == 3) {
     static std::atomic<uint64_t> lds_ok3{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
-    nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<3, NT, true>, lds_ok3, 160 * 1024);
-    hipLaunchKernelGGL((wide2_step_kernel<3, NT, true>), grid, blk, ldsb, s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
+    nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<3, NT, 1>, lds_ok3, 160 * 1024);
+    hipLaunchKernelGGL((wide2_step_kernel<3, NT, 1>), grid, blk, ldsb, s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
   } else {
     static std::atomic<uint64_t> lds_ok{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
-    nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<4, NT, true>, lds_ok, 160 * 1024);
-    hipLaunchKernelGGL((wide2_step_kernel<4, NT, true>), grid, blk, ldsb, s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
+    nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<4, NT, 1>, lds_ok, 160 * 1024);
+    hipLaunchKernelGGL((wide2_step_kernel<4, NT, 1>), grid, blk, ldsb, s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight);
   }
 }

@@ -534,11 +534,7 @@ __device__ __forceinline__ void step_body(char *arena, const float *__restrict__
   const double *sumB = NMFK_PTR(const double, g, g.which == 0 ? rdp->osumW : rdp->osumH);
   const int PB = g.which == 0 ? gp->PW : gp->PH;
   double *den = lds;
-  if (tid < KP) {
-    double sd = 0;
-    for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * KP + tid];
-    den[tid] = sd;
-  }
+  if (tid < KP) den[tid] = nmfk_slot_sum<4>(sumB, KP, PB, tid);
   __syncthreads();
   T *__restrict__ Anew = g.which == 0 ? NMFK_PTR(T, g, NMFK_HOFF(*rdp, g.it + 1)) : NMFK_PTR(T, g, rdp->oWt);
   const int k = rdp->k;
@@ -844,11 +840,7 @@ __global__ __launch_bounds__(2 * NMFK_TILE) void mfma_wide_kernel(char *arena, c
   const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
   const int PB = which == 0 ? gp->PW : gp->PH;
   double *den = lds;
-  if (tid < KP) {
-    double sd = 0;
-    for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * KP + tid];
-    den[tid] = sd;
-  }
+  if (tid < KP) den[tid] = nmfk_slot_sum<4>(sumB, KP, PB, tid);
   __syncthreads();
   float *__restrict__ Anew = which == 0 ? (float *)(arena + NMFK_HOFF(*rdp, it + 1)) : (float *)(arena + rdp->oWt);
   double *sumA = (double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)) + (int64_t)tile * KP;
@@ -1724,21 +1716,27 @@ __global__ __launch_bounds__(NMFK_TILE) void reduce_kernel(NmfkStepArgs g, int u
     zero_slot(sumA + (int64_t)b * kp, kp);
     return;
   }
-  if (threadIdx.x < kp) {
-    double sd = 0;
-    for (int pp = 0; pp < PB; ++pp) sd += sumB[pp * kp + threadIdx.x];
-    den[threadIdx.x] = sd;
-  }
+  if (threadIdx.x < kp) den[threadIdx.x] = nmfk_slot_sum<16>(sumB, kp, PB, threadIdx.x);  // (256 slots of W at 65536 rows)
   __syncthreads();
   int l0, l1;
   slot_range(g.L, PA, b, l0, l1);
   const T *part = NMFK_PTR(const T, g, rd.opart);
   const int64_t LK = (int64_t)g.L * kp;
+  const T floorv = (g.clampw && g.which == 1 && (g.it + 1) % 10 == 0) ? (T)2.220446049250313e-16 : -(T)INFINITY;
   for (int64_t e = (int64_t)l0 * kp + threadIdx.x; e < (int64_t)l1 * kp; e += NMFK_TILE) {
     const int c = (int)(e % kp);
+    const T aold = Aold[e];
     T num = (T)0;
-    for (int s = 0; s < g.S; ++s) num += part[(int64_t)s * LK + e];
-    T v = Aold[e] * num / (T)den[c];  // same operation order as Mult:67,70
+    for (int s0 = 0; s0 < g.S; s0 += 8) {  // eight partials in flight, added in the order of the splits
+      T pv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = s0 + j < g.S ? part[(int64_t)(s0 + j) * LK + e] : (T)0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (s0 + j < g.S) num += pv[j];
+    }
+    T v = aold * num / (T)den[c];  // same operation order as Mult:67,70
+    v = v < floorv ? floorv : v;      // (NmfkStepArgs::clampw: W of a check iteration; a NaN stays)
     if (c >= k) v = (T)0;
     Anew[e] = v;
   }

@@ -1352,3 +1352,27 @@ def test_deferred_check_against_the_plain_order(NMFk, ctx, oracle, monkeypatch):
         #  the plain order's clamp pass recomputes the table -- the same sums in another order)
         np.testing.assert_allclose(a[k]["W"], b[k]["W"], rtol=1e-5, atol=1e-12)
         np.testing.assert_allclose(a[k]["H"], b[k]["H"], rtol=1e-5, atol=1e-12)
+    # ranks above 16 (wide2_step_kernel, one launch group per rank; loop range split over workgroups, reduce kernel): the same
+    for key in ("NMFK_HYB", "NMFK_HYB_MINK", "NMFK_HYB_PHASES"):
+        monkeypatch.delenv(key)
+    ks = [24, 40, 64]
+    seeds = _seeds(NMFk, 5, ks, 2)
+    wide, winfo, wtrace = {}, {}, {}
+    ctx.set_objective_trace(True)
+    try:
+        for mode in ("0", "1"):
+            monkeypatch.setenv("NMFK_DEFER_OBJ", mode)
+            wide[mode] = ctx.mu_sweep(ks, 2, seeds=seeds, maxiter=45, **NOSTOP)
+            winfo[mode] = ctx.last_sweep_info()
+            wtrace[mode] = {(k, r): ctx.objective_trace(ks.index(k), r) for k in ks for r in range(2)}
+    finally:
+        ctx.set_objective_trace(False)
+    assert winfo["1"]["wide_mfma_units"] == 6 and winfo["1"]["deferred_checks"] == 12 and winfo["1"]["plain_checks"] == 0, winfo["1"]
+    assert winfo["0"]["deferred_checks"] == 0 and winfo["0"]["plain_checks"] == 12, winfo["0"]
+    for k in ks:
+        assert (wide["0"][k]["iters"] == 45).all() and (wide["1"][k]["iters"] == 45).all()
+        np.testing.assert_allclose(wide["1"][k]["W"], wide["0"][k]["W"], rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(wide["1"][k]["H"], wide["0"][k]["H"], rtol=1e-5, atol=1e-12)
+        for r in range(2):
+            assert len(wtrace["1"][(k, r)]) == 4 and len(wtrace["0"][(k, r)]) == 4
+            np.testing.assert_allclose(wtrace["1"][(k, r)], wtrace["0"][(k, r)], rtol=2e-6)

@@ -1497,6 +1497,16 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
     return;
   }
   double *den = lds;
+  // this lane's old values of its four signals per block of sixteen (kp is a multiple of 4: whole quads), requested in front of
+  // the denominators' barriers
+  f32x4_t aold[NT][NB];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      aold[t][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (lv[t] && 16 * nb + 4 * g < kp) aold[t][nb] = *(const f32x4_u *)(A + (int64_t)lt[t] * kp + 16 * nb + 4 * g);
+    }
   __syncthreads();  // (every wave has left the staging buffers: the table goes there)
   if (tabpre) {
     double *tab = (double *)sb;
@@ -1518,29 +1528,35 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
   double *red = den + NMFK_MAX_K;  // [8][kp]
   const float floorv = (gp->clampw && which == 1 && (it + 1) % 10 == 0) ? HYB_EPS : -__builtin_inff();
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
+  for (int nb = 0; nb < NB; ++nb) {
+    const int c0 = 16 * nb + 4 * g;
+    float vs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < kp) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (lv[t]) {
+          f32x4_t v4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = 0.f;
+            if (c0 + r < k) {
+              v = aold[t][nb][r] * acc[t][nb][r] / (float)den[c0 + r];  // Mult:67 / Mult:70 order
+              v = v < floorv ? floorv : v;                             // (NmfkStepArgs::clampw; a NaN stays)
+            }
+            v4[r] = v;
+            vs[r] += v;
+          }
+          *(f32x4_u *)(Anew + (int64_t)lt[t] * kp + c0) = v4;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int c = 16 * nb + 4 * g + r;
-      float vs = 0.f;
-      if (c < kp) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-          if (lv[t]) {
-            float v = 0.f;
-            if (c < k) {
-              v = A[c + (int64_t)lt[t] * kp] * acc[t][nb][r] / (float)den[c];  // Mult:67 / Mult:70 order
-              v = v < floorv ? floorv : v;                                       // (NmfkStepArgs::clampw; a NaN stays)
-            }
-            Anew[c + (int64_t)lt[t] * kp] = v;
-            vs += v;
-          }
-      }
-      double v = (double)vs;
+      double v = (double)vs[r];
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (c16 == 0 && c < kp) red[wave * kp + c] = v;
+      if (c16 == 0 && c0 + r < kp) red[wave * kp + c0 + r] = v;
     }
+  }
   __syncthreads();
   if (tid < kp) {
     double t = red[tid];

@@ -140,7 +140,7 @@ def secondary_cfg4(NMFk, ctx, iters=100):
             "algorithmic_bytes_per_iter": bytes_iter,
             "kernel": "sp_blk_kernel<NC> (nmfk_step_impl.h; sliced ELL, one lane element per lane, the gathered factor through LDS) "
                       "for both half-steps of every rank <= 32",
-            "profile": "profiles/r04/secondary_cfg4_cfg5_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/r4_secondary.py)"}
+            "profile": "profiles/r04/secondary_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/r4_secondary.py)"}
 
 
 def secondary_cfg2(NMFk, ctx, X, iters=1000):
@@ -190,8 +190,8 @@ def secondary_cfg5(NMFk, ctx, iters=40):
             "matrix_pipe_occupancy_note": "derived: algorithmic rate x (704 matrix cycles the split-operand form issues per tile / 1024 of "
                                           "the all-fp32 form the peak is quoted for); counters: profiles/r04",
             "half_steps": halves,
-            "kernel": "wide2_step_kernel<4,2,false> (nmfk_step_hyb.hip: W*H from three-term bf16 splits, numerators in fp32 MFMAs)",
-            "profile": "profiles/r04/secondary_cfg4_cfg5_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/r4_secondary.py)"}
+            "kernel": "wide2_step_kernel<4,2,0> (nmfk_step_hyb.hip: W*H from three-term bf16 splits, numerators in fp32 MFMAs; <4,2,2> behind a check iteration: the same half-step leaves the monitored objective)",
+            "profile": "profiles/r04/secondary_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/r4_secondary.py)"}
 
 
 def main():

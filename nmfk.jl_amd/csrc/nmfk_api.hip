@@ -1291,7 +1291,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // Deferred check (see the loop): is the sweep eligible, and does a pair of half-step geometries allow it -- the H half-step
   // must have an objective mode for its geometry, and the W half-step must end on a kernel that clamps what it writes in a check
   // iteration (NmfkStepArgs::clampw)
-  const bool defer_ok = T.defer_obj && !ctx->sparse && !f64 && !P.Hfixed && !P.Wfixed && ctx->Wgt == nullptr && T.hyb_sse && T.wide_sse;
+  const bool defer_ok = T.defer_obj && !ctx->sparse && !f64 && !P.Hfixed && !P.Wfixed && ctx->Wgt == nullptr && T.hyb_sse && T.wide_sse &&
+                        P.weight > 0;  // (the launchers take the weight as the switch: objw > 0)
   auto defer_geo = [&](const NmfkStepArgs &h, const NmfkStepArgs &w, bool hyb) {
     NmfkStepArgs hh = h;
     if (!hyb) hh.res_wgs = 0;  // (the resident form is the rank <= 16 kernels' only)

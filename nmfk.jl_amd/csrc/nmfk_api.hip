@@ -1117,7 +1117,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // half-step (see the loop), one per workgroup of that launch -- in any tier of the retire-aware schedule
   int obj_cap = tiles_n + 1;
   {
-    auto hparts = [&](int res, int wsplit, int S) { return res > 0 || wsplit > 1 ? 0 : (m + nmfk_hyb_lane_tile(1) - 1) / nmfk_hyb_lane_tile(1) * S; };
+    auto hparts = [&](int res, int wsplit, int S) { return res > 0 ? 0 : (m + nmfk_hyb_lane_tile(wsplit) - 1) / nmfk_hyb_lane_tile(wsplit) * S; };
     int want = 0;
     for (const Group &G : groups)
       if (G.hyb || (use_wide_k(G.k) && use_wide2_k(G.k))) want = std::max(want, hparts(G.hyb ? res_wgs[0] : 0, ghp[G.phase].wsplit, ghp[G.phase].S));
@@ -1296,7 +1296,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   auto defer_geo = [&](const NmfkStepArgs &h, const NmfkStepArgs &w, bool hyb) {
     NmfkStepArgs hh = h;
     if (!hyb) hh.res_wgs = 0;  // (the resident form is the rank <= 16 kernels' only)
-    const int parts = nmfk_hyb_step_parts(hh);  // (the wide-rank kernel has the same lane tile and no wsplit form)
+    if (!hyb && hh.wsplit > 1) return 0;        // (the wide-rank kernel has no form for per-wave loop ranges)
+    const int parts = nmfk_hyb_step_parts(hh);  // (and the same lane tile)
     const bool wfin = hyb || !w.fused || w.wsplit == 1;  // the W half-step ends on a kernel that clamps (the matrix-pipe kernels' fused finishes, reduce_kernel)
     return (defer_ok && parts > 0 && parts <= obj_cap && wfin) ? parts : 0;
   };
@@ -1471,7 +1472,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // the plain order, both far below fp32 rounding: the objective is that of the factors AFTER the clamp (entries below eps()
   // raised to eps(): <= 1e-13 of the objective), and a unit that stops on `tol` (Mult:75-78) keeps clamped factors.
   // Not for the last iteration (no half-step follows), fixed factors, array weights, nor where the H half-step runs in its resident
-  // form or with per-wave loop ranges (wsplit > 1: few units left) -- those checks keep their objective launch.
+  // form -- those checks keep their objective launch.
   auto defer_parts = [&](const Group &G) {
     return (defer_kind(G) && wsP[G.phase].clampw) ? defer_geo(hsP[G.phase], wsP[G.phase], defer_kind(G) == 1) : 0;
   };

@@ -319,7 +319,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
   const NmfkRun *__restrict__ rdp = runs + u;
   const int k = rdp->k;  // = kp: row stride of the fp32 rows and of the sum tables
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const int which = gp->which, ws = (OBJ || SSE) ? 1 : gp->wsplit, S = OBJ ? 1 : gp->S, L = gp->L, D = gp->D;  // (SSE: the host launches wsplit = 1 only)
+  const int which = gp->which, ws = OBJ ? 1 : gp->wsplit, S = OBJ ? 1 : gp->S, L = gp->L, D = gp->D;
   const int nwaves = blockDim.x >> 6;
   const int lpw = 16 * NT * (ws > 1 ? 1 : nwaves);
   const int tile = bx / S, s = bx - tile * S;
@@ -1666,9 +1666,7 @@ void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, 
 
 // objective partials per unit a streaming-form launch with these arguments leaves (0: no objective mode for this geometry)
 int nmfk_hyb_step_parts(const NmfkStepArgs &a) {
-  // (the waves of a workgroup share the loop range: with the per-wave staging of wsplit > 1 compiled in, the kernel needs scratch
-  //  memory at four waves per SIMD)
-  if (a.res_wgs > 0 || a.wsplit > 1) return 0;
+  if (a.res_wgs > 0) return 0;
   const int lpw = nmfk_hyb_lane_tile(a.wsplit);
   return (a.L + lpw - 1) / lpw * a.S;
 }

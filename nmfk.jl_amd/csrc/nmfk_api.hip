@@ -636,6 +636,14 @@ namespace {
 // Launch geometry of a launch group of `units` units on the matrix-pipe kernels (ranks 2..16, dense fp32) at an n x m matrix on a GPU
 // of `cus` CUs: pure host arithmetic, the rule nmfk_mu_sweep applies to such a group (its tier 0) and to every later tier of the
 // retire-aware schedule.  [0] = H half-step (lanes = m columns, loop = n rows), [1] = W half-step.
+// Workgroups of a matrix-pipe half-step below which the waves of a workgroup take loop ranges of their own (wsplit = 8, every wave
+// staging for itself) instead of sharing staged blocks, the loop range split over workgroups (S > 1, reduce_kernel finishes).  Round 3
+// put the line at 1.5 per CU (240 units x 2 lane tiles: 0.376 ms shared against 0.436 ms per-wave); measured again with the kernels
+// as they are (profiles/r04/few_units_shared_staging.txt, k = 2:16 at 8192 x 512): the shared form wins down to ~90 units (120 units:
+// 0.40-0.41 against 0.44-0.46 ms per iteration, 90: 0.32-0.33 against 0.34-0.36), the two are equal at 30-75 and the per-wave form
+// wins below (15 units: 0.111 against 0.116, one unit: 0.064 against 0.071): 0.7 per CU.
+static int hyb_target_ws(int cus) { return 7 * cus / 10; }
+
 struct HybPlan {
   int units;
   int res[2];     // workgroups per unit of the resident form (0: streaming form)
@@ -649,7 +657,7 @@ HybPlan plan_hyb_group(int n, int m, int cus, int vmax, int units, int target_wg
   HybPlan p;
   p.units = units;
   const int target = target_wgs > 0 ? target_wgs : 2 * cus;
-  const int target_ws = target_wgs > 0 ? target : 3 * cus / 2;
+  const int target_ws = target_wgs > 0 ? target : hyb_target_ws(cus);
   const int res_tpw = Tuning::hyb_res_tpw, max_ws = Tuning::max_wsplit;
   for (int which = 0; which < 2; ++which) {
     const int L = which == 0 ? m : n, D = which == 0 ? n : m;
@@ -806,6 +814,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // reference shape.  The phases are taken when (a) the group's launches are long enough not to be launch-bound,
   // (b) its workgroups in the short dimension cover at least half the CUs, and (c) the model promises >= 300
   // rank-restarts of saving (k = 2:12 x 32 would lose 3 %, k = 2:16 x 32 gains 15 %, x 16 gains 5 %).
+  // Round 4: the rule used to ask for >= 16 restarts per rank, which left 9..15 -- the reference's README example runs 10 -- on the
+  // per-rank packed-VALU launches: k = 2:16 x 9..15 at 8192 x 512 took 0.78-1.03 ms per iteration there against 0.51-0.77 ms on the
+  // group, k = 2:5 x 10 0.23 against 0.14-0.18 (profiles/r04/schedule_9_to_15_restarts.txt); (b) now asks for a quarter of the CUs.
   int hyb_on = T.hyb, hyb_mink = T.hyb_mink;
   const int hyb_groups = T.hyb_groups;  // merged sweeps: number of mixed-rank launch groups of the split-operand MFMA kernel
   int merge = T.merge;
@@ -840,7 +851,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if ((merge > 0 && !merge_env) || few) {  // few restarts per rank: merged sweep
       hyb_on = 1;
       if (hyb_units > 0) merge = 1;  // the few small ranks left: one packed-VALU group (126 vs 130 ms per 400 iterations)
-    } else if (merge == 0 && !merge_env && nruns >= 16 && launch_ns >= 50e3 && 2 * h_wgs >= cus && (T.hyb_small || hyb_score >= 300)) {
+    } else if (merge == 0 && !merge_env && nruns > NMFK_MERGE_MAX_RUNS && launch_ns >= 50e3 && 4 * h_wgs >= cus && (T.hyb_small || hyb_score >= 300)) {
       hyb_on = 1;
       hyb_phases = true;  // (only matters when packed-VALU ranks are left: they run behind the matrix-pipe groups)
     } else {
@@ -937,7 +948,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     // kernel, whose per-wave staging form is the slower one (240 units x 2 lane tiles: 0.376 ms shared vs 0.436 ms split)
     bool phase_hyb = false;
     for (int q = 0; q < nk; ++q) phase_hyb = phase_hyb || (phase_of_k(ks[q]) == phase && use_hyb_k(ks[q]));
-    const int target_ws = (T.target_wgs > 0 || !phase_hyb) ? target : 3 * cus / 2;
+    const int target_ws = (T.target_wgs > 0 || !phase_hyb) ? target : hyb_target_ws(cus);
     // (the split-operand wide-rank kernel has no form in which the waves of a workgroup split the loop range: a phase
     //  that runs it fills the chip by splitting the range over workgroups instead, S below)
     bool phase_wide2 = false;

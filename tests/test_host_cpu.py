@@ -463,7 +463,7 @@ def test_retire_aware_tiers_are_consistent_launch_geometries(monkeypatch):
                     wgs = g["ns"] * g["S"] * t["units"]
                     per_unit.append(g["ns"] * g["S"] * g["wsplit"])
                     room = (L + 31) // 32 * max(1, D // 512) * t["units"]  # 32 lanes x 512 of the loop is the least a workgroup takes
-                    assert wgs * g["wsplit"] >= min(256, room // 8), (n, m, units, variant, t)  # wsplit waves work on separate ranges
+                    assert wgs * (16 if g["res"] else g["wsplit"]) >= min(256, room // 8), (n, m, units, variant, t)  # (waves with work of their own: wsplit ranges, the resident form's 16 tile walkers)
                 if prev:
                     assert per_unit[0] >= prev[0] or per_unit[1] >= prev[1]
                 prev = per_unit

@@ -828,38 +828,49 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // (the kernel's buffer loads address X with 32-bit byte offsets from the array base)
   const bool hyb_fits = mfma_ok && (int64_t)n * m * 4 < ((int64_t)1 << 32) - 4096;
   if (hyb_on < 0) {  // automatic (an explicit NMFK_MERGE keeps the packed-VALU groups)
-    const double Erel = (double)n * m / (8192.0 * 512.0);
-    const double wg_ns = 8.5 * ((double)n + m) / 256.0;              // per-workgroup overhead of a unit of the group
-    const double k0 = 8.8 + (wg_ns / Erel - 8.5 * 34.0) / 324.0;     // round 2's break-even rank against the 16-signal form
     // Round 3: the matrix-pipe kernel no longer pads a rank to 16 signals (nmfk_step_hyb.hip: one bf16 MFMA and 4x4x1
-    // numerator blocks for k <= 4, two and eight for k <= 8), which puts EVERY rank <= 16 below its packed-VALU cost
-    // (k = 2: ~1.5 vs 2.1 us per factorization and iteration at the reference shape, k = 8: ~2.2 vs 4.0): first rank 2.
-    // (Tuning::hyb_small = 0 is round 2's rule: first rank = break-even against the 16-signal form; 2 / 6 in merged sweeps.)
+    // numerator blocks for k <= 4, two and eight for k <= 8): first rank 2.  (Tuning::hyb_small = 0 is round 2's rule: first
+    // rank = break-even against the 16-signal form, k0 above; 2 / 6 in merged sweeps.)
+    const double Erel = (double)n * m / (8192.0 * 512.0);
+    const double wg_ns = 8.5 * ((double)n + m) / 256.0;
+    const double k0 = 8.8 + (wg_ns / Erel - 8.5 * 34.0) / 324.0;
     const int mk = hyb_mink >= 0 ? hyb_mink
                    : T.hyb_small ? 2
                                  : (nruns <= 4 ? 2 : nruns <= 8 ? 6 : std::min(16, (int)ceil(k0)));
-    int hyb_units = 0;
-    double hyb_score = 0;  // what the group saves, in rank-restarts (round 2's model: a packed-VALU unit costs ~k, a unit of the group ~k0)
-    for (int q = 0; q < nk; ++q)
+    int hyb_units = 0, hyb_kmax = 0;
+    for (int q = 0; q < nk; ++q) {
       if (hyb_fits && ks[q] <= 16 && ks[q] >= mk) {
         hyb_units += nruns;
-        hyb_score += (ks[q] - k0) * nruns;
+        hyb_kmax = std::max(hyb_kmax, ks[q]);
       }
-    const bool few = !merge_env && !ctx->sparse && nruns <= 8 && hyb_units > 0;  // (8 restarts: 177-179 vs 186 ms)
-    const double launch_ns = hyb_units * Erel * 1835.0;                         // one half-step launch of the group
-    const int64_t h_wgs = (int64_t)hyb_units * ((std::min(n, m) + 255) / 256);  // its workgroups in the short dimension
-    if ((merge > 0 && !merge_env) || few) {  // few restarts per rank: merged sweep
+    }
+    // Round 4: rounds 2-3 guarded the group with a cost model of THEIR kernels -- >= 16 restarts per rank (or <= 8: merged
+    // sweeps), a launch of >= 50 us, workgroups for half the CUs, a break-even rank.  Measured again over eight shapes x ten
+    // sweeps (scripts/r4_schedule_probe.py, profiles/r04/schedule_probe_before.txt) the guards cost up to 4x: the group beats the
+    // per-rank packed-VALU launches almost everywhere -- 9..15 restarts per rank (0.78-1.04 -> 0.47-0.75 ms per iteration at
+    // 8192 x 512), small matrices (1024 x 128, k = 2:16 x 10: 0.279 -> 0.064 ms), single ranks (k = 16 x 10: 0.171 -> 0.107).
+    // What is left on the packed-VALU kernels by measurement: (i) a few units of the smallest ranks only (k = 3 x 10: 0.055
+    // against 0.063 ms), (ii) ranks <= 5 only on a large matrix whose short W half-step loop cannot take the resident form (m not
+    // a multiple of 64: 20000 x 1000, k = 2:5 x 10: 0.56 against 0.74 ms, k = 4 x 64: 0.71 against 1.05 -- but 2048 x 2048, 512 x 8192
+    // and 300 x 300, also without the resident form, run the group 1.3-3 x faster: profiles/r04/schedule_probe_after.txt).
+    const int vmax_auto = hyb_kmax <= 4 ? 4 : hyb_kmax <= 8 ? 8 : 16;
+    const bool tiny_small = hyb_kmax <= 4 && hyb_units < 24;
+    const bool small_streaming = hyb_kmax <= 5 && (!T.hyb_res || nmfk_hyb_resident_lds(T.hyb_small ? vmax_auto : 16, m) == 0) && m < 2048 && Erel >= 0.5;
+    if (hyb_units > 0 && !merge_env && !ctx->sparse && !tiny_small && !small_streaming) {
       hyb_on = 1;
-      if (hyb_units > 0) merge = 1;  // the few small ranks left: one packed-VALU group (126 vs 130 ms per 400 iterations)
-    } else if (merge == 0 && !merge_env && nruns > NMFK_MERGE_MAX_RUNS && launch_ns >= 50e3 && 4 * h_wgs >= cus && (T.hyb_small || hyb_score >= 300)) {
-      hyb_on = 1;
-      hyb_phases = true;  // (only matters when packed-VALU ranks are left: they run behind the matrix-pipe groups)
+      // the other ranks run BEHIND the group (the group's fp32 MFMAs and their kernels' packed FMAs / fp32 MFMAs share the
+      // multipliers; side by side k = 2:32 x 8 took 1.62 ms per iteration at 8192 x 512 against 1.43 phased, 1.77 against
+      // 0.57 at 512 x 8192), each phase with its own launch geometry
+      hyb_phases = true;  // (one mixed-rank launch group for the ranks on it; the other ranks in phase 1)
+      bool low_left = false;  // ranks below the group's first one (only with Tuning::hyb_small = 0 or NMFK_HYB_MINK)
+      for (int q = 0; q < nk; ++q) low_left = low_left || ks[q] < mk;
+      merge = (low_left && (merge > 0 || nruns <= 8)) ? 1 : 0;  // (few restarts: they share one packed-VALU group beside the matrix-pipe group)
     } else {
       hyb_on = 0;
     }
     hyb_mink = mk;
   }
-  if (T.phases >= 0) hyb_phases = hyb_on && merge == 0 && T.phases != 0;
+  if (T.phases >= 0) hyb_phases = hyb_on && T.phases != 0;
   if (hyb_mink < 0) hyb_mink = 5;
   // The ranks <= 16 that are not on the MFMA group share `merge` mixed-rank packed-VALU launch groups (step_kernel_multi)
   // when the sweep has few restarts per rank.  (Round 2 met the gfx950 packed-fp32 hazard in this kernel first -- DESIGN.md,

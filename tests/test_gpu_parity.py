@@ -340,7 +340,7 @@ def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle, R):
     a = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
     info = ctx.last_sweep_info()
     assert info["mfma_group_units"] == R * sum(2 <= k <= 16 for k in ks), info
-    assert info["phases"] == 1 and info["merged_valu_groups"] == 0, info
+    assert info["phases"] == 2 and info["merged_valu_groups"] == 0, info  # (round 4: the rank above 16 runs behind the group, not beside it)
     os.environ["NMFK_HYB"] = "0"
     try:
         b = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
@@ -350,8 +350,8 @@ def test_few_restarts_mixed_rank_mfma_group(NMFk, ctx, oracle, R):
         for r in range(R):
             e = _rel(a[k]["W"][r] @ a[k]["H"][r], b[k]["W"][r] @ b[k]["H"][r], X)
             assert e <= 5e-6, (k, r, e)
-            if k > 16:
-                assert e == 0.0  # not on the MFMA group: the same kernels in both runs
+            # (k > 16 is on the same kernel in both runs, but behind the group since round 4, with the launch geometry of its own
+            #  phase: the loop range is split differently, the sums differ in the last bits)
         W0, H0 = oracle.init_factors(int(seeds[q, 0]), n, m, k)
         ref = oracle.singlerun(X, k, W0, H0, maxiter=iters, **NOSTOP)
         assert _rel(a[k]["W"][0] @ a[k]["H"][0], ref["W"] @ ref["H"], X) <= 1e-4
@@ -397,8 +397,8 @@ def test_resident_form_of_the_mfma_half_step(NMFk, ctx, oracle, shape, monkeypat
 
 
 def test_up_to_four_restarts_all_ranks_on_the_mfma_group(NMFk, ctx, oracle):
-    """Up to 4 restarts per rank (a rank's share at 8 GPUs): every rank 2..16 runs on the split-operand MFMA group in ONE
-    phase, no packed-VALU launch (nmfk_mu_sweep's rule); k = 1 and k > 16 keep their kernels.  Against the oracle."""
+    """Up to 4 restarts per rank (a rank's share at 8 GPUs): every rank 2..16 runs on the split-operand MFMA group, no
+    packed-VALU launch (nmfk_mu_sweep's rule); k = 1 and k > 16 keep their kernels and run behind the group.  Against the oracle."""
     n, m = 700, 130
     X = (0.05 + oracle.uniform_fill(35, 0, n * m)).reshape(n, m).astype(np.float32)
     ctx.set_X(X)
@@ -408,7 +408,7 @@ def test_up_to_four_restarts_all_ranks_on_the_mfma_group(NMFk, ctx, oracle):
         a = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=iters, **NOSTOP)
         info = ctx.last_sweep_info()
         assert info["mfma_group_units"] == R * sum(k <= 16 for k in ks) and info["merged_valu_groups"] == 0, info
-        assert info["phases"] == 1
+        assert info["phases"] == (2 if max(ks) > 16 else 1)  # (a rank above 16 runs behind the group)
         for q, k in enumerate(ks):
             for r in range(R):
                 W0, H0 = oracle.init_factors(int(seeds[q, r]), n, m, k)

@@ -849,14 +849,12 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     // sweeps (scripts/r4_schedule_probe.py, profiles/r04/schedule_probe_before.txt) the guards cost up to 4x: the group beats the
     // per-rank packed-VALU launches almost everywhere -- 9..15 restarts per rank (0.78-1.04 -> 0.47-0.75 ms per iteration at
     // 8192 x 512), small matrices (1024 x 128, k = 2:16 x 10: 0.279 -> 0.064 ms), single ranks (k = 16 x 10: 0.171 -> 0.107).
-    // What is left on the packed-VALU kernels by measurement: (i) a few units of the smallest ranks only (k = 3 x 10: 0.055
-    // against 0.063 ms), (ii) ranks <= 5 only on a large matrix whose short W half-step loop cannot take the resident form (m not
-    // a multiple of 64: 20000 x 1000, k = 2:5 x 10: 0.56 against 0.74 ms, k = 4 x 64: 0.71 against 1.05 -- but 2048 x 2048, 512 x 8192
-    // and 300 x 300, also without the resident form, run the group 1.3-3 x faster: profiles/r04/schedule_probe_after.txt).
-    const int vmax_auto = hyb_kmax <= 4 ? 4 : hyb_kmax <= 8 ? 8 : 16;
+    // What is left on the packed-VALU kernels by measurement: a few units of the smallest ranks only (k = 3 x 10: 0.055 against
+    // 0.063 ms).  (A second exception -- ranks <= 5 on a large matrix whose short W half-step loop could not take the resident form --
+    // went away when that form learnt loop lengths that are not multiples of 64: 20000 x 1000, k = 4 x 64: 1.05 -> 0.63 ms against
+    // 0.72 on the packed-VALU kernel; one measured case is left where that kernel is ahead, k = 2:5 x 10 there: 0.55 against 0.70.)
     const bool tiny_small = hyb_kmax <= 4 && hyb_units < 24;
-    const bool small_streaming = hyb_kmax <= 5 && (!T.hyb_res || nmfk_hyb_resident_lds(T.hyb_small ? vmax_auto : 16, m) == 0) && m < 2048 && Erel >= 0.5;
-    if (hyb_units > 0 && !merge_env && !ctx->sparse && !tiny_small && !small_streaming) {
+    if (hyb_units > 0 && !merge_env && !ctx->sparse && !tiny_small) {
       hyb_on = 1;
       // the other ranks run BEHIND the group (the group's fp32 MFMAs and their kernels' packed FMAs / fp32 MFMAs share the
       // multipliers; side by side k = 2:32 x 8 took 1.62 ms per iteration at 8192 x 512 against 1.43 phased, 1.77 against
@@ -1502,7 +1500,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     const NmfkStepArgs &hs = hsP[G.phase], &ws = wsP[G.phase];
     return (int)(!T.clamp_always && use_hyb(G) && !P.Hfixed && !P.Wfixed && (hs.fused || hs.res_wgs > 0) && (ws.fused || ws.res_wgs > 0));
   };
-  std::vector<char> pending((size_t)ngroups, 0);  // the group's check of the previous iteration waits for this H half-step
+  std::vector<int> pending((size_t)ngroups, 0);  // > 0: the group's check of the previous iteration waits for this H half-step (= its objective partials per unit)
   int ndeferred = 0, nclassic = 0;
   for (int phase = 0; phase < nphases; ++phase) {
   // (units still active when a phase's loop ends ran all `maxiter` iterations, so one total_iters serves every phase)
@@ -1559,7 +1557,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         if (pending[j]) {  // the deferred check of iteration it - 1: the objective has just been left by the half-step
           NmfkCheckArgs cb = ca;
           cb.it = it - 1;
-          cb.ntile_n = nmfk_hyb_step_parts(hs);
+          cb.ntile_n = pending[j];  // (the partials this launch has left: defer_parts at the check iteration)
           cb.track_low = track_low_of(G);
           nmfk_launch_check_f32(cb, G.begin, G.count, gs, 1 | 4);
           pending[j] = 0;
@@ -1603,7 +1601,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       if (check && it + 1 < maxiter && defer_parts(G) > 0) {
         ca.track_low = track_low_of(G);
         nmfk_launch_check_f32(ca, G.begin, G.count, gs, 2);
-        pending[j] = 1;
+        pending[j] = defer_parts(G);
         deferring = true;
         ++ndeferred;
       } else if (check) {

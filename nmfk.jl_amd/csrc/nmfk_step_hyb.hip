@@ -788,7 +788,9 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
 // half-step's vector instructions sat outside the loop).  Here a workgroup of 16 waves stages the factor ONCE, and then
 // every wave walks SEVERAL pairs of lane tiles on its own -- no barrier, no staging, operands straight from LDS, X two
 // chunks ahead across tile boundaries -- with a slim per-tile epilogue (reciprocal denominators, sums kept per lane and
-// reduced once per workgroup).  One sum-table slot per workgroup.  Needs D % 64 == 0 (the host checks; else streaming).
+// reduced once per workgroup).  One sum-table slot per workgroup.  The loop runs in whole trips of four chunks: a D that is not a
+// multiple of 64 (round 4: m = 1000 is as natural as 1024) is walked as roundup64(D) steps -- the rows behind D staged as zeros, their
+// ratios (0 / 0) masked in the last trip.
 // ------------------------------------------------------------------------------------------------------
 #ifndef NMFK_HYB_RW
 #define NMFK_HYB_RW 16  // waves per workgroup of the resident form
@@ -796,7 +798,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
 // OBJ: the monitored objective (Mult:74) of the units instead of a half-step, like the streaming kernel's OBJ mode: gp = the
 // W half-step's arguments, `it` = parity of the H buffer that holds the current H, first product only, one partial per
 // workgroup in ossepart[b] (the entries b >= gridDim.x up to ntile are zeroed: check_a_kernel adds ntile of them).
-template <int KS, int NS, int NT, bool OBJ>
+template <int KS, int NS, int NT, bool OBJ, bool RAG>  // RAG: D is not a multiple of 64 (a kernel of its own: the masks cost the other 1-2 %)
 __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restrict__ Xt, const NmfkRun *__restrict__ runs,
                                              const NmfkState *__restrict__ state, const NmfkStepArgs *__restrict__ gp, int it, int u0,
                                              double weight, int ntile,
@@ -813,16 +815,18 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
   const int k = rdp->k;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
   const int which = gp->which, L = gp->L, D = gp->D;
-  const int nch = D >> 4;
+  const int Dp = (D + 63) & ~63;  // loop steps walked (whole trips)
+  const int nch = Dp >> 4;
+  constexpr bool ragged = RAG;    // the last trip holds steps >= D
   const float *__restrict__ A = (const float *)(arena + (which == 0 ? NMFK_HOFF(*rdp, it) : rdp->oWt));          // lane factor
   const float *__restrict__ B = (const float *)(arena + (which == 0 ? rdp->oWt : NMFK_HOFF(*rdp, OBJ ? it : it + 1)));  // loop factor
   char *sb = (char *)(lds + 18 * 16);  // den[16], red[16][16], rden[16] (+ padding)
   const int BFB = nch * ST::CHP;
 
   // ---- the whole loop factor -> LDS, once per workgroup: item = (row, pair of adjacent signals)
-  for (int q = tid; q < D * ST::PPR; q += 64 * RW) {
+  for (int q = tid; q < Dp * ST::PPR; q += 64 * RW) {
     const int r = q / ST::PPR, cp = q - r * ST::PPR;
-    const float v0 = 2 * cp < k ? B[(int64_t)r * k + 2 * cp] : 0.0f, v1 = 2 * cp + 1 < k ? B[(int64_t)r * k + 2 * cp + 1] : 0.0f;
+    const float v0 = (r < D && 2 * cp < k) ? B[(int64_t)r * k + 2 * cp] : 0.0f, v1 = (r < D && 2 * cp + 1 < k) ? B[(int64_t)r * k + 2 * cp + 1] : 0.0f;
     uint32_t h, m, l;
     split3_pair(v0, v1, h, m, l);
     const int ch = r >> 4, rr = r & 15;
@@ -864,7 +868,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
 
   const int ntp = (L + 16 * NT - 1) / (16 * NT);  // pairs (NT-tuples) of 16-lane tiles
   const int stride = RW * G;
-  const int nD16 = nch, nL16 = (L + 15) >> 4;
+  const int nD16 = (D + 15) >> 4, nL16 = (L + 15) >> 4;  // (chunks of the tiled copy of X: the chunks behind it read its last one again, masked)
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)Xt, 0, -1, 0x00020000);
   int fofs[NM];
 #pragma unroll
@@ -885,7 +889,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
   auto xload = [&](const int (&xo)[NT], int c, f32x4_t (&xv)[NT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
-      xv[t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, xlane, xo[t] + c * 1024, 0));
+      xv[t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, xlane, xo[t] + (RAG ? min(c, nD16 - 1) : c) * 1024, 0));
   };
   f32x4_t xr[4][NT];
   u32x4_t avn[NM];
@@ -973,7 +977,11 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
             f32x2_t s2 = {0.0f, 0.0f};
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
-              const f32x2_t e2 = (f32x2_t){xr[ci][t][r], xr[ci][t][r + 1]} - (f32x2_t){p[t][r], p[t][r + 1]};
+              f32x2_t e2 = (f32x2_t){xr[ci][t][r], xr[ci][t][r + 1]} - (f32x2_t){p[t][r], p[t][r + 1]};
+              if (TAIL && ragged) {
+                e2.x = 16 * c + 4 * g + r < D ? e2.x : 0.0f;
+                e2.y = 16 * c + 4 * g + r + 1 < D ? e2.y : 0.0f;
+              }
               s2 = __builtin_elementwise_fma(e2, e2, s2);
             }
             part += lv[t] ? s2.x + s2.y : 0.0f;
@@ -991,6 +999,10 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
             const f32x2_t q2 = (f32x2_t){xr[ci][t][r], xr[ci][t][r + 1]} * rc;
             q[t][r] = q2.x;
             q[t][r + 1] = q2.y;
+            if (TAIL && ragged) {
+              q[t][r] = 16 * c + 4 * g + r < D ? q[t][r] : 0.0f;
+              q[t][r + 1] = 16 * c + 4 * g + r + 1 < D ? q[t][r + 1] : 0.0f;
+            }
           }
         if (NS > 0) {
 #pragma unroll
@@ -1060,6 +1072,10 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
             const f32x2_t q2 = (f32x2_t){xr[ci][t][r], xr[ci][t][r + 1]} * rc;
             q[t][r] = q2.x;
             q[t][r + 1] = q2.y;
+            if (TAIL && ragged) {  // (steps >= D: zero rows of the loop factor, 0 / 0)
+              q[t][r] = 16 * c + 4 * g + r < D ? q[t][r] : 0.0f;
+              q[t][r + 1] = 16 * c + 4 * g + r + 1 < D ? q[t][r + 1] : 0.0f;
+            }
           }
         __builtin_amdgcn_sched_barrier(0);
         if (!last) {  // operands of the chunk after next (the last-but-one chunk fetches chunk 0 again: the next tile pair's)
@@ -1586,15 +1602,15 @@ __global__ __launch_bounds__(64 * (NW > 8 ? NW : 8), MODE == 1 ? 2 : 4) void hyb
   }
 }
 
-template <int NT, bool OBJ>
+template <int NT, bool OBJ, bool RAG = false>
 __global__ __launch_bounds__(64 * NMFK_HYB_RW) void hyb_res_kernel(char *arena, const float *__restrict__ Xt, const NmfkRun *__restrict__ runs,
                                                       const NmfkState *__restrict__ state, const NmfkStepArgs *__restrict__ gp,
                                                       int it, int u0, double weight, int ntile) {
   extern __shared__ double lds[];
   switch (runs[u0 + blockIdx.y].hyb) {
-    case 4: hyb_res_body<4, OBJ ? 0 : 1, NT, OBJ>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
-    case 8: hyb_res_body<8, OBJ ? 0 : 2, NT, OBJ>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
-    default: hyb_res_body<16, 0, NT, OBJ>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
+    case 4: hyb_res_body<4, OBJ ? 0 : 1, NT, OBJ, RAG>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
+    case 8: hyb_res_body<8, OBJ ? 0 : 2, NT, OBJ, RAG>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
+    default: hyb_res_body<16, 0, NT, OBJ, RAG>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
   }
 }
 
@@ -1630,10 +1646,10 @@ size_t hyb_chunk_bytes(int vmax) {
 
 int nmfk_hyb_resident_waves() { return NMFK_HYB_RW; }
 // Resident form: bytes of LDS a workgroup needs for a loop dimension of D when the widest variant of the launch is vmax
-// (0: not applicable -- D % 64 != 0 or too long)
+// (0: not applicable -- shorter than one trip, or too long); any D: the kernel walks roundup64(D) steps
 size_t nmfk_hyb_resident_lds(int vmax, int D) {
-  if (D < 64 || (D & 63) != 0) return 0;
-  const size_t need = sizeof(double) * 18 * 16 + (size_t)(D >> 4) * hyb_chunk_bytes(vmax);
+  if (D < 64) return 0;
+  const size_t need = sizeof(double) * 18 * 16 + (size_t)(((D + 63) & ~63) >> 4) * hyb_chunk_bytes(vmax);
   return need <= 160 * 1024 ? need : 0;
 }
 
@@ -1643,10 +1659,16 @@ size_t nmfk_hyb_resident_lds(int vmax, int D) {
 void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int vmax, int u0, int cnt, hipStream_t s, double objw) {
   constexpr int NT = NMFK_HYB_NT, NW = NMFK_HYB_NW;
   if (a.res_wgs > 0) {  // resident form (the host has checked nmfk_hyb_resident_lds)
-    static std::atomic<uint64_t> lds_ok{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
-    nmfk_allow_dynamic_lds((const void *)hyb_res_kernel<NT, false>, lds_ok, 160 * 1024);
-    hipLaunchKernelGGL((hyb_res_kernel<NT, false>), dim3(a.res_wgs, cnt), dim3(64 * NMFK_HYB_RW), nmfk_hyb_resident_lds(vmax, a.D), s,
-                       a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0, 0);
+    static std::atomic<uint64_t> lds_ok{0}, lds_okr{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
+    if ((a.D & 63) != 0) {
+      nmfk_allow_dynamic_lds((const void *)hyb_res_kernel<NT, false, true>, lds_okr, 160 * 1024);
+      hipLaunchKernelGGL((hyb_res_kernel<NT, false, true>), dim3(a.res_wgs, cnt), dim3(64 * NMFK_HYB_RW), nmfk_hyb_resident_lds(vmax, a.D), s,
+                         a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0, 0);
+    } else {
+      nmfk_allow_dynamic_lds((const void *)hyb_res_kernel<NT, false>, lds_ok, 160 * 1024);
+      hipLaunchKernelGGL((hyb_res_kernel<NT, false>), dim3(a.res_wgs, cnt), dim3(64 * NMFK_HYB_RW), nmfk_hyb_resident_lds(vmax, a.D), s,
+                         a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0, 0);
+    }
     return;
   }
   const int ws = a.wsplit, nwaves = ws > 1 ? ws : NW;
@@ -1685,11 +1707,17 @@ void nmfk_launch_hyb_sse(const NmfkStepArgs &w, const NmfkStepArgs *dw, double w
                          hipStream_t s) {
   constexpr int NT = NMFK_HYB_NT, NW = 8;
   if (w.res_wgs > 0) {  // resident form (W orientation: the loop factor H sits in LDS), res_wgs partials per unit
-    static std::atomic<uint64_t> lds_ok{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
-    nmfk_allow_dynamic_lds((const void *)hyb_res_kernel<NT, true>, lds_ok, 160 * 1024);
+    static std::atomic<uint64_t> lds_ok{0}, lds_okr{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
     const int ntile = (w.L + NMFK_TILE - 1) / NMFK_TILE;  // partials check_a_kernel adds (sse_kernel's count)
-    hipLaunchKernelGGL((hyb_res_kernel<NT, true>), dim3(std::min(w.res_wgs, ntile), cnt), dim3(64 * NMFK_HYB_RW),
-                       nmfk_hyb_resident_lds(vmax, w.D), s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight, ntile);
+    if ((w.D & 63) != 0) {
+      nmfk_allow_dynamic_lds((const void *)hyb_res_kernel<NT, true, true>, lds_okr, 160 * 1024);
+      hipLaunchKernelGGL((hyb_res_kernel<NT, true, true>), dim3(std::min(w.res_wgs, ntile), cnt), dim3(64 * NMFK_HYB_RW),
+                         nmfk_hyb_resident_lds(vmax, w.D), s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight, ntile);
+    } else {
+      nmfk_allow_dynamic_lds((const void *)hyb_res_kernel<NT, true>, lds_ok, 160 * 1024);
+      hipLaunchKernelGGL((hyb_res_kernel<NT, true>), dim3(std::min(w.res_wgs, ntile), cnt), dim3(64 * NMFK_HYB_RW),
+                         nmfk_hyb_resident_lds(vmax, w.D), s, w.arena, w.Xtile, w.runs, w.state, dw, hsel, u0, weight, ntile);
+    }
     return;
   }
   const int lpw = 16 * NT * NW;  // = NMFK_TILE: the partials line up with sse_kernel's

@@ -1300,7 +1300,7 @@ def test_deferred_check_against_the_plain_order(NMFk, ctx, oracle, monkeypatch):
     maxiter is a multiple of 10 has no half-step behind it and stays plain; also with the loop range split over two workgroups
     (140 units: S = 2, partials per split, the half-step finished by the reduce kernel).  (The oracle comparisons of the stop
     rule -- the fixture test, the branch tests -- run in the default mode, i.e. deferred wherever the geometry allows.)"""
-    n, m, k0 = 650, 640, 3  # (n % 64 != 0: the H half-step in its streaming form; m = 640: lane tiles of 256 columns, the last one ragged)
+    n, m, k0 = 2650, 640, 3  # (n too long for LDS: the H half-step in its streaming form; m = 640: lane tiles of 256 columns, the last one ragged)
     W0 = oracle.uniform_fill(9, 0, n * k0).reshape(n, k0)
     H0 = oracle.uniform_fill(9, n * k0, k0 * m).reshape(k0, m)
     X = np.asfortranarray((W0 @ H0 + 0.02 * oracle.uniform_fill(9, n * k0 + k0 * m, n * m).reshape(n, m)).astype(np.float32))

@@ -1417,7 +1417,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   const bool hyb_sse = T.hyb_sse != 0;  // objective of those groups on the matrix pipe
   // sparse X: the (few, large) launch groups run one after the other -- side by side their gathers evict each other's
   // factor rows from L2 (29.2 vs 31.7 ms per iteration on BASELINE configs[3])
-  const int max_streams = T.streams > 0 ? T.streams : (ctx->sparse ? 1 : 8);
+  // dense X: per-rank launch groups (ranks above 16, fp64 compute) side by side on up to 8 streams, 16 when there are a dozen
+  // groups or more on a matrix that is not tiny (k = 17:32 x 8 at 8192 x 512: 1.37 -> 1.05 ms per iteration, at 20000 x 1000 5.9 -> 5.0;
+  // one after the other: 6.3 ms; at 1024 x 128 the loop is bound by the host's launches and more streams buy nothing --
+  // profiles/r04/wide_rank_streams.txt)
+  const int max_streams = T.streams > 0 ? T.streams : ctx->sparse ? 1 : (ngroups >= 12 && (double)n * m >= 0.25 * 8192.0 * 512.0) ? 16 : 8;
   const int NS = std::min(ngroups, max_streams);
   while ((int)ctx->gstreams.size() < NS) {
     hipStream_t gs;

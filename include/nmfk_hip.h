@@ -300,6 +300,8 @@ int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *
  *                     matrix-pipe kernels: the H half-step that follows a check iteration leaves it as a by-product and the check's
  *                     tests run behind that half-step; same stop decisions, the objective taken after the clamp instead of before:
  *                     <= 1e-13 of its value)
+ *   NMFK_WIDE_GROUPS  0: a launch group per rank above 16; f: the ranks of one kernel instantiation (32 / 48 / 64 signals) share launch
+ *                     groups of up to f workgroups per CU (default 2)
  *   NMFK_SP_BLK       0: sparse X in the gather form only (no sliced-ELL copies are built); 2: blocked form whatever the size
  *   NMFK_TARGET_WGS   workgroups a half-step launch should have before loop ranges are split (default 2 x CUs)
  *   NMFK_STREAMS      concurrent launch-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1: host / GPU wait times on stderr

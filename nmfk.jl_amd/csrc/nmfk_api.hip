@@ -117,7 +117,7 @@ struct Sampler {
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, merge = -1, phases = -1;
   int wide_sse = 1, streams = -1, host_timing = 0;
-  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1;
+  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1, wide_groups = 2;
   // (not knobs any more -- round 3's A/B switches with their measured settings: one mixed-rank matrix-pipe group, the waves of
   //  a workgroup may split a loop range 8 ways, the small ranks on their own kernel variants, four pairs of lane tiles per
   //  wave of the resident form, merged sweeps side by side)
@@ -145,6 +145,7 @@ Tuning read_tuning() {
   geti("NMFK_REPLAN", t.replan);
   geti("NMFK_CLAMP_ALWAYS", t.clamp_always);
   geti("NMFK_DEFER_OBJ", t.defer_obj);
+  geti("NMFK_WIDE_GROUPS", t.wide_groups);
   return t;
 }
 
@@ -1103,7 +1104,22 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     if (hyb_phases && use_hyb_k(k)) continue;
     // sparse X: one kernel instantiation serves every rank with the same number of lanes per lane element, so those
     // ranks share a launch group (31 per-rank launches of 16 units each left the GPU half empty: 33 -> 21 ms)
-    if (ctx->sparse && !groups.empty() && nmfk_sp_lpr(groups.back().kp) == nmfk_sp_lpr(nmfk_padded_k(k))) {
+    // ranks above 16 on the split-operand kernel: the instantiation is chosen by the padded width's blocks of sixteen signals
+    // (32 / 48 / 64) and a workgroup takes its unit's rank from NmfkRun, so the ranks of one instantiation share a launch group
+    // (round 4; NMFK_WIDE_GROUPS=0: a group per rank.  k = 2:40 x 4 at 8192 x 512: 1.51 -> 1.27 ms per iteration, k = 17:32 x 2:
+    //  0.41 -> 0.31, at 1024 x 128 0.47 -> 0.18 -- profiles/r04/wide_rank_groups.txt)
+    auto wide2_nb = [](int kp) { return kp <= 32 ? 2 : kp <= 48 ? 3 : 4; };
+    const bool w2 = T.wide_groups && !ctx->sparse && !f64 && use_wide_k(k) && use_wide2_k(k) && ghp[phase_of_k(k)].wsplit == 1 &&
+                    gwp[phase_of_k(k)].wsplit == 1;
+    // ... as long as the group is short of workgroups: a launch group per rank keeps the half-steps of different ranks overlapping
+    // (no launch-wide barrier between them), which is worth 4-10 % once a rank fills the chip by itself: ranks join a group until
+    // its W half-step has T.wide_groups (2) workgroups per CU
+    const int64_t w2_wgs = groups.empty() ? 0 : (int64_t)groups.back().count * ((n + nmfk_wide2_lane_tile() - 1) / nmfk_wide2_lane_tile());
+    if (w2 && !groups.empty() && groups.back().hyb == 0 && groups.back().kp > 16 && use_wide2_k(groups.back().k) &&
+        groups.back().phase == phase_of_k(k) && wide2_nb(groups.back().kp) == wide2_nb(nmfk_padded_k(k)) &&
+        w2_wgs < (int64_t)T.wide_groups * cus) {
+      groups.back().count += nruns;  // (ranks come in descending order: k and kp of the group stay its widest rank's)
+    } else if (ctx->sparse && !groups.empty() && nmfk_sp_lpr(groups.back().kp) == nmfk_sp_lpr(nmfk_padded_k(k))) {
       groups.back().kp = std::max(groups.back().kp, nmfk_padded_k(k));
       groups.back().count += nruns;
     } else {

@@ -6,8 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import nmfk_jl_amd as N
 ctx = N.Context(0)
-MODES = {"default": {}, "streams=4": {"NMFK_STREAMS": "4"}, "streams=16": {"NMFK_STREAMS": "16"}, "streams=24": {"NMFK_STREAMS": "24"}}
-for (n, m) in ((8192, 512), (20000, 1000), (1024, 128)):
+MODES = {"f=0": {"NMFK_WIDE_GROUPS": "0"}, "f=1": {"NMFK_WIDE_GROUPS": "1"}, "f=2": {"NMFK_WIDE_GROUPS": "2"}, "f=4": {"NMFK_WIDE_GROUPS": "4"}, "f=1000": {"NMFK_WIDE_GROUPS": "1000"}}
+for (n, m) in ((8192, 512), (20000, 1000), (1024, 128), (2048, 2048), (65536, 2048)):
     X = ctx.fill_uniform(5, 0, n * m).reshape(m, n).T
     ctx.set_X(X)
     for ks, R in ((list(range(17, 33)), 8), (list(range(17, 33)), 2), ([20, 30, 40, 50, 64], 8), (list(range(2, 41)), 4), ([24, 48], 16)):
@@ -16,7 +16,7 @@ for (n, m) in ((8192, 512), (20000, 1000), (1024, 128)):
         seeds = np.array([[N.run_seed(1, k, r) for r in range(R)] for k in ks], dtype=np.uint64)
         out = []
         for mode, env in MODES.items():
-            for key in ("NMFK_STREAMS", "NMFK_WIDE2"):
+            for key in ("NMFK_STREAMS", "NMFK_WIDE2", "NMFK_WIDE_GROUPS"):
                 os.environ.pop(key, None)
             os.environ.update(env)
             ctx.mu_sweep(ks, R, seeds=seeds, maxiter=10, maxbaditers=10 ** 9)

@@ -1376,3 +1376,30 @@ def test_deferred_check_against_the_plain_order(NMFk, ctx, oracle, monkeypatch):
         for r in range(2):
             assert len(wtrace["1"][(k, r)]) == 4 and len(wtrace["0"][(k, r)]) == 4
             np.testing.assert_allclose(wtrace["1"][(k, r)], wtrace["0"][(k, r)], rtol=2e-6)
+
+
+@pytest.mark.gpu
+def test_wide_ranks_of_one_instantiation_share_a_launch_group(NMFk, ctx, oracle, monkeypatch):
+    """Round 4: ranks above 16 whose padded widths take the same instantiation of wide2_step_kernel (32 / 48 / 64 signals) run
+    in ONE launch group (a workgroup takes its unit's rank from NmfkRun), instead of a launch group per rank.  The launch geometry
+    is a function of the ranks, not of the groups: the same bits as with a group per rank (NMFK_WIDE_GROUPS=0); against the oracle."""
+    n, m = 300, 520
+    X = (0.05 + oracle.uniform_fill(21, 0, n * m)).reshape(n, m).astype(np.float32)
+    ctx.set_X(X)
+    ks, R = [17, 20, 24, 31, 40, 48, 64], 2
+    seeds = _seeds(NMFk, 7, ks, R)
+    a = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=25, **NOSTOP)
+    ia = ctx.last_sweep_info()
+    monkeypatch.setenv("NMFK_WIDE_GROUPS", "0")
+    b = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=25, **NOSTOP)
+    ib = ctx.last_sweep_info()
+    assert ia["launch_groups"] == 3 and ib["launch_groups"] == len(ks), (ia, ib)
+    assert ia["wide_mfma_units"] == len(ks) * R
+    for k in ks:
+        for key in ("W", "H", "objvalue", "iters"):
+            assert (a[k][key] == b[k][key]).all(), (k, key)
+    for q, k in enumerate(ks):
+        W0, H0 = oracle.init_factors(int(seeds[q, 1]), n, m, k)
+        ref = oracle.singlerun(X, k, W0, H0, maxiter=25, **NOSTOP)
+        assert _rel(a[k]["W"][1] @ a[k]["H"][1], ref["W"] @ ref["H"], X) <= 1e-4, k
+        assert abs(a[k]["objvalue"][1] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]

@@ -297,7 +297,7 @@ int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *
  *   NMFK_CLAMP_ALWAYS 1: the clamp pass of a check block (Mult:99-100) scans every unit (default: only units whose half-step kernels
  *                     wrote a value below eps() in the check iteration; the same elements are clamped either way, the results agree to rounding)
  *   NMFK_DEFER_OBJ    0: every check block computes its monitored objective (Mult:74) in a launch of its own (default on the
- *                     matrix-pipe kernels: the H half-step that follows a check iteration leaves it as a by-product and the check's
+ *                     matrix-pipe kernels and for sparse X in the blocked form: the H half-step that follows a check iteration leaves it as a by-product and the check's
  *                     tests run behind that half-step; same stop decisions, the objective taken after the clamp instead of before:
  *                     <= 1e-13 of its value)
  *   NMFK_WIDE_GROUPS  0: a launch group per rank above 16; f: the ranks of one kernel instantiation (32 / 48 / 64 signals) share launch

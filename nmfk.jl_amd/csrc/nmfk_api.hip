@@ -1327,8 +1327,12 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // Deferred check (see the loop): is the sweep eligible, and does a pair of half-step geometries allow it -- the H half-step
   // must have an objective mode for its geometry, and the W half-step must end on a kernel that clamps what it writes in a check
   // iteration (NmfkStepArgs::clampw)
-  const bool defer_ok = T.defer_obj && !ctx->sparse && !f64 && !P.Hfixed && !P.Wfixed && ctx->Wgt == nullptr && T.hyb_sse && T.wide_sse &&
-                        P.weight > 0;  // (the launchers take the weight as the switch: objw > 0)
+  const bool defer_any = T.defer_obj && !f64 && !P.Hfixed && !P.Wfixed && ctx->Wgt == nullptr &&
+                         P.weight > 0;  // (the launchers take the weight as the switch: objw > 0)
+  const bool defer_ok = defer_any && !ctx->sparse && T.hyb_sse && T.wide_sse;
+  // sparse X, blocked form (ranks up to 32): the H half-step's products at the non-zeros are the objective's; the Gram term keeps its
+  // launches.  Needs both half-steps in the blocked form and a slot per lane tile of the H half-step behind slot 0 of ossepart.
+  const bool defer_sp = defer_any && ctx->sparse && sp_blk[0] && sp_blk[1] && (m + NMFK_SPB_ROWS - 1) / NMFK_SPB_ROWS <= tiles_n;
   auto defer_geo = [&](const NmfkStepArgs &h, const NmfkStepArgs &w, bool hyb) {
     NmfkStepArgs hh = h;
     if (!hyb) hh.res_wgs = 0;  // (the resident form is the rank <= 16 kernels' only)
@@ -1338,7 +1342,10 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     return (defer_ok && parts > 0 && parts <= obj_cap && wfin) ? parts : 0;
   };
   // groups whose kernels have the objective mode: the rank <= 16 matrix-pipe group(s) and the split-operand wide-rank kernel
-  auto defer_kind = [&](const Group &G) { return G.hyb != 0 ? 1 : (use_wide_k(G.k) && use_wide2_k(G.k) && G.kp != 0) ? 2 : 0; };
+  auto defer_kind = [&](const Group &G) {
+    if (ctx->sparse) return (defer_sp && nmfk_sp_blk_rank(G.kp)) ? 3 : 0;
+    return G.hyb != 0 ? 1 : (use_wide_k(G.k) && use_wide2_k(G.k) && G.kp != 0) ? 2 : 0;
+  };
   for (int ph = 0; ph < 2; ++ph) {
     bool any = false, all = true;
     for (const Group &G : groups)
@@ -1411,6 +1418,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   sph.ellptr = ctx->ellptr[1];
   sph.ngb = ctx->ell_ngb[1];
   sph.D = n;
+  sph.objw = 0.0;
+  sph.ntile_obj = tiles_n;
+  sph.clampw = 0;
   spw = sph;
   spw.split = 0;
   spw.ell = sp_blk[1] ? ctx->ell[0] : nullptr;
@@ -1514,6 +1524,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // Not for the last iteration (no half-step follows), fixed factors, array weights, nor where the H half-step runs in its resident
   // form -- those checks keep their objective launch.
   auto defer_parts = [&](const Group &G) {
+    if (defer_kind(G) == 3) return tiles_n + 1;  // (what check_a adds: slot 0 = the Gram term, the H half-step's lane tiles, zeros)
     return (defer_kind(G) && wsP[G.phase].clampw) ? defer_geo(hsP[G.phase], wsP[G.phase], defer_kind(G) == 1) : 0;
   };
   auto track_low_of = [&](const Group &G) {
@@ -1547,6 +1558,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       if (!P.Hfixed) {  // Mult:66-68
         const size_t e0 = timed ? prof.begin(gs) : 0;
         sph.it = it;
+        sph.objw = (sparse && pending[j]) ? P.weight : 0.0;
         if (sparse && f64)
           nmfk_launch_sp_step_f64(&sph, G.kp, G.begin, G.count, gs);
         else if (sparse)
@@ -1587,6 +1599,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       if (!P.Wfixed) {  // Mult:69-71
         const size_t e0 = timed ? prof.begin(gs) : 0;
         spw.it = it;
+        spw.clampw = defer_kind(G) == 3;
         if (sparse && f64)
           nmfk_launch_sp_step_f64(&spw, G.kp, G.begin, G.count, gs);
         else if (sparse)
@@ -1617,10 +1630,14 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             nmfk_launch_reduce_f32(wr, G.begin, G.count, gs);
         }
       }
-      ca.w_clamped = defer_kind(G) != 0 && wsP[G.phase].clampw;
+      ca.w_clamped = defer_kind(G) == 3 || (defer_kind(G) != 0 && wsP[G.phase].clampw);
       if (check && it + 1 < maxiter && defer_parts(G) > 0) {
         ca.track_low = track_low_of(G);
         nmfk_launch_check_f32(ca, G.begin, G.count, gs, 2);
+        if (sparse) {  // the Gram term of the clamped factors -> slot 0; the non-zero terms come with the next H half-step
+          spw.it = it;
+          nmfk_launch_sp_obj_f32(&spw, n, m, (it + 1) & 1, 0, P.weight, G.begin, G.count, gs, 2);
+        }
         pending[j] = defer_parts(G);
         deferring = true;
         ++ndeferred;
@@ -2055,6 +2072,9 @@ NMFK_EXPORT int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float
     ia.nan_flag = (int32_t *)(S + oFlag);
     nmfk_launch_init_f32(ia, st);
     NmfkSparseArgs sp;
+    sp.objw = 0.0;
+    sp.ntile_obj = 0;
+    sp.clampw = 0;
     sp.arena = S;
     sp.ptr = ctx->rowptr;
     sp.rec = ctx->rec_csr;

@@ -132,6 +132,11 @@ struct NmfkSparseArgs {
   const int32_t *ellptr;
   int32_t ngb;
   int32_t D;      // the loop dimension (rows of the gathered factor)
+  // deferred check (nmfk_mu_sweep; blocked form): objw > 0: the H half-step also leaves the non-zero terms of the objective of the
+  // factors it reads, scaled by objw^2, in ossepart[1 + tile] (ntile_obj entries behind slot 0 in all: the rest zeroed);
+  // clampw: the W half-step's finish of a check iteration writes max(W, eps())
+  double objw;
+  int32_t ntile_obj, clampw;
 };
 #define NMFK_SPB_ROWS 1024  // blocked form: lane elements per workgroup (one per thread; = its sum-table slot) and rows of the
                             // gathered factor per granule of the sliced ELL
@@ -284,7 +289,7 @@ static inline int nmfk_padded_k(int k) {
                                    hipStream_t s);                                                                \
   void nmfk_launch_sp_step_##SUF(const void *sparse_args, int kp, int u0, int cnt, hipStream_t s);                \
   void nmfk_launch_sp_obj_##SUF(const void *sparse_args, int n, int m, int hsel, int total_iters, double weight,   \
-                                int u0, int cnt, hipStream_t s);                                                  \
+                                int u0, int cnt, hipStream_t s, int parts = 3);                                   \
   void nmfk_launch_finish_##SUF(const NmfkFinishArgs &a, hipStream_t s);
 NMFK_DECLARE_LAUNCHERS(f32)
 void nmfk_launch_kmeans(const float *X, int d, int n, int k, int repeats, int maxiter, double tol, uint64_t seed,

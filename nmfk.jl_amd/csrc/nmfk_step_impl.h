@@ -1269,7 +1269,9 @@ __global__ __launch_bounds__(NMFK_TILE) void sp_step_kernel(NmfkSparseArgs g, in
 #ifdef NMFK_IS_F32
 // OBJ: the non-zero terms of the objective (see sp_obj_kernel) instead of a half-step: rows of W as lane elements, Hobj the
 // H to measure, the workgroup's partial in ossepart[1 + 4 tile] (the entries of the three other 256-row tiles are zeroed)
-template <int NC, bool OBJ>
+// SSE (round 4, the deferred check): a half-step (H orientation) that also leaves the objective's non-zero terms of the factors it
+// reads -- its products p = <h_j, w_i> at the non-zeros are the ones sp_blk_obj_kernel recomputes -- in ossepart[1 + tile]
+template <int NC, bool OBJ, bool SSE = false>
 __device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkRun &rd, const int tile, char *lds,
                                             const T *__restrict__ Hobj, double weight) {
   constexpr int KQ = 4 * NC;                   // signals a lane holds (kp rounded up to 4)
@@ -1385,10 +1387,11 @@ __device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkR
               s1 = fma2(T2{a[c][2], a[c][3]}, T2{h[c][2], h[c][3]}, s1);
             }
             const T pr = (s0.x + s0.y) + (s1.x + s1.y);
-            if (OBJ) {
+            if (OBJ || SSE) {
               const double xd = (double)x, p = (double)pr;
               sobj += (xd - p) * (xd - p) - p * p;
-            } else {
+            }
+            if (!OBJ) {
               const T q = div_t(x, pr);
 #pragma unroll
               for (int c = 0; c < NC; ++c) {
@@ -1419,6 +1422,23 @@ __device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkR
     }
     return;
   }
+  if (SSE) {  // the workgroup's partial of the objective (lanes in a butterfly, the 16 waves in order), slot 1 + tile
+    double *wsum = (double *)lds;
+    sobj *= g.objw * g.objw;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sobj += __shfl_xor(sobj, o, 64);
+    if (lane == 0) wsum[wave] = sobj;
+    __syncthreads();
+    double *part = NMFK_PTR(double, g, rd.ossepart);
+    if (tid == 0) {
+      double t = 0;
+      for (int wv = 0; wv < 16; ++wv) t += wsum[wv];
+      part[1 + tile] = t;
+    }
+    if (tile == 0)  // (the entries behind the lane tiles' own: check_a adds ntile_obj of them)
+      for (int e = 1 + (g.L + NMFK_SPB_ROWS - 1) / NMFK_SPB_ROWS + tid; e < 1 + g.ntile_obj; e += 1024) part[e] = 0.0;
+    __syncthreads();
+  }
   // denominators: the other factor's sum table, thread (j, c) adds the slots j, j + 32, ... of signal c, then the 32 partial
   // sums are added in order (a fixed order: reproducible)
   double *red = (double *)lds, *den = red + 1024;
@@ -1439,6 +1459,7 @@ __device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkR
     __syncthreads();
   }
   // fused finish (Mult:67 / Mult:70 order)
+  const T floorv = (g.clampw && g.which == 1 && (g.it + 1) % 10 == 0) ? (T)2.220446049250313e-16 : -(T)INFINITY;
   sp_vec4 v[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
@@ -1446,6 +1467,7 @@ __device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkR
     for (int e = 0; e < 4; ++e) {
       const int sig = 4 * c + e;
       v[c][e] = (valid && sig < k) ? a[c][e] * acc[c][e] / (T)den[sig < kp ? sig : 0] : (T)0;
+      if (valid && sig < k && v[c][e] < floorv) v[c][e] = floorv;  // (NmfkSparseArgs::clampw; a NaN stays)
     }
   if (valid) {
     T *dst = Anew + (int64_t)l * kp;
@@ -1518,6 +1540,26 @@ __global__ __launch_bounds__(1024) void sp_blk_kernel(NmfkSparseArgs g, int u0, 
     case 6: sp_blk_body<6, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
     case 7: sp_blk_body<7, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
     case 8: sp_blk_body<8, false>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    default: break;
+  }
+}
+// the H half-step behind a check iteration (deferred check): the half-step and the objective's non-zero terms
+__global__ __launch_bounds__(1024) void sp_blk_sse_kernel(NmfkSparseArgs g, int u0, int cnt) {
+  extern __shared__ char spb_lds[];
+  int tile, ul;
+  if (!sp_blk_where(g, cnt, tile, ul)) return;
+  const int u = u0 + ul;
+  if (!g.force && !g.state[u].active) return;
+  const NmfkRun rd = g.runs[u];
+  switch ((rd.kp + 3) >> 2) {
+    case 1: sp_blk_body<1, false, true>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    case 2: sp_blk_body<2, false, true>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    case 3: sp_blk_body<3, false, true>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    case 4: sp_blk_body<4, false, true>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    case 5: sp_blk_body<5, false, true>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    case 6: sp_blk_body<6, false, true>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    case 7: sp_blk_body<7, false, true>(g, rd, tile, spb_lds, nullptr, 0.0); break;
+    case 8: sp_blk_body<8, false, true>(g, rd, tile, spb_lds, nullptr, 0.0); break;
     default: break;
   }
 }
@@ -2164,9 +2206,14 @@ void NMFK_NAME(nmfk_launch_sp_step)(const void *argsv, int kp, int u0, int cnt, 
   const NmfkSparseArgs &a = *(const NmfkSparseArgs *)argsv;
 #ifdef NMFK_IS_F32
   if (a.ell && nmfk_sp_blk_rank(kp)) {  // blocked form: a lane element per thread, the gathered factor through LDS
-    static std::atomic<uint64_t> lds_ok{0};
-    nmfk_allow_dynamic_lds((const void *)sp_blk_kernel, lds_ok, NMFK_SPB_LDS);
-    hipLaunchKernelGGL(sp_blk_kernel, dim3(sp_blk_grid(a, cnt)), dim3(1024), NMFK_SPB_LDS, s, a, u0, cnt);
+    static std::atomic<uint64_t> lds_ok{0}, lds_oks{0};
+    if (a.objw > 0 && a.which == 0) {
+      nmfk_allow_dynamic_lds((const void *)sp_blk_sse_kernel, lds_oks, NMFK_SPB_LDS);
+      hipLaunchKernelGGL(sp_blk_sse_kernel, dim3(sp_blk_grid(a, cnt)), dim3(1024), NMFK_SPB_LDS, s, a, u0, cnt);
+    } else {
+      nmfk_allow_dynamic_lds((const void *)sp_blk_kernel, lds_ok, NMFK_SPB_LDS);
+      hipLaunchKernelGGL(sp_blk_kernel, dim3(sp_blk_grid(a, cnt)), dim3(1024), NMFK_SPB_LDS, s, a, u0, cnt);
+    }
     return;
   }
 #endif
@@ -2186,19 +2233,22 @@ void NMFK_NAME(nmfk_launch_sp_step)(const void *argsv, int kp, int u0, int cnt, 
 }
 
 // objective of units [u0, u0 + cnt): ssepart[0] = <W'W, HH'>, ssepart[1 + tile] = non-zero terms
+// parts: 1 = the non-zero terms, 2 = the Gram term (the deferred check launches only the latter: the next H half-step leaves the former)
 void NMFK_NAME(nmfk_launch_sp_obj)(const void *argsv, int n, int m, int hsel, int total_iters, double weight, int u0,
-                                   int cnt, hipStream_t s) {
+                                   int cnt, hipStream_t s, int parts) {
   const NmfkSparseArgs &a = *(const NmfkSparseArgs *)argsv;  // CSR view: L = n
-  hipLaunchKernelGGL(sp_obj_kernel, dim3((a.L + NMFK_TILE - 1) / NMFK_TILE, cnt), dim3(NMFK_TILE), 0, s, a, hsel,
-                     total_iters, weight, u0);
+  if (parts & 1)
+    hipLaunchKernelGGL(sp_obj_kernel, dim3((a.L + NMFK_TILE - 1) / NMFK_TILE, cnt), dim3(NMFK_TILE), 0, s, a, hsel,
+                       total_iters, weight, u0);
 #ifdef NMFK_IS_F32
-  if (a.ell) {  // units of ranks up to 32 in the blocked form (either kernel leaves the other's units alone)
+  if ((parts & 1) && a.ell) {  // units of ranks up to 32 in the blocked form (either kernel leaves the other's units alone)
     static std::atomic<uint64_t> lds_ok{0};
     nmfk_allow_dynamic_lds((const void *)sp_blk_obj_kernel, lds_ok, NMFK_SPB_LDS);
     hipLaunchKernelGGL(sp_blk_obj_kernel, dim3(sp_blk_grid(a, cnt)), dim3(1024), NMFK_SPB_LDS, s, a, hsel, total_iters, weight,
                        u0, cnt);
   }
 #endif
+  if (!(parts & 2)) return;
   const int chunks = (n + NMFK_GRAM_ROWS - 1) / NMFK_GRAM_ROWS + (m + NMFK_GRAM_ROWS - 1) / NMFK_GRAM_ROWS;
   hipLaunchKernelGGL(sp_gram_part_kernel, dim3(chunks, cnt), dim3(NMFK_TILE), 0, s, a, n, m, hsel, total_iters, u0);
   hipLaunchKernelGGL(sp_gram_dot_kernel, dim3(cnt), dim3(NMFK_TILE), 0, s, a, n, m, weight, u0);

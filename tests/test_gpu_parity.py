@@ -1403,3 +1403,46 @@ def test_wide_ranks_of_one_instantiation_share_a_launch_group(NMFk, ctx, oracle,
         ref = oracle.singlerun(X, k, W0, H0, maxiter=25, **NOSTOP)
         assert _rel(a[k]["W"][1] @ a[k]["H"][1], ref["W"] @ ref["H"], X) <= 1e-4, k
         assert abs(a[k]["objvalue"][1] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
+
+
+@pytest.mark.gpu
+def test_sparse_deferred_check_against_the_plain_order(NMFk, ctx, oracle, monkeypatch):
+    """Round 4: sparse X, blocked form -- the H half-step behind a check iteration leaves the objective's non-zero terms (its
+    products at the non-zeros are the ones the objective launch recomputed), the Gram term keeps its launches, the W half-step clamps
+    what it writes.  Against the plain order (NMFK_DEFER_OBJ=0): fixed budget with checks at 10..40 (deferred) and none at the end,
+    objective trace check by check, results to rounding; ranks above 32 (gather form) keep the plain order in the same sweep; and a
+    tol stop decided by the deferred objective (Mult:75-78) lands on the same iteration."""
+    monkeypatch.setenv("NMFK_SP_BLK", "2")
+    n, m = 2300, 1100  # (three lane tiles of rows, two of columns; granules of 1024)
+    X, Xs = _sparse_case(oracle, n, m, 0.01, 77)
+    ctx.set_X_sparse(Xs)
+    ks, R = [3, 8, 17, 30, 40], 3
+    seeds = _seeds(NMFk, 9, ks, R)
+    out, info, trace = {}, {}, {}
+    ctx.set_objective_trace(True)
+    try:
+        for mode in ("0", "1"):
+            monkeypatch.setenv("NMFK_DEFER_OBJ", mode)
+            out[mode] = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=45, **NOSTOP)
+            info[mode] = ctx.last_sweep_info()
+            trace[mode] = {(k, r): ctx.objective_trace(ks.index(k), r) for k in ks for r in range(R)}
+    finally:
+        ctx.set_objective_trace(False)
+    assert info["0"]["deferred_checks"] == 0 and info["1"]["deferred_checks"] > 0 and info["1"]["plain_checks"] > 0, (info["0"], info["1"])
+    assert info["1"]["deferred_checks"] + info["1"]["plain_checks"] == info["0"]["plain_checks"]
+    for k in ks:
+        assert (out["0"][k]["iters"] == 45).all() and (out["1"][k]["iters"] == 45).all()
+        np.testing.assert_allclose(out["1"][k]["W"], out["0"][k]["W"], rtol=2e-5, atol=1e-12)
+        np.testing.assert_allclose(out["1"][k]["H"], out["0"][k]["H"], rtol=2e-5, atol=1e-12)
+        np.testing.assert_allclose(out["1"][k]["objvalue"], out["0"][k]["objvalue"], rtol=1e-6)
+        for r in range(R):
+            assert len(trace["1"][(k, r)]) == 4 and len(trace["0"][(k, r)]) == 4
+            np.testing.assert_allclose(trace["1"][(k, r)], trace["0"][(k, r)], rtol=2e-6, err_msg=str((k, r)))
+    # the tol stop by the deferred objective: bracket the objective of the first check
+    k = 8
+    obj10 = float(trace["1"][(k, 0)][0])
+    monkeypatch.setenv("NMFK_DEFER_OBJ", "1")
+    hi = ctx.mu_sweep([k], 1, seeds=seeds[1:2, :1], maxiter=30, tol=obj10 * (1 + 1e-5), **NOSTOP)[k]
+    lo = ctx.mu_sweep([k], 1, seeds=seeds[1:2, :1], maxiter=30, tol=obj10 * (1 - 1e-5), **NOSTOP)[k]
+    assert hi["iters"][0] == 10 and hi["reason"][0] == NMFk.STOP_TOL
+    assert lo["iters"][0] > 10

@@ -1153,7 +1153,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // half-step (see the loop), one per workgroup of that launch -- in any tier of the retire-aware schedule
   int obj_cap = tiles_n + 1;
   {
-    auto hparts = [&](int res, int wsplit, int S) { return res > 0 ? 0 : (m + nmfk_hyb_lane_tile(wsplit) - 1) / nmfk_hyb_lane_tile(wsplit) * S; };
+    auto hparts = [&](int res, int wsplit, int S) { return res > 0 ? res : (m + nmfk_hyb_lane_tile(wsplit) - 1) / nmfk_hyb_lane_tile(wsplit) * S; };
     int want = 0;
     for (const Group &G : groups)
       if (G.hyb || (use_wide_k(G.k) && use_wide2_k(G.k))) want = std::max(want, hparts(G.hyb ? res_wgs[0] : 0, ghp[G.phase].wsplit, ghp[G.phase].S));
@@ -1521,8 +1521,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // retires ends with the factors of iteration j as before (NmfkState::iters = j selects the buffer).  Two differences from
   // the plain order, both far below fp32 rounding: the objective is that of the factors AFTER the clamp (entries below eps()
   // raised to eps(): <= 1e-13 of the objective), and a unit that stops on `tol` (Mult:75-78) keeps clamped factors.
-  // Not for the last iteration (no half-step follows), fixed factors, array weights, nor where the H half-step runs in its resident
-  // form -- those checks keep their objective launch.
+  // Not for the last iteration (no half-step follows), fixed factors, array weights -- those checks keep their objective launch.
   auto defer_parts = [&](const Group &G) {
     if (defer_kind(G) == 3) return tiles_n + 1;  // (what check_a adds: slot 0 = the Gram term, the H half-step's lane tiles, zeros)
     return (defer_kind(G) && wsP[G.phase].clampw) ? defer_geo(hsP[G.phase], wsP[G.phase], defer_kind(G) == 1) : 0;

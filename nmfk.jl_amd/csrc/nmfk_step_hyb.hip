@@ -798,7 +798,9 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
 // OBJ: the monitored objective (Mult:74) of the units instead of a half-step, like the streaming kernel's OBJ mode: gp = the
 // W half-step's arguments, `it` = parity of the H buffer that holds the current H, first product only, one partial per
 // workgroup in ossepart[b] (the entries b >= gridDim.x up to ntile are zeroed: check_a_kernel adds ntile of them).
-template <int KS, int NS, int NT, bool OBJ, bool RAG>  // RAG: D is not a multiple of 64 (a kernel of its own: the masks cost the other 1-2 %)
+// SSE: the half-step also leaves the objective of the factors it reads (the streaming form's SSE mode; one partial per workgroup in
+// ossepart[b], gridDim.x of them per unit)
+template <int KS, int NS, int NT, bool OBJ, bool RAG, bool SSE>  // RAG: D is not a multiple of 64 (a kernel of its own: the masks cost the other 1-2 %)
 __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restrict__ Xt, const NmfkRun *__restrict__ runs,
                                              const NmfkState *__restrict__ state, const NmfkStepArgs *__restrict__ gp, int it, int u0,
                                              double weight, int ntile,
@@ -1063,6 +1065,22 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
             for (int t = 0; t < NT; ++t)
               pn[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, avn[j]), bop[t][j], pn[t], 0, 0, 0);
         }
+        if (SSE) {  // residuals of chunk c (fp32 squares, the chunk's partial into the fp64 sum; anchored: see hyb_step_body)
+          float spart = 0.0f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            float sqs = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float e = xr[ci][t][r] - pc[t][r];
+              if (TAIL && ragged) e = 16 * c + 4 * g + r < D ? e : 0.0f;
+              sqs = __builtin_fmaf(e, e, sqs);
+            }
+            spart += lv[t] ? sqs : 0.0f;
+          }
+          asm volatile("" : "+v"(spart));
+          ssum += (double)spart;
+        }
         f32x4_t q[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -1175,6 +1193,18 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
     return;
   }
   if ((it + 1) % 10 == 0 && __any(low) && lane == 0) atomicOr(&const_cast<NmfkState *>(state)[u].lowflag, 1);
+  if (SSE) {  // the workgroup's partial of the objective, waves in order (den[0..15] is free: the finishes read rden)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ssum += __shfl_down(ssum, o, 64);
+    __syncthreads();
+    if (lane == 0) lds[wave] = ssum;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0;
+      for (int w = 0; w < RW; ++w) t += lds[w];
+      ((double *)(arena + rdp->ossepart))[b] = t * weight * weight;
+    }
+  }
   // ---- sums of the new factor over the workgroup's lane elements -> slot b (fixed order: lanes, then waves)
   double *red = den + 16;  // [RW][16]
 #pragma unroll
@@ -1602,15 +1632,15 @@ __global__ __launch_bounds__(64 * (NW > 8 ? NW : 8), MODE == 1 ? 2 : 4) void hyb
   }
 }
 
-template <int NT, bool OBJ, bool RAG = false>
+template <int NT, bool OBJ, bool RAG = false, bool SSE = false>
 __global__ __launch_bounds__(64 * NMFK_HYB_RW) void hyb_res_kernel(char *arena, const float *__restrict__ Xt, const NmfkRun *__restrict__ runs,
                                                       const NmfkState *__restrict__ state, const NmfkStepArgs *__restrict__ gp,
                                                       int it, int u0, double weight, int ntile) {
   extern __shared__ double lds[];
   switch (runs[u0 + blockIdx.y].hyb) {
-    case 4: hyb_res_body<4, OBJ ? 0 : 1, NT, OBJ, RAG>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
-    case 8: hyb_res_body<8, OBJ ? 0 : 2, NT, OBJ, RAG>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
-    default: hyb_res_body<16, 0, NT, OBJ, RAG>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
+    case 4: hyb_res_body<4, OBJ ? 0 : 1, NT, OBJ, RAG, SSE>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
+    case 8: hyb_res_body<8, OBJ ? 0 : 2, NT, OBJ, RAG, SSE>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
+    default: hyb_res_body<16, 0, NT, OBJ, RAG, SSE>(arena, Xt, runs, state, gp, it, u0, weight, ntile, lds); break;
   }
 }
 
@@ -1654,21 +1684,32 @@ size_t nmfk_hyb_resident_lds(int vmax, int D) {
 }
 
 // half-step of the `cnt` units [u0, u0 + cnt) (any mix of variants; vmax = the widest among them)
-// objw > 0 (streaming form only, see nmfk_hyb_step_parts): the launch also leaves the objective of the factors it reads, scaled
+// objw > 0: the launch also leaves the objective of the factors it reads, scaled
 // by objw^2, as nmfk_hyb_step_parts(a) partials per unit in NmfkRun::ossepart
 void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, int vmax, int u0, int cnt, hipStream_t s, double objw) {
   constexpr int NT = NMFK_HYB_NT, NW = NMFK_HYB_NW;
   if (a.res_wgs > 0) {  // resident form (the host has checked nmfk_hyb_resident_lds)
-    static std::atomic<uint64_t> lds_ok{0}, lds_okr{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
-    if ((a.D & 63) != 0) {
-      nmfk_allow_dynamic_lds((const void *)hyb_res_kernel<NT, false, true>, lds_okr, 160 * 1024);
-      hipLaunchKernelGGL((hyb_res_kernel<NT, false, true>), dim3(a.res_wgs, cnt), dim3(64 * NMFK_HYB_RW), nmfk_hyb_resident_lds(vmax, a.D), s,
-                         a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0, 0);
+    static std::atomic<uint64_t> lds_ok[4] = {{0}, {0}, {0}, {0}};  // (more than 64 KB of dynamic LDS: per kernel and device)
+    const dim3 grid(a.res_wgs, cnt), blk(64 * NMFK_HYB_RW);
+    const size_t ldsb = nmfk_hyb_resident_lds(vmax, a.D);
+#define NMFK_RES_LAUNCH(RAGV, SSEV, W)                                                                          \
+  do {                                                                                                          \
+    nmfk_allow_dynamic_lds((const void *)hyb_res_kernel<NT, false, RAGV, SSEV>, lds_ok[2 * RAGV + SSEV], 160 * 1024); \
+    hipLaunchKernelGGL((hyb_res_kernel<NT, false, RAGV, SSEV>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, W, 0); \
+  } while (0)
+    const bool rag = (a.D & 63) != 0;
+    if (objw > 0) {  // the launch also leaves the objective of the factors it reads: res_wgs partials per unit
+      if (rag)
+        NMFK_RES_LAUNCH(true, true, objw);
+      else
+        NMFK_RES_LAUNCH(false, true, objw);
     } else {
-      nmfk_allow_dynamic_lds((const void *)hyb_res_kernel<NT, false>, lds_ok, 160 * 1024);
-      hipLaunchKernelGGL((hyb_res_kernel<NT, false>), dim3(a.res_wgs, cnt), dim3(64 * NMFK_HYB_RW), nmfk_hyb_resident_lds(vmax, a.D), s,
-                         a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0, 0);
+      if (rag)
+        NMFK_RES_LAUNCH(true, false, 1.0);
+      else
+        NMFK_RES_LAUNCH(false, false, 1.0);
     }
+#undef NMFK_RES_LAUNCH
     return;
   }
   const int ws = a.wsplit, nwaves = ws > 1 ? ws : NW;
@@ -1686,9 +1727,9 @@ void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, 
     hipLaunchKernelGGL((hyb_step_kernel<NT, NW, 0>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
 }
 
-// objective partials per unit a streaming-form launch with these arguments leaves (0: no objective mode for this geometry)
+// objective partials per unit a launch with these arguments leaves in its objective mode
 int nmfk_hyb_step_parts(const NmfkStepArgs &a) {
-  if (a.res_wgs > 0) return 0;
+  if (a.res_wgs > 0) return a.res_wgs;  // (the resident form: a partial per workgroup)
   const int lpw = nmfk_hyb_lane_tile(a.wsplit);
   return (a.L + lpw - 1) / lpw * a.S;
 }

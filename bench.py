@@ -321,7 +321,7 @@ def main():
             # units in one launch per half-step (the kernels switch between their rank variants per workgroup):
             #   H half-step  hyb_step_kernel<2,8,0>   streaming form (loop dimension n = 8192); <2,8,2> behind a check iteration:
             #                the same half-step leaves the monitored objective (deferred check), 1 launch in 10
-            #   W half-step  hyb_res_kernel<2,false,false>      resident form  (loop factor H, 512 rows, in LDS)
+            #   W half-step  hyb_res_kernel<2,false,false,false>      resident form  (loop factor H, 512 rows, in LDS)
             # A launch has the GPU to itself, so its sampled duration (HIP events on the launching stream, every 47th
             # iteration) is exclusive GPU time; rocprofv3 --kernel-trace --stats of the same command gives the same
             # averages (profiles/r03/bench_default_kernel_stats.csv).
@@ -337,7 +337,7 @@ def main():
             whole = {"achieved": tf, "frac": tf / PEAK_FP32_TFLOPS, "mu_loop_gpu_ms": loop["ms"],
                      "note": "algorithmic flops of ALL half-step launches / GPU time of the whole MU loop (HIP events), check blocks included"}
             kernel_of = {"h_step<mfma>": "hyb_step_kernel<2,8,0> (nmfk_step_hyb.hip, streaming form; <2,8,2> = the same with the monitored objective as a by-product behind a check iteration): the H half-step of ALL units of the sweep in one launch",
-                         "w_step<mfma>": "hyb_res_kernel<2,false,false> (nmfk_step_hyb.hip, resident form: the loop factor H in LDS): the W half-step of ALL units of the sweep in one launch"}
+                         "w_step<mfma>": "hyb_res_kernel<2,false,false,false> (nmfk_step_hyb.hip, resident form: the loop factor H in LDS): the W half-step of ALL units of the sweep in one launch"}
             traffic, tsrc = _pmc_traffic()
             if dom in kernel_of:
                 d = prof[dom]

@@ -21,7 +21,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REP
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $SHORT > /dev/null 2> $OUT/pmc_write.err
 cd $REPO
 python3 scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1
-python3 scripts/make_traffic.py $OUT "${TRAFFIC_KERNEL:-hyb_res_kernel<2, false, false>}" $OUT/traffic.json > /dev/null 2>&1
+python3 scripts/make_traffic.py $OUT "${TRAFFIC_KERNEL:-hyb_res_kernel<2, false, false, false>}" $OUT/traffic.json > /dev/null 2>&1
 # keep only the small summaries (gpurun_out merge is capped at 64 MiB)
 find $OUT -name '*.csv' -size +4M -delete
 find $OUT -name '*.db' -delete

@@ -34,7 +34,7 @@ echo "secondary done" >&2
 cd $REPO
 python3 scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1
 python3 scripts/summarize_pmc.py $OUT/sp > $OUT/pmc_summary_sparse.txt 2>&1
-python3 scripts/make_traffic.py $OUT "hyb_res_kernel<2, false, false>" $OUT/traffic.json > /dev/null 2>&1
+python3 scripts/make_traffic.py $OUT "hyb_res_kernel<2, false, false, false>" $OUT/traffic.json > /dev/null 2>&1
 python3 scripts/make_traffic.py $OUT "hyb_step_kernel<2, 8, 0>" $OUT/traffic_h_step.json > /dev/null 2>&1
 python3 scripts/make_traffic.py $OUT/sp "sp_blk_kernel" $OUT/traffic_sp_blk.json > /dev/null 2>&1
 find $OUT -name '*.csv' -size +4M -delete

@@ -287,8 +287,9 @@ int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *
 
 /* Environment variables the library reads (at the start of every sweep; tests and A/B measurements -- the defaults are the
  * product and need none of them):
- *   NMFK_HYB          0 / 1: split-operand MFMA half-step off / on for the ranks >= NMFK_HYB_MINK (default: automatic)
- *   NMFK_HYB_PHASES   0 / 1: the matrix-pipe ranks as ONE launch group that runs first (default: by sweep size)
+ *   NMFK_HYB          0 / 1: split-operand MFMA half-step off / on for the ranks >= NMFK_HYB_MINK (default: on for every rank 2..16 of a
+ *                     dense fp32 sweep without missing data, except a few units of ranks <= 4 only)
+ *   NMFK_HYB_PHASES   0 / 1: the matrix-pipe ranks as ONE launch group that runs first, the other ranks behind it (default: 1)
  *   NMFK_HYB_RES      0: no resident form of that half-step (short loop dimension: the loop factor in LDS)
  *   NMFK_MERGE        g: the ranks <= 16 share g mixed-rank packed-VALU launch groups (default: by restarts per rank)
  *   NMFK_MFMA_WIDE    0: ranks > 16 on the packed-VALU kernel;  NMFK_WIDE2 0: on the all-fp32 MFMA kernel only;
@@ -304,7 +305,7 @@ int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *
  *                     groups of up to f workgroups per CU (default 2)
  *   NMFK_SP_BLK       0: sparse X in the gather form only (no sliced-ELL copies are built); 2: blocked form whatever the size
  *   NMFK_TARGET_WGS   workgroups a half-step launch should have before loop ranges are split (default 2 x CUs)
- *   NMFK_STREAMS      concurrent launch-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1: host / GPU wait times on stderr
+ *   NMFK_STREAMS      concurrent launch-group streams (8; 16 for a dozen launch groups or more; sparse X: 1);  NMFK_HOST_TIMING=1: host / GPU wait times on stderr
  *   NMFK_RCCL_LIB     the RCCL shared object nmfk_comm_* loads (default: librccl.so.1 ...) */
 
 #ifdef __cplusplus

@@ -269,13 +269,15 @@ int nmfk_set_profiling(nmfk_ctx *ctx, int enabled);
  * of the last plan (tier j is planned for ceil(units / 2^j) units), info[7] = units in the work list of the last plan. */
 int nmfk_last_sweep_info(nmfk_ctx *ctx, int32_t info[8]);
 /* The same with `count` <= 16 entries: info[8] = checks (per launch group) whose objective came out of the following H half-step
- * (the deferred check, see NMFK_DEFER_OBJ below), info[9] = checks with an objective launch of their own; the rest 0. */
+ * (the deferred check, see NMFK_DEFER_OBJ below), info[9] = checks with an objective launch of their own, info[10] = cohorts of the
+ * matrix-pipe launch group (its units dealt to that many streams, see NMFK_COHORTS below; 1 = one launch per half-step); the rest 0. */
 int nmfk_last_sweep_info_ex(nmfk_ctx *ctx, int32_t *info, int count);
 /* Test hook, pure host arithmetic (no device): the tiers of the retire-aware schedule for a sweep of `units` units of ranks 2..16
  * (widest kernel variant 4 / 8 / 16) in one launch group on the matrix-pipe kernels, on a GPU of `cus` CUs -- tier j is the launch
  * geometry for ceil(units / 2^j) units; the sweep switches to it when the units still active fit.  Row j of `out` (16 ints per
  * row, <= cap rows): units; then for the H and for the W half-step: workgroups per unit of the resident form (0 = streaming form),
- * wsplit, S, dchunk, fused, table slots, slots a unit writes.  *count = rows written. */
+ * wsplit, S, dchunk, fused, table slots, slots a unit writes; then the cohorts such a group would run as.  *count = rows written.
+ * variant 0: the ranks 2..16 in equal numbers (8 : 4 : 3 units of the variants 16 : 8 : 4, the bench sweep's mix). */
 int nmfk_plan_hyb_tiers(int64_t n, int64_t m, int variant, int units, int cus, int32_t *out, int cap, int *count);
 /* The objective the stop rule monitors -- sum((((X - W*H) .* weight)[.!inan]).^2) every 10th iteration (Mult:73-74) -- as
  * the device computed it, for every check of every restart of the NEXT sweeps (parity tests compare it with the oracle's
@@ -303,6 +305,8 @@ int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *
  *                     <= 1e-13 of its value)
  *   NMFK_WIDE_GROUPS  0: a launch group per rank above 16; f: the ranks of one kernel instantiation (32 / 48 / 64 signals) share launch
  *                     groups of up to f workgroups per CU (default 2)
+ *   NMFK_COHORTS      c: the launch group on the matrix-pipe kernels (ranks 2..16) runs as c cohorts of units, each on its own stream, so
+ *                     that one cohort's half-step fills the CUs another's leaves idle (default: by the group's size; same bits per unit)
  *   NMFK_SP_BLK       0: sparse X in the gather form only (no sliced-ELL copies are built); 2: blocked form whatever the size
  *   NMFK_TARGET_WGS   workgroups a half-step launch should have before loop ranges are split (default 2 x CUs)
  *   NMFK_STREAMS      concurrent launch-group streams (8; 16 for a dozen launch groups or more; sparse X: 1);  NMFK_HOST_TIMING=1: host / GPU wait times on stderr

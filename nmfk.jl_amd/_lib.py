@@ -221,7 +221,8 @@ def shard_owner(nruns, nranks, r):
 
 def plan_hyb_tiers(n, m, variant, units, cus=256):
     """nmfk_plan_hyb_tiers (host arithmetic, no device) -> one dict per tier of the retire-aware schedule: units and, for the
-    H and the W half-step, {res, wsplit, S, dchunk, fused, slots, ns}."""
+    H and the W half-step, {res, wsplit, S, dchunk, fused, slots, ns}; cohorts.  variant 4 / 8 / 16: units of that kernel variant only;
+    0: the ranks 2..16 in equal numbers (the bench sweep's mix)."""
     cap = 40
     out = (C.c_int32 * (16 * cap))()
     cnt = C.c_int()
@@ -230,7 +231,7 @@ def plan_hyb_tiers(n, m, variant, units, cus=256):
     rows = []
     for j in range(cnt.value):
         o = out[16 * j:16 * j + 16]
-        rows.append({"units": o[0], "H": dict(zip(names, o[1:8])), "W": dict(zip(names, o[8:15]))})
+        rows.append({"units": o[0], "H": dict(zip(names, o[1:8])), "W": dict(zip(names, o[8:15])), "cohorts": o[15]})
     return rows
 
 
@@ -544,7 +545,7 @@ class Context:
         _check(lib().nmfk_last_sweep_info_ex(self._h, info, 16))
         return dict(phases=info[0], mfma_group_units=info[1], merged_valu_groups=info[2], launch_groups=info[3],
                     wide_mfma_units=info[4], replans=info[5], last_tier=info[6], units_in_last_plan=info[7],
-                    deferred_checks=info[8], plain_checks=info[9])
+                    deferred_checks=info[8], plain_checks=info[9], cohorts=info[10])
 
     def set_objective_trace(self, on=True):
         """nmfk_set_objective_trace: record the monitored objective (Mult:74) at every check of the next sweeps."""

@@ -64,6 +64,7 @@ int ensure_pinned(nmfk_ctx *ctx, size_t bytes) {
 struct Sample {
   int kind, group, it;
   size_t e0, e1;
+  int u0 = 0, cnt = 0, epoch = 0;  // the launch's units as positions of the work list of re-plan `epoch`
 };
 struct Sampler {
   nmfk_ctx *ctx;
@@ -90,11 +91,11 @@ struct Sampler {
     if (on) (void)hipEventRecord(ctx->events[e], s);
     return e;
   }
-  void end(size_t e0, int kind, int group, int it, hipStream_t s) {
+  void end(size_t e0, int kind, int group, int it, hipStream_t s, int u0, int cnt, int epoch) {
     const size_t e1 = event();
     if (!on) return;
     (void)hipEventRecord(ctx->events[e1], s);
-    samples.push_back({kind, group, it, e0, e1});
+    samples.push_back({kind, group, it, e0, e1, u0, cnt, epoch});
   }
 };
 
@@ -114,10 +115,12 @@ struct Sampler {
 //   NMFK_CLAMP_ALWAYS 1: the clamp pass of every check block looks at every unit (default: only where a fused finish wrote a value below eps())
 //   NMFK_SP_BLK       0: sparse X in the gather form only (also: no sliced-ELL copies are built); 2: blocked form whatever the size
 //   NMFK_STREAMS      concurrent rank-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1 prints the host's share of the loop
+//   NMFK_COHORTS      c: the matrix-pipe launch group runs as c cohorts of units on c streams (default: by the group's size)
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, merge = -1, phases = -1;
   int wide_sse = 1, streams = -1, host_timing = 0;
-  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1, wide_groups = 2;
+  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1, wide_groups = 2, cohorts = -1, legacy_geo = 0;
+  int exp_geo[2][3] = {{-1, -1, -1}, {-1, -1, -1}};  // NMFK_EXP_GEO="hws,hS,hres,wws,wS,wres": forced geometry of the matrix-pipe group (experiments)
   // (not knobs any more -- round 3's A/B switches with their measured settings: one mixed-rank matrix-pipe group, the waves of
   //  a workgroup may split a loop range 8 ways, the small ranks on their own kernel variants, four pairs of lane tiles per
   //  wave of the resident form, merged sweeps side by side)
@@ -146,6 +149,10 @@ Tuning read_tuning() {
   geti("NMFK_CLAMP_ALWAYS", t.clamp_always);
   geti("NMFK_DEFER_OBJ", t.defer_obj);
   geti("NMFK_WIDE_GROUPS", t.wide_groups);
+  geti("NMFK_COHORTS", t.cohorts);
+  if (const char *e = getenv("NMFK_EXP_GEO")) sscanf(e, "%d,%d,%d,%d,%d,%d", &t.exp_geo[0][0], &t.exp_geo[0][1], &t.exp_geo[0][2], &t.exp_geo[1][0], &t.exp_geo[1][1], &t.exp_geo[1][2]);
+  geti("NMFK_EXP_LEGACY_GEO", t.legacy_geo);
+  if (t.cohorts >= 0) t.cohorts = std::max(1, std::min(8, t.cohorts));
   return t;
 }
 
@@ -645,6 +652,158 @@ namespace {
 // wins below (15 units: 0.111 against 0.116, one unit: 0.064 against 0.071): 0.7 per CU.
 static int hyb_target_ws(int cus) { return 7 * cus / 10; }
 
+// ---- Launch geometry of a matrix-pipe launch group (ranks 2..16, dense fp32), round 5: a cost model instead of thresholds.
+// Rounds 2-4 chose the geometry by rules of thumb found at one or two sizes (workgroups per CU below which the waves of a workgroup
+// take loop ranges of their own, "fill the chip four times", "at least two pairs per wave") -- right at 480 and 240 units of the
+// bench shape, up to 45 % off below (profiles/r05/geometry_scan.txt: 60 units 0.232 -> 0.191 ms per iteration with the best geometry
+// by exhaustive scan, 15 units 0.110 -> 0.074, one unit of k = 8 81 -> 45 us).  What the scan showed is what a GPU launch is: a list of
+// workgroups handed, in grid order, to whichever CU slot is free -- so the time of a candidate geometry is the makespan of that list
+// schedule, and it can be computed on the host: workgroup time = a fixed part + chunks of 16 loop steps x the time per chunk of the
+// unit's kernel variant (k <= 4 / <= 8 / <= 16: 0.39 / 0.57 / 0.75 us per chunk and workgroup on a full CU), units in list order (widest
+// ranks first).  The constants are a least-squares fit to 58 measured launches of 30..480 units (tools/planner/fit_model.py: rms error
+// 5-6 % of a launch's duration; profiles/r05/planner_fit.txt).  Candidates: the streaming form with shared staging and the loop range split
+// S ways over workgroups (S > 1: + reduce_kernel), the same with per-wave loop ranges (wsplit), and -- where the loop factor fits the
+// LDS -- the resident form with g workgroups per unit.  The cheapest wins; ties go to fewer workgroups.
+struct HybMix {
+  int n16 = 0, n8 = 0, n4 = 0;  // units per kernel variant; list order: 16, 8, 4 (ranks descending)
+  int units() const { return n16 + n8 + n4; }
+  int variant_of(int u) const { return u < n16 ? 16 : u < n16 + n8 ? 8 : 4; }
+  int vmax() const { return n16 ? 16 : n8 ? 8 : 4; }
+  HybMix scaled(int c) const {  // the same mix for c units (later tiers of the retire-aware schedule); the widest variant stays in:
+    const int tot = std::max(1, units());  // the launches' LDS is sized for it whatever is left of the list
+    HybMix r;
+    r.n16 = n16 ? std::max(1, (int)(((int64_t)n16 * c + tot / 2) / tot)) : 0;
+    r.n16 = std::min(r.n16, c);
+    r.n8 = n8 ? std::min(c - r.n16, std::max((n16 || c - r.n16 == 0) ? 0 : 1, (int)(((int64_t)n8 * c + tot / 2) / tot))) : 0;
+    r.n4 = c - r.n16 - r.n8;
+    if (n4 == 0 && r.n4 > 0) (n8 ? r.n8 : r.n16) += r.n4, r.n4 = 0;
+    return r;
+  }
+};
+static double hyb_chunk_us(int variant) { return 0.75 * (variant <= 4 ? 0.52 : variant <= 8 ? 0.76 : 1.0); }  // per chunk of 16 loop steps and workgroup, full CU
+// makespan of a launch: workgroups in grid order (wpu per unit, unit u's take t[u] us) onto `slots` slots; also the busy fraction
+static double list_makespan(const std::vector<double> &t, int wpu, int slots, double *busy_frac) {
+  const int64_t total = (int64_t)t.size() * wpu;
+  double sum = 0, tmax = 0;
+  for (double x : t) sum += x * wpu, tmax = std::max(tmax, x);
+  double ms;
+  if (total <= slots) {
+    ms = tmax;
+  } else if (total > 60000) {  // (too many to walk: the bound of list scheduling)
+    ms = sum / slots + tmax * (1.0 - 1.0 / slots);
+  } else {
+    std::vector<double> heap((size_t)slots, 0.0);  // min-heap of the slots' free times
+    auto cmp = [](double a, double b) { return a > b; };
+    for (size_t u = 0; u < t.size(); ++u)
+      for (int w = 0; w < wpu; ++w) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        heap.back() += t[u];
+        std::push_heap(heap.begin(), heap.end(), cmp);
+      }
+    ms = *std::max_element(heap.begin(), heap.end());
+  }
+  if (busy_frac) *busy_frac = ms > 0 ? sum / (ms * slots) : 1.0;
+  return ms;
+}
+// The same for workgroups that SHARE a CU (the streaming kernels: up to `wpc` workgroups of 16 / wpc waves per CU): a workgroup runs
+// faster the fewer neighbours it has -- two of eight waves side by side take 0.84 us per chunk each, one alone 0.45 (CU throughput
+// 1 : 0.935) -- so the tail of a launch is shorter than fixed slot times make it.  Event simulation per CU: resident workgroups
+// progress at rate(residents), a finished one is replaced by the next of the list.  t[u]: us of unit u's workgroups on a FULL CU.
+static double cu_share_makespan(const std::vector<double> &t, int wpu, int cus, int wpc, double *busy_frac) {
+  const int64_t total = (int64_t)t.size() * wpu;
+  double sum = 0, tmax = 0;
+  for (double x : t) sum += x * wpu, tmax = std::max(tmax, x);
+  auto rate = [&](int residents) { return 1.0 / (0.2 + 0.8 * (double)residents / wpc); };  // per workgroup, 1 = full CU
+  double ms;
+  if (total > 60000) {
+    ms = sum / ((double)cus * wpc) + tmax * (1.0 - 1.0 / ((double)cus * wpc));
+  } else {
+    struct Cu {
+      double rem[4];
+      int nres;
+      double last;
+    };
+    std::vector<Cu> cu((size_t)cus, Cu{{0, 0, 0, 0}, 0, 0.0});
+    size_t next_u = 0;
+    int next_w = 0;
+    auto take = [&](double &work) {
+      if (next_u >= t.size()) return false;
+      work = t[next_u];
+      if (++next_w == wpu) next_w = 0, ++next_u;
+      return true;
+    };
+    // the dispatcher fills the CUs breadth first: one workgroup each, then the second slots, ...
+    for (int slot = 0; slot < wpc; ++slot)
+      for (int c = 0; c < cus; ++c) {
+        double w;
+        if (!take(w)) break;
+        cu[(size_t)c].rem[cu[(size_t)c].nres++] = w;
+      }
+    typedef std::pair<double, int> Ev;  // (time of the CU's next completion, CU)
+    std::vector<Ev> heap;
+    auto cmp = [](const Ev &a, const Ev &b) { return a.first > b.first; };
+    auto next_done = [&](const Cu &q) {
+      double mn = 1e300;
+      for (int i = 0; i < q.nres; ++i) mn = std::min(mn, q.rem[i]);
+      return q.last + mn / rate(q.nres);
+    };
+    for (int c = 0; c < cus; ++c)
+      if (cu[(size_t)c].nres) heap.push_back({next_done(cu[(size_t)c]), c});
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    ms = 0;
+    while (!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end(), cmp);
+      const Ev e = heap.back();
+      heap.pop_back();
+      Cu &q = cu[(size_t)e.second];
+      const double done = (e.first - q.last) * rate(q.nres);
+      int keep = 0;
+      for (int i = 0; i < q.nres; ++i) {
+        const double r = q.rem[i] - done;
+        if (r > 1e-9) q.rem[keep++] = r;
+      }
+      q.nres = keep;
+      q.last = e.first;
+      ms = std::max(ms, e.first);
+      double w;
+      while (q.nres < wpc && take(w)) q.rem[q.nres++] = w;
+      if (q.nres) {
+        heap.push_back({next_done(q), e.second});
+        std::push_heap(heap.begin(), heap.end(), cmp);
+      }
+    }
+  }
+  if (busy_frac) *busy_frac = ms > 0 ? sum / (ms * cus * wpc) : 1.0;
+  return ms;
+}
+// streaming form: lanes L, loop D, wsplit ws (1: the eight waves of a workgroup share staged blocks and 256 lanes; > 1: they share 32
+// lanes and split the workgroup's loop range), S splits of the loop range over workgroups.  us per launch (+ reduce_kernel)
+static double hyb_stream_cost(const HybMix &mix, int L, int D, int cus, int ws, int S, double *busy) {
+  const int lt = nmfk_hyb_lane_tile(ws), ntile = (L + lt - 1) / lt;
+  int dchunk = (D + S - 1) / S;
+  if (S > 1) dchunk = (dchunk + 15) & ~15;
+  const int nch = ws > 1 ? ((((dchunk + ws - 1) / ws) + 15) >> 4) : ((dchunk + 15) >> 4);
+  const int wpc = ws == 4 ? 4 : 2;  // workgroups per CU (16 waves of 128 registers)
+  const double perwave = ws > 1 ? 1.3 : 1.0;  // per-wave staging (60 units, wsplit 8: 125 us)
+  std::vector<double> t((size_t)mix.units());
+  for (int u = 0; u < mix.units(); ++u) t[(size_t)u] = 6.0 + nch * hyb_chunk_us(mix.variant_of(u)) * perwave;
+  double c = 5.0 + cu_share_makespan(t, ntile * S, cus, wpc, busy);
+  if (S > 1) c += 5.0 + (double)mix.units() * (S + 2) * L * 10.0 * 4.0 / 3.0e6;  // reduce_kernel: a launch + the partials (9 us at 60 units, S = 8)
+  return c;
+}
+// resident form: g workgroups (16 waves, one per CU) per unit stage the loop factor and walk ceil(pairs / (16 g)) pairs of lane tiles
+// per wave (30 units at 8192 x 512, g = 4 / 6 / 8: 114 / 89 / 65 us: 11 us of staging + 24 us per pair of 32 chunks at k = 16)
+static double hyb_res_cost(const HybMix &mix, int L, int D, int cus, int g, double *busy) {
+  const int ntp = (L + 31) / 32, rw = nmfk_hyb_resident_waves(), nch = ((D + 63) & ~63) >> 4;
+  const int pairs = (ntp + rw * g - 1) / (rw * g);
+  std::vector<double> t((size_t)mix.units());
+  for (int u = 0; u < mix.units(); ++u) {
+    const int v = mix.variant_of(u);
+    t[(size_t)u] = 2.0 + 9.0 * (D / 512.0) * (v / 16.0) + pairs * nch * hyb_chunk_us(v) * 0.987;
+  }
+  return 5.0 + list_makespan(t, g, cus, busy);
+}
+
 struct HybPlan {
   int units;
   int res[2];     // workgroups per unit of the resident form (0: streaming form)
@@ -653,72 +812,156 @@ struct HybPlan {
   int dchunk[2], fused[2];
   int slots[2];   // sum-table slots the half-step's helper kernels cover
   int ns[2];      // sum-table slots a unit's own kernels write
+  double us[2], busy[2];  // the model's time of a launch and the fraction of the CU slots it keeps busy
 };
-HybPlan plan_hyb_group(int n, int m, int cus, int vmax, int units, int target_wgs, bool hyb_res) {
+// rounds 3-4's resident-form rule (NMFK_EXP_LEGACY_GEO=1, A/B measurements)
+static int hyb_res_wgs_legacy(int L, int D, int cus, int vmax, int units) {
+  if (units <= 0 || nmfk_hyb_resident_lds(vmax, D) == 0) return 0;
+  const int ntp = (L + 31) / 32, rw = nmfk_hyb_resident_waves(), res_tpw = Tuning::hyb_res_tpw;
+  const int fill = (4 * cus + units - 1) / units;
+  const int gmax = std::max(1, ntp / (2 * rw)), gmin = std::min(gmax, std::max(std::max(1, ntp / (rw * res_tpw)), fill));
+  int best = gmin;
+  double waste = 1e30;
+  for (int gq = gmin; gq <= gmax; ++gq) {
+    const int rounds = (ntp + rw * gq - 1) / (rw * gq);
+    const double wq = (double)rounds * rw * gq / ntp;
+    if (wq < waste - 1e-9) {
+      waste = wq;
+      best = gq;
+    }
+  }
+  return best;
+}
+// [0] = H half-step (lanes = m columns, loop = n rows), [1] = W half-step
+HybPlan plan_hyb_group(int n, int m, int cus, const HybMix &mix, int target_wgs, bool hyb_res, bool legacy = false,
+                       const int (*exp_geo)[3] = nullptr) {
   HybPlan p;
+  const int units = std::max(1, mix.units()), vmax = mix.vmax();
   p.units = units;
   const int target = target_wgs > 0 ? target_wgs : 2 * cus;
   const int target_ws = target_wgs > 0 ? target : hyb_target_ws(cus);
-  const int res_tpw = Tuning::hyb_res_tpw, max_ws = Tuning::max_wsplit;
+  const int max_ws = Tuning::max_wsplit;
+  const char *dbge = getenv("NMFK_DEBUG");
+  const bool dbg = dbge && atoi(dbge) >= 2;
   for (int which = 0; which < 2; ++which) {
     const int L = which == 0 ? m : n, D = which == 0 ? n : m;
-    p.res[which] = 0;
-    if (hyb_res && units > 0 && nmfk_hyb_resident_lds(vmax, D) != 0) {
-      const int ntp = (L + 31) / 32, rw = nmfk_hyb_resident_waves();
-      const int fill = (4 * cus + units - 1) / units;
-      const int gmax = std::max(1, ntp / (2 * rw)), gmin = std::min(gmax, std::max(std::max(1, ntp / (rw * res_tpw)), fill));
-      int best = gmin;
-      double waste = 1e30;
-      for (int gq = gmin; gq <= gmax; ++gq) {
-        const int rounds = (ntp + rw * gq - 1) / (rw * gq);
-        const double wq = (double)rounds * rw * gq / ntp;
-        if (wq < waste - 1e-9) {
-          waste = wq;
-          best = gq;
+    const int wsN = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
+    p.us[which] = 0, p.busy[which] = 1;
+    int res = 0, ws = 1, S = 1;
+    if (legacy || target_wgs > 0) {  // (NMFK_TARGET_WGS keeps the threshold rule: tests force split geometries with it)
+      res = hyb_res ? hyb_res_wgs_legacy(L, D, cus, vmax, units) : 0;
+      auto tiles = [&](int w) { return res > 0 ? res : (L + nmfk_hyb_lane_tile(w) - 1) / nmfk_hyb_lane_tile(w); };
+      if ((int64_t)tiles(1) * units < target_ws) ws = wsN;
+      const int64_t have = std::max<int64_t>((int64_t)tiles(ws) * units, 1);
+      S = (int)((target + have - 1) / have);
+    } else {
+      double best = 1e30;
+      const bool can_res = hyb_res && nmfk_hyb_resident_lds(vmax, D) != 0;
+      if (can_res) {  // (where the loop factor fits the LDS the resident form is the better kernel at every size measured)
+        const int ntp = (L + 31) / 32, rw = nmfk_hyb_resident_waves(), gmax = std::max(1, ntp / rw);
+        for (int g = std::max(1, ntp / (rw * Tuning::hyb_res_tpw)); g <= gmax; ++g) {
+          double b;
+          const double c = hyb_res_cost(mix, L, D, cus, g, &b);
+          if (dbg) fprintf(stderr, "[nmfk]   %c half-step, %d units: resident g %d: %.1f us (busy %.2f)\n", "HW"[which], units, g, c, b);
+          if (c < best * 0.97) best = c, res = g, p.busy[which] = b;
         }
+      } else {
+        static const int Ss[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32, 48, 64};
+        for (int w : {1, wsN})
+          for (int Sq : Ss) {
+            if (Sq > std::max(1, D / (64 * w))) break;
+            double b;
+            const double c = hyb_stream_cost(mix, L, D, cus, w, Sq, &b);
+            if (dbg) fprintf(stderr, "[nmfk]   %c half-step, %d units: streaming wsplit %d S %d: %.1f us (busy %.2f)\n", "HW"[which], units, w, Sq, c, b);
+            if (c < best * 0.97) best = c, ws = w, S = Sq, p.busy[which] = b;
+          }
       }
-      p.res[which] = best;
+      p.us[which] = best;
     }
-    auto tiles = [&](int ws) { return p.res[which] > 0 ? p.res[which] : (L + nmfk_hyb_lane_tile(ws) - 1) / nmfk_hyb_lane_tile(ws); };
-    auto wgs = [&](int ws) { return std::max<int64_t>((int64_t)tiles(ws) * units, 1); };
-    p.wsplit[which] = 1;
-    if (wgs(1) < target_ws) p.wsplit[which] = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
-    const int64_t have = wgs(p.wsplit[which]);
-    const int S0 = (int)((target + have - 1) / have);
-    const int maxS = std::max(1, D / (64 * p.wsplit[which]));
-    p.S[which] = std::max(1, std::min(S0, maxS));
+    if (exp_geo && exp_geo[which][2] >= 0 && nmfk_hyb_resident_lds(vmax, D) != 0) res = exp_geo[which][2];
+    if (exp_geo && exp_geo[which][0] > 0) ws = exp_geo[which][0];
+    if (exp_geo && exp_geo[which][1] > 0) S = exp_geo[which][1];
+    p.res[which] = res;
+    p.wsplit[which] = ws;
+    auto tiles = [&](int w) { return p.res[which] > 0 ? p.res[which] : (L + nmfk_hyb_lane_tile(w) - 1) / nmfk_hyb_lane_tile(w); };
+    const int maxS = std::max(1, D / (64 * ws));
+    p.S[which] = std::max(1, std::min(S, maxS));
     p.dchunk[which] = (D + p.S[which] - 1) / p.S[which];
     if (p.S[which] > 1) {
       p.dchunk[which] = (p.dchunk[which] + 15) & ~15;
       p.S[which] = (D + p.dchunk[which] - 1) / p.dchunk[which];
     }
     p.fused[which] = p.S[which] == 1;
-    p.slots[which] = tiles(p.wsplit[which]);
+    p.slots[which] = tiles(ws);
     if (!p.fused[which]) p.slots[which] = std::max(p.slots[which], std::min(64, (L + 31) / 32));
-    p.ns[which] = (p.fused[which] || p.res[which] > 0) ? tiles(p.wsplit[which]) : p.slots[which];
+    p.ns[which] = (p.fused[which] || p.res[which] > 0) ? tiles(ws) : p.slots[which];
   }
   return p;
+}
+// Cohorts of a matrix-pipe launch group (nmfk_mu_sweep, "Cohorts"; NMFK_COHORTS overrides): two when the plan's launches leave CU slots
+// idle (tails, rounds of unequal workgroups), which a second stream of launches fills.  One
+//  * when a launch fills the chip for many rounds anyway: two kernels side by side then only fragment the CUs (65536 x 256 at 240 units:
+//    + 5 %, at 480: + 12 %);
+//  * when the launches are short -- below ~80 us per iteration the launch count is what costs (300 x 300: + 4 %, 2048 x 2048,
+//    k = 16 x 10: + 14 %, 8192 x 512, k = 16 x 10: 71 -> 80 us);
+//  * when a streaming launch has no more workgroups than CUs: each then has a CU to itself, at 1.87x the speed of two side by side,
+//    and the workgroups of two such launches from two queues land on the SAME CUs (2048 x 2048, k = 2:16 x 2: + 20 %).
+static int nmfk_default_cohorts(const HybPlan &p, int64_t n, int64_t m, int cus) {
+  if (p.units < 4 || n * m < 100000 || p.us[0] + p.us[1] < 80.0) return 1;
+  const double busy = (p.busy[0] * p.us[0] + p.busy[1] * p.us[1]) / (p.us[0] + p.us[1]);
+  for (int w = 0; w < 2; ++w)
+    if (p.res[w] == 0 && (int64_t)p.ns[w] * p.S[w] * p.units < 3 * cus / 2) return 1;
+  return busy < 0.9 ? 2 : 1;
+}
+// The plan of a group WITH its cohorts: the group as one launch decides the cohorts; with c > 1 a launch holds units / c of them, so the
+// geometry is the plan of such a launch (finer: 60 units as two cohorts run the plan of 30 -- S = 8, eight resident workgroups per
+// unit -- which the exhaustive scan found best for them: 0.2317 -> 0.1905 ms per iteration, profiles/r05/geometry_scan.txt).
+struct HybCohortPlan {
+  HybPlan plan;
+  int cohorts;
+};
+static HybCohortPlan plan_hyb_cohorts(int n, int m, int cus, const HybMix &mix, const Tuning &T, bool hyb_res) {
+  HybCohortPlan r;
+  r.plan = plan_hyb_group(n, m, cus, mix, T.target_wgs, hyb_res, T.legacy_geo != 0, T.exp_geo);
+  const bool model = !(T.legacy_geo || T.target_wgs > 0);
+  r.cohorts = T.cohorts > 0 ? T.cohorts : model ? nmfk_default_cohorts(r.plan, n, m, cus) : 1;
+  r.cohorts = std::max(1, std::min(r.cohorts, mix.units()));
+  if (r.cohorts > 1 && model) {
+    const int units = mix.units();
+    r.plan = plan_hyb_group(n, m, cus, mix.scaled((units + r.cohorts - 1) / r.cohorts), T.target_wgs, hyb_res, false, T.exp_geo);
+    r.plan.units = units;
+  }
+  return r;
 }
 }  // namespace
 
 // Test hook (no device needed): the tiers nmfk_mu_sweep plans for a sweep of `units` units whose ranks (all in 2..16, widest kernel
 // variant `variant` = 4 / 8 / 16) run in one launch group on the matrix-pipe kernels: tier j for ceil(units / 2^j) units.  Row j of
 // `out` (16 ints per row, at most `cap` rows): units, then for the H and the W half-step: res, wsplit, S, dchunk, fused, slots, ns;
-// out[15] = 0.  *count = tiers.  The retire-aware schedule switches to tier j when the units still active are <= its `units`.
+// out[15] = cohorts the group would run as with that many units (nmfk_mu_sweep, "Cohorts").  *count = tiers.  The retire-aware schedule switches to tier j when the units still active are <= its `units`.
 NMFK_EXPORT int nmfk_plan_hyb_tiers(int64_t n, int64_t m, int variant, int units, int cus, int32_t *out, int cap, int *count) {
   if (!out || !count || cap < 1 || n < 16 || m < 16 || units < 1 || cus < 1) return fail(NMFK_ERR_BAD_ARG, "bad argument");
   const Tuning T = read_tuning();
   int rows = 0;
   for (int c = units;; c = (c + 1) / 2) {
     if (rows >= cap) break;
-    const HybPlan p = plan_hyb_group((int)n, (int)m, cus, variant, c, T.target_wgs, T.hyb_res != 0);
+    HybMix mix;
+    if (variant == 0) {  // the ranks 2..16 in equal numbers (the bench sweep): 8 : 4 : 3 of the variants 16 : 8 : 4
+      HybMix all;
+      all.n16 = 8, all.n8 = 4, all.n4 = 3;
+      mix = all.scaled(c);
+    } else {
+      (variant <= 4 ? mix.n4 : variant <= 8 ? mix.n8 : mix.n16) = c;
+    }
+    const HybCohortPlan cp = plan_hyb_cohorts((int)n, (int)m, cus, mix, T, T.hyb_res != 0);
+    const HybPlan &p = cp.plan;
     int32_t *o = out + 16 * rows++;
     o[0] = p.units;
     for (int w = 0; w < 2; ++w) {
       int32_t *q = o + 1 + 7 * w;
       q[0] = p.res[w], q[1] = p.wsplit[w], q[2] = p.S[w], q[3] = p.dchunk[w], q[4] = p.fused[w], q[5] = p.slots[w], q[6] = p.ns[w];
     }
-    o[15] = 0;
+    o[15] = cp.cohorts;
     if (c == 1) break;
   }
   *count = rows;
@@ -732,13 +975,15 @@ namespace {
 // consumers add the slots -- sum = ((s0 + s1) + ...) + 0 + ... is then bit for bit what it was.  One wave per unit.
 __global__ __launch_bounds__(64) void replan_kernel(char *arena, const NmfkRun *runs_old, const NmfkState *state_old,
                                                     NmfkRun *runs_new, NmfkState *state_new, const int32_t *perm, int nsW,
-                                                    int nsH, int PW, int PH, int PWz, int PHz) {  // PW / PH: slots in use so far; PWz / PHz: slots to leave defined
+                                                    int nsH, int PW, int PH, int PWz, int PHz,  // PW / PH: slots in use so far; PWz / PHz: slots to leave defined
+                                                    int64_t opart0, int64_t opart_stride, int live) {  // partial-numerator buffer of position p < live (idle between half-steps)
   const int p = blockIdx.x, q = perm[p], t = threadIdx.x;
   NmfkRun rd = runs_old[q];
   if (t == 0) {
     state_new[p] = state_old[q];
     rd.nsW = nsW;
     rd.nsH = nsH;
+    rd.opart = opart0 + (int64_t)(p < live ? p : 0) * opart_stride;  // (a stopped unit's kernels never run again)
     runs_new[p] = rd;
   }
   const int kp = rd.kp;
@@ -893,40 +1138,23 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // Resident form of the split-operand MFMA half-step (nmfk_step_hyb.hip, hyb_res_kernel): when the loop dimension is
   // short enough for the whole loop factor to sit in LDS (the W half-step of a tall X), the units of the matrix-pipe
   // groups run it with res_wgs[which] workgroups of 16 waves per unit, each wave walking several pairs of lane tiles.
-  auto plan_res = [&](int hyb_units, int (&res)[2]) {
-    res[0] = res[1] = 0;
-    if (!(hyb_on && T.hyb_res)) return;
-    for (int which = 0; which < 2 && hyb_units > 0; ++which) {
-      const int L = which == 0 ? m : n, D = which == 0 ? n : m;
-      if (nmfk_hyb_resident_lds(hyb_vmax, D) == 0) continue;
-      const int ntp = (L + 31) / 32;                                     // pairs of 16-lane tiles
-      const int fill = (4 * cus + hyb_units - 1) / hyb_units;            // workgroups per unit that fill the chip a few times
-      const int rw = nmfk_hyb_resident_waves();
-      // between "a few pairs per wave" / "enough workgroups to fill the chip" and "one pair per wave": the count that
-      // leaves the fewest wave slots without a pair in the last round (240 units: 8 workgroups x 2 pairs per wave, not
-      // 5 x 3.2 -- a fifth of the waves would walk a fourth pair while the others wait)
-      // (at least two pairs per wave: with one, a workgroup stages the whole factor for a single pair per wave and the form
-      //  loses against the streaming kernel -- 120 units: W half-step 0.237 vs 0.218 ms)
-      const int gmax = std::max(1, ntp / (2 * rw)), gmin = std::min(gmax, std::max(std::max(1, ntp / (rw * T.hyb_res_tpw)), fill));
-      int best = gmin;
-      double waste = 1e30;
-      for (int gq = gmin; gq <= gmax; ++gq) {
-        const int rounds = (ntp + rw * gq - 1) / (rw * gq);
-        const double wq = (double)rounds * rw * gq / ntp;
-        if (wq < waste - 1e-9) {
-          waste = wq;
-          best = gq;
-        }
-      }
-      res[which] = best;
+  HybMix hyb_mix;  // the units on the matrix-pipe kernels, by kernel variant
+  for (int q = 0; q < nk; ++q)
+    if (use_hyb_k(ks[q])) {
+      const int v = hyb_variant_of(ks[q]);
+      (v <= 4 ? hyb_mix.n4 : v <= 8 ? hyb_mix.n8 : hyb_mix.n16) += nruns;
     }
-  };
+  // their launch geometry (plan_hyb_group: the cost model) -- the resident form's workgroups per unit, wsplit, S of both half-steps
+  const HybCohortPlan hyb_cplan0 = plan_hyb_cohorts(n, m, cus, hyb_mix, T, hyb_on && T.hyb_res);
+  const HybPlan &hyb_plan0 = hyb_cplan0.plan;
+  int hyb_ranks = 0;
+  for (int q = 0; q < nk; ++q) hyb_ranks += use_hyb_k(ks[q]) ? 1 : 0;
+  if (getenv("NMFK_DEBUG") && hyb_mix.units() > 0)
+    fprintf(stderr, "[nmfk] plan of %d matrix-pipe units (%d / %d / %d of variant 16 / 8 / 4) at %d x %d: H res %d wsplit %d S %d (model %.1f us, busy %.2f) | W res %d wsplit %d S %d (%.1f us, %.2f) | cohorts %d\n",
+            hyb_mix.units(), hyb_mix.n16, hyb_mix.n8, hyb_mix.n4, n, m, hyb_plan0.res[0], hyb_plan0.wsplit[0], hyb_plan0.S[0], hyb_plan0.us[0], hyb_plan0.busy[0],
+            hyb_plan0.res[1], hyb_plan0.wsplit[1], hyb_plan0.S[1], hyb_plan0.us[1], hyb_plan0.busy[1], hyb_cplan0.cohorts);
   int res_wgs[2] = {0, 0};  // [0] H half-step (L = m, D = n), [1] W half-step (L = n, D = m)
-  {
-    int hyb_units = 0;
-    for (int q = 0; q < nk; ++q) hyb_units += use_hyb_k(ks[q]) ? nruns : 0;
-    plan_res(hyb_units, res_wgs);
-  }
+  if (hyb_mix.units() > 0) res_wgs[0] = hyb_plan0.res[0], res_wgs[1] = hyb_plan0.res[1];
   // workgroups (= lane tiles = sum-table slots) of one unit of rank k in the half-step `which`
   auto tiles_of_res = [&](int k, int which, int L, int ws, const int (&res)[2]) {
     if (use_hyb_k(k) && res[which] > 0) return res[which];
@@ -945,6 +1173,18 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // retire-aware schedule plan a sweep that has shrunk), with `res` the resident-form plan of that sweep
   auto geometry_for = [&](int L, int D, int phase, int which, const int (&res)[2], double units_of_rank) {
     Geo g;
+    {  // a phase that holds the matrix-pipe units and nothing else (the default schedule's phase 0): their plan
+      int ranks_in = 0, hyb_in = 0;
+      for (int q = 0; q < nk; ++q)
+        if (phase_of_k(ks[q]) == phase) {
+          ++ranks_in;
+          hyb_in += use_hyb_k(ks[q]) ? 1 : 0;
+        }
+      if (ranks_in > 0 && hyb_in == ranks_in && hyb_in == hyb_ranks && units_of_rank < 0 && hyb_plan0.res[which] == res[which]) {
+        const HybPlan &p = hyb_plan0;
+        return Geo{p.wsplit[which], p.S[which], p.dchunk[which], p.fused[which], p.slots[which]};
+      }
+    }
     const double per_rank = units_of_rank >= 0 ? units_of_rank : (double)nruns;
     auto wgs = [&](int ws) {  // workgroups of one half-step over all units of the phase
       double t = 0;
@@ -1024,6 +1264,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     int res[2];
     int nsH, nsW;  // slots a unit's kernels write under the tier (NmfkRun::nsH / nsW)
     int PH, PW;    // slots the tier's helper kernels (reduce, clamp) cover: written or zeroed
+    int ncoh;      // cohorts the tier's units run as
   };
   std::vector<Tier> tiers;
   {
@@ -1031,19 +1272,25 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     for (int q = 0; q < nk; ++q) all_hyb = all_hyb && use_hyb_k(ks[q]) && ks[q] <= NMFK_MULTI_MAXK;
     const bool one_group = all_hyb && !ctx->sparse && !f64 && (merge > 0 || hyb_phases) && hyb_groups == 1;
     if (T.replan && one_group && (nunits >= 32 || T.replan >= 2)) {
-      tiers.push_back({nunits, ghp[0], gwp[0], {res_wgs[0], res_wgs[1]}, 0, 0, 0, 0});
+      tiers.push_back({nunits, ghp[0], gwp[0], {res_wgs[0], res_wgs[1]}, 0, 0, 0, 0, hyb_cplan0.cohorts});
       {  // the standalone rule (plan_hyb_group: what the later tiers and the CPU tests use) is the general one for such a sweep
-        const HybPlan p0 = plan_hyb_group(n, m, cus, hyb_vmax, nunits, T.target_wgs, T.hyb_res != 0);
+        const HybPlan &p0 = hyb_plan0;
         const Geo g0[2] = {ghp[0], gwp[0]};
+        bool same = true;
         for (int w = 0; w < 2; ++w)
-          if (p0.res[w] != res_wgs[w] || p0.wsplit[w] != g0[w].wsplit || p0.S[w] != g0[w].S || p0.dchunk[w] != g0[w].dchunk ||
-              p0.fused[w] != g0[w].fused || p0.slots[w] != g0[w].slots)
-            return fail(NMFK_ERR_HIP, "internal: the tier planner disagrees with the sweep's launch geometry");
+          same = same && p0.res[w] == res_wgs[w] && p0.wsplit[w] == g0[w].wsplit && p0.S[w] == g0[w].S && p0.dchunk[w] == g0[w].dchunk &&
+                 p0.fused[w] == g0[w].fused && p0.slots[w] == g0[w].slots;
+        if (!same) {  // (an unusual NMFK_TARGET_WGS or shape: a pure optimisation must not fail the sweep -- static schedule)
+          if (getenv("NMFK_DEBUG")) fprintf(stderr, "[nmfk] the tier planner disagrees with the sweep's launch geometry: static schedule\n");
+          tiers.clear();
+        }
       }
-      for (int c = (nunits + 1) / 2; c >= 1 && c < tiers.back().count; c = (c + 1) / 2) {
-        const HybPlan p = plan_hyb_group(n, m, cus, hyb_vmax, c, T.target_wgs, T.hyb_res != 0);
+      for (int c = (nunits + 1) / 2; !tiers.empty() && c >= 1 && c < tiers.back().count; c = (c + 1) / 2) {
+        const HybCohortPlan cp = plan_hyb_cohorts(n, m, cus, hyb_mix.scaled(c), T, T.hyb_res != 0);
+        const HybPlan &p = cp.plan;
         Tier t;
         t.count = c;
+        t.ncoh = cp.cohorts;
         t.res[0] = p.res[0], t.res[1] = p.res[1];
         t.gh = Geo{p.wsplit[0], p.S[0], p.dchunk[0], p.fused[0], p.slots[0]};
         t.gw = Geo{p.wsplit[1], p.S[1], p.dchunk[1], p.fused[1], p.slots[1]};
@@ -1084,6 +1331,28 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   const size_t o_ptrs = B.take(sizeof(void *) * 7 * nk);
   const int trace_stride = ctx->trace_objective ? (int)std::max<int64_t>(1, P.maxiter / 10) : 0;
   const size_t o_trace = ctx->trace_objective ? B.take(sizeof(double) * (size_t)nunits * trace_stride) : 0;
+  // Partial numerators (half-steps whose loop range is split over workgroups) and check_b's index scratch.  Static schedule: a buffer
+  // per unit.  Retire-aware schedule: the late tiers run few units with many splits (S up to 64), so a buffer per unit sized for the
+  // widest tier would cost S_max * kp * max(n, m) for EVERY unit of the sweep (~1 GB at 8192 x 512 x 480); the buffers are idle between
+  // half-steps, so they belong to the POSITIONS of the work list instead -- position p of tier t at p * stride_t of one pool sized
+  // for the largest count_t * stride_t (count_t halves where S_t doubles); replan_kernel hands them out.
+  size_t part_stride0 = 0, o_partpool = 0;
+  std::vector<size_t> part_stride(tiers.size(), 0);
+  if (replanning) {
+    int kpm = 1;
+    for (int q = 0; q < nk; ++q) kpm = std::max(kpm, nmfk_padded_k(ks[q]));
+    size_t pool = 0;
+    for (size_t j = 0; j < tiers.size(); ++j) {
+      const Tier &t = tiers[j];
+      const size_t sh = (t.res[0] > 0 || t.gh.fused) ? 0 : (size_t)t.gh.S, sw = (t.res[1] > 0 || t.gw.fused) ? 0 : (size_t)t.gw.S;
+      size_t b = std::max(tsz * std::max(sh * kpm * m, sw * kpm * n), sizeof(int32_t) * (size_t)m);
+      b = (b + 255) & ~(size_t)255;
+      part_stride[j] = b;
+      pool = std::max(pool, b * (size_t)t.count);
+    }
+    part_stride0 = part_stride[0];
+    o_partpool = B.take(pool);
+  }
   std::vector<NmfkRun> runs(nunits);
   std::vector<size_t> o_Wi(nk, 0), o_Hi(nk, 0), o_Wo(nk), o_Ho(nk), o_frob(nk), o_iters(nk), o_reason(nk);
   struct Group {
@@ -1149,6 +1418,32 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     }
     if (G.count > 0) groups.push_back(G);
   }
+  // Cohorts (round 5).  A half-step launch of few units ends in a tail -- its last workgroups leave most CUs idle -- and the next
+  // launch of the same units cannot start before it has drained: the kernel trace of a 60-unit share of the bench sweep shows no
+  // gaps between launches, the time is inside them (H / W half-step 125 / 108 us where an eighth of the 480-unit launches is
+  // 84 / 89).  So the units of the matrix-pipe group are dealt round-robin (the list is sorted by rank: every cohort gets the
+  // same mix) to `ncoh` COHORTS, contiguous in the work list, each with its own stream: their launches share the launch
+  // geometry of the group (a unit's arithmetic, and therefore its bits, does not depend on its cohort) and overlap freely,
+  // one cohort's W half-step filling the CUs another's H half-step leaves idle.  The check block runs per cohort; the
+  // retire-aware schedule joins the cohort streams for a re-plan and deals the units still active out again.
+  std::vector<std::vector<std::pair<int, int>>> coh(groups.size());  // [group][cohort] = (first unit, units)
+  for (size_t j = 0; j < groups.size(); ++j) {
+    const Group &G = groups[j];
+    int nc = 1;
+    if (G.hyb && G.kp == 0 && !ctx->sparse && !f64) nc = G.count == hyb_mix.units() ? hyb_cplan0.cohorts : (T.cohorts > 0 ? T.cohorts : 1);
+    nc = std::max(1, std::min(nc, G.count));
+    if (nc > 1) {
+      std::vector<std::pair<int, int>> seg(ulist.begin() + G.begin, ulist.begin() + G.begin + G.count);
+      int w = G.begin;
+      for (int c = 0; c < nc; ++c) {
+        const int b = w;
+        for (int i = c; i < G.count; i += nc) ulist[(size_t)w++] = seg[(size_t)i];
+        coh[j].push_back({b, w - b});
+      }
+    } else {
+      coh[j].push_back({G.begin, G.count});
+    }
+  }
   // objective partials per unit: a workgroup of 256 rows each (sse kernels), or, when the check is deferred into the next H
   // half-step (see the loop), one per workgroup of that launch -- in any tier of the retire-aware schedule
   int obj_cap = tiles_n + 1;
@@ -1173,7 +1468,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         rd.oH0 = (int64_t)B.take(tsz * (size_t)kp * m);
         rd.oH1 = P.Hfixed ? rd.oH0 : (int64_t)B.take(tsz * (size_t)kp * m);
         const size_t pe = std::max((size_t)Sh * kp * m, (size_t)Sw * kp * n);
-        rd.opart = (int64_t)B.take(std::max(tsz * pe, sizeof(int32_t) * (size_t)m));
+        rd.opart = replanning ? (int64_t)(o_partpool + (size_t)u * part_stride0) : (int64_t)B.take(std::max(tsz * pe, sizeof(int32_t) * (size_t)m));
         rd.osumW = (int64_t)B.take(sizeof(double) * (size_t)PWmax * kp);
         rd.osumH = (int64_t)B.take(sizeof(double) * (size_t)PHmax * kp);
         rd.ossepart = (int64_t)B.take(sizeof(double) * (size_t)obj_cap);  // (sparse objective: slot 0 = <W'W, HH'>)
@@ -1448,7 +1743,17 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   // one after the other: 6.3 ms; at 1024 x 128 the loop is bound by the host's launches and more streams buy nothing --
   // profiles/r04/wide_rank_streams.txt)
   const int max_streams = T.streams > 0 ? T.streams : ctx->sparse ? 1 : (ngroups >= 12 && (double)n * m >= 0.25 * 8192.0 * 512.0) ? 16 : 8;
-  const int NS = std::min(ngroups, max_streams);
+  int ncohorts = 0;  // stream slots: one per cohort of every launch group
+  std::vector<std::vector<int>> coh_stream(groups.size());
+  for (size_t j = 0; j < groups.size(); ++j) {
+    size_t parts = coh[j].size();
+    if (replanning && j == 0)  // (a later tier may deal the units still active to more cohorts than the sweep starts with)
+      for (const Tier &t : tiers) parts = std::max(parts, (size_t)t.ncoh);
+    for (size_t c = 0; c < parts; ++c) coh_stream[j].push_back(ncohorts++);
+  }
+  const int NS = std::min(ncohorts, max_streams);
+  for (auto &v : coh_stream)
+    for (int &x : v) x %= NS;
   while ((int)ctx->gstreams.size() < NS) {
     hipStream_t gs;
     HIPCHECK(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
@@ -1471,6 +1776,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   } events;
   std::vector<hipEvent_t> gev(2 * (size_t)NS);
   for (auto &e : gev) HIPCHECK(events.make(&e, hipEventDisableTiming));
+  std::vector<hipEvent_t> rp_ev((size_t)NS + 1);  // re-plans: join / fork of the cohort streams
+  for (auto &e : rp_ev) HIPCHECK(events.make(&e, hipEventDisableTiming));
   hipEvent_t snap_ev[2], start_ev;
   HIPCHECK(events.make(&snap_ev[0], hipEventDisableTiming));
   HIPCHECK(events.make(&snap_ev[1], hipEventDisableTiming));
@@ -1507,6 +1814,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   std::vector<char> in_phase(nunits);
   // retire-aware schedule: state of the re-plans (see the tiers above)
   const std::vector<Group> groups0 = groups;  // (the profile below counts over the launch groups as they started)
+  const std::vector<NmfkRun> runs0 = runs;    // (units by NmfkRun::uid = position in the list the sweep starts with)
   int cur_tier = 0, cur_buf = 0, nreplans = 0, snap_epoch[2] = {0, 0};
   std::vector<std::vector<int32_t>> order_hist(1, std::vector<int32_t>((size_t)nunits));  // [re-plan][position] = NmfkRun::uid
   for (int u = 0; u < nunits; ++u) order_hist[0][(size_t)u] = u;
@@ -1530,6 +1838,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     const NmfkStepArgs &hs = hsP[G.phase], &ws = wsP[G.phase];
     return (int)(!T.clamp_always && use_hyb(G) && !P.Hfixed && !P.Wfixed && (hs.fused || hs.res_wgs > 0) && (ws.fused || ws.res_wgs > 0));
   };
+  int max_cohorts = 1;
+  for (const auto &v : coh) max_cohorts = std::max(max_cohorts, (int)v.size());
   std::vector<int> pending((size_t)ngroups, 0);  // > 0: the group's check of the previous iteration waits for this H half-step (= its objective partials per unit)
   int ndeferred = 0, nclassic = 0;
   for (int phase = 0; phase < nphases; ++phase) {
@@ -1553,45 +1863,49 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       if (G.phase != phase) continue;
       const NmfkStepArgs &hs = hsP[G.phase], &ws = wsP[G.phase];
       const NmfkStepArgs *d_hs = d_hsP[G.phase], *d_ws = d_wsP[G.phase];
-      hipStream_t gs = ctx->gstreams[j % NS];
+      const int pend = pending[j];  // (the same for every cohort of the group)
+      const int epoch = (int)order_hist.size() - 1;
+      for (size_t cq = 0; cq < coh[j].size(); ++cq) {
+      const int ub = coh[j][cq].first, uc = coh[j][cq].second;
+      if (uc <= 0) continue;
+      hipStream_t gs = ctx->gstreams[coh_stream[j][cq]];
       if (!P.Hfixed) {  // Mult:66-68
         const size_t e0 = timed ? prof.begin(gs) : 0;
         sph.it = it;
-        sph.objw = (sparse && pending[j]) ? P.weight : 0.0;
+        sph.objw = (sparse && pend) ? P.weight : 0.0;
         if (sparse && f64)
-          nmfk_launch_sp_step_f64(&sph, G.kp, G.begin, G.count, gs);
+          nmfk_launch_sp_step_f64(&sph, G.kp, ub, uc, gs);
         else if (sparse)
-          nmfk_launch_sp_step_f32(&sph, G.kp, G.begin, G.count, gs);
+          nmfk_launch_sp_step_f32(&sph, G.kp, ub, uc, gs);
         else if (use_hyb(G))
-          nmfk_launch_step_hyb_f32(hs, d_hs, G.hyb, G.begin, G.count, gs, pending[j] ? P.weight : 0.0);
+          nmfk_launch_step_hyb_f32(hs, d_hs, G.hyb, ub, uc, gs, pend ? P.weight : 0.0);
         else if (G.kp == 0 && f64)
-          nmfk_launch_step_multi_f64(hs, d_hs, G.begin, G.count, gs);
+          nmfk_launch_step_multi_f64(hs, d_hs, ub, uc, gs);
 #if NMFK_WITH_MERGED_F32
         else if (G.kp == 0)
-          nmfk_launch_step_multi_f32(hs, d_hs, G.begin, G.count, gs);
+          nmfk_launch_step_multi_f32(hs, d_hs, ub, uc, gs);
 #endif
         else if (f64)
-          nmfk_launch_step_f64(hs, d_hs, G.kp, G.begin, G.count, gs);
+          nmfk_launch_step_f64(hs, d_hs, G.kp, ub, uc, gs);
         else if (use_wide(G) && use_wide2_k(G.k) && hs.wsplit == 1)
-          nmfk_launch_step_wide2_f32(hs, d_hs, G.kp, G.begin, G.count, gs, pending[j] ? P.weight : 0.0);
+          nmfk_launch_step_wide2_f32(hs, d_hs, G.kp, ub, uc, gs, pend ? P.weight : 0.0);
         else if (use_wide(G))
-          nmfk_launch_step_mfma_wide_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
+          nmfk_launch_step_mfma_wide_f32(hs, d_hs, G.kp, ub, uc, gs);
         else
-          nmfk_launch_step_f32(hs, d_hs, G.kp, G.begin, G.count, gs);
-        if (timed) prof.end(e0, PK_HSTEP, j, it, gs);
+          nmfk_launch_step_f32(hs, d_hs, G.kp, ub, uc, gs);
+        if (timed) prof.end(e0, PK_HSTEP, j, it, gs, ub, uc, epoch);
         if (!hs.fused && !(use_hyb(G) && hs.res_wgs > 0)) {  // (the resident form always finishes itself)
           if (f64)
-            nmfk_launch_reduce_f64(hs, G.begin, G.count, gs);
+            nmfk_launch_reduce_f64(hs, ub, uc, gs);
           else
-            nmfk_launch_reduce_f32(hs, G.begin, G.count, gs);
+            nmfk_launch_reduce_f32(hs, ub, uc, gs);
         }
-        if (pending[j]) {  // the deferred check of iteration it - 1: the objective has just been left by the half-step
+        if (pend) {  // the deferred check of iteration it - 1: the objective has just been left by the half-step
           NmfkCheckArgs cb = ca;
           cb.it = it - 1;
-          cb.ntile_n = pending[j];  // (the partials this launch has left: defer_parts at the check iteration)
+          cb.ntile_n = pend;  // (the partials this launch has left: defer_parts at the check iteration)
           cb.track_low = track_low_of(G);
-          nmfk_launch_check_f32(cb, G.begin, G.count, gs, 1 | 4);
-          pending[j] = 0;
+          nmfk_launch_check_f32(cb, ub, uc, gs, 1 | 4);
           completing = true;
         }
       }
@@ -1600,72 +1914,77 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         spw.it = it;
         spw.clampw = defer_kind(G) == 3;
         if (sparse && f64)
-          nmfk_launch_sp_step_f64(&spw, G.kp, G.begin, G.count, gs);
+          nmfk_launch_sp_step_f64(&spw, G.kp, ub, uc, gs);
         else if (sparse)
-          nmfk_launch_sp_step_f32(&spw, G.kp, G.begin, G.count, gs);
+          nmfk_launch_sp_step_f32(&spw, G.kp, ub, uc, gs);
         else if (use_hyb(G))
-          nmfk_launch_step_hyb_f32(ws, d_ws, G.hyb, G.begin, G.count, gs);
+          nmfk_launch_step_hyb_f32(ws, d_ws, G.hyb, ub, uc, gs);
         else if (G.kp == 0 && f64)
-          nmfk_launch_step_multi_f64(ws, d_ws, G.begin, G.count, gs);
+          nmfk_launch_step_multi_f64(ws, d_ws, ub, uc, gs);
 #if NMFK_WITH_MERGED_F32
         else if (G.kp == 0)
-          nmfk_launch_step_multi_f32(ws, d_ws, G.begin, G.count, gs);
+          nmfk_launch_step_multi_f32(ws, d_ws, ub, uc, gs);
 #endif
         else if (f64)
-          nmfk_launch_step_f64(ws, d_ws, G.kp, G.begin, G.count, gs);
+          nmfk_launch_step_f64(ws, d_ws, G.kp, ub, uc, gs);
         else if (use_wide(G) && use_wide2_k(G.k) && ws.wsplit == 1)
-          nmfk_launch_step_wide2_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
+          nmfk_launch_step_wide2_f32(ws, d_ws, G.kp, ub, uc, gs);
         else if (use_wide(G))
-          nmfk_launch_step_mfma_wide_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
+          nmfk_launch_step_mfma_wide_f32(ws, d_ws, G.kp, ub, uc, gs);
         else
-          nmfk_launch_step_f32(ws, d_ws, G.kp, G.begin, G.count, gs);
-        if (timed) prof.end(e0, PK_WSTEP, j, it, gs);
+          nmfk_launch_step_f32(ws, d_ws, G.kp, ub, uc, gs);
+        if (timed) prof.end(e0, PK_WSTEP, j, it, gs, ub, uc, epoch);
         if (!ws.fused && !(use_hyb(G) && ws.res_wgs > 0)) {
           NmfkStepArgs wr = ws;  // (the phase's argument block serves groups on other kernels too: only this group's choice counts)
           wr.clampw = defer_kind(G) != 0 && ws.clampw;
           if (f64)
-            nmfk_launch_reduce_f64(wr, G.begin, G.count, gs);
+            nmfk_launch_reduce_f64(wr, ub, uc, gs);
           else
-            nmfk_launch_reduce_f32(wr, G.begin, G.count, gs);
+            nmfk_launch_reduce_f32(wr, ub, uc, gs);
         }
       }
       ca.w_clamped = defer_kind(G) == 3 || (defer_kind(G) != 0 && wsP[G.phase].clampw);
       if (check && it + 1 < maxiter && defer_parts(G) > 0) {
         ca.track_low = track_low_of(G);
-        nmfk_launch_check_f32(ca, G.begin, G.count, gs, 2);
+        nmfk_launch_check_f32(ca, ub, uc, gs, 2);
         if (sparse) {  // the Gram term of the clamped factors -> slot 0; the non-zero terms come with the next H half-step
           spw.it = it;
-          nmfk_launch_sp_obj_f32(&spw, n, m, (it + 1) & 1, 0, P.weight, G.begin, G.count, gs, 2);
+          nmfk_launch_sp_obj_f32(&spw, n, m, (it + 1) & 1, 0, P.weight, ub, uc, gs, 2);
         }
-        pending[j] = defer_parts(G);
         deferring = true;
-        ++ndeferred;
       } else if (check) {
-        ++nclassic;
         if (sparse) {
           spw.it = it;
           if (f64)
-            nmfk_launch_sp_obj_f64(&spw, n, m, (it + 1) & 1, 0, P.weight, G.begin, G.count, gs);
+            nmfk_launch_sp_obj_f64(&spw, n, m, (it + 1) & 1, 0, P.weight, ub, uc, gs);
           else
-            nmfk_launch_sp_obj_f32(&spw, n, m, (it + 1) & 1, 0, P.weight, G.begin, G.count, gs);
+            nmfk_launch_sp_obj_f32(&spw, n, m, (it + 1) & 1, 0, P.weight, ub, uc, gs);
         } else if (f64) {
-          nmfk_launch_sse_f64(sa, G.begin, G.count, gs);
+          nmfk_launch_sse_f64(sa, ub, uc, gs);
         } else if (use_hyb(G) && sa.Wgt == nullptr && hyb_sse) {
-          nmfk_launch_hyb_sse(wsP[G.phase], d_wsP[G.phase], P.weight, (it + 1) & 1, G.hyb, G.begin, G.count, gs);
+          nmfk_launch_hyb_sse(wsP[G.phase], d_wsP[G.phase], P.weight, (it + 1) & 1, G.hyb, ub, uc, gs);
         } else if (use_wide(G) && use_wide2_k(G.k) && sa.Wgt == nullptr && wide_sse) {
-          nmfk_launch_wide2_sse(wsP[G.phase], d_wsP[G.phase], P.weight, (it + 1) & 1, G.kp, G.begin, G.count, gs);
+          nmfk_launch_wide2_sse(wsP[G.phase], d_wsP[G.phase], P.weight, (it + 1) & 1, G.kp, ub, uc, gs);
         } else if (use_wide(G) && sa.Wgt == nullptr && wide_sse) {
-          nmfk_launch_sse_mfma_wide_f32(sa, G.kp, G.begin, G.count, gs);
+          nmfk_launch_sse_mfma_wide_f32(sa, G.kp, ub, uc, gs);
         } else {
-          nmfk_launch_sse_f32(sa, G.begin, G.count, gs);
+          nmfk_launch_sse_f32(sa, ub, uc, gs);
         }
         // the clamp pass only where a value below eps() may exist: the matrix-pipe kernels' fused finishes watch what they write
         // in a check iteration (both half-steps run and finish themselves; NmfkState::lowflag)
         ca.track_low = track_low_of(G);
         if (f64)
-          nmfk_launch_check_f64(ca, G.begin, G.count, gs);
+          nmfk_launch_check_f64(ca, ub, uc, gs);
         else
-          nmfk_launch_check_f32(ca, G.begin, G.count, gs);
+          nmfk_launch_check_f32(ca, ub, uc, gs);
+      }
+      }  // cohorts
+      if (pend && !P.Hfixed) pending[j] = 0;
+      if (check && it + 1 < maxiter && defer_parts(G) > 0) {
+        pending[j] = defer_parts(G);
+        ++ndeferred;
+      } else if (check) {
+        ++nclassic;
       }
     }
     total_iters = std::max(total_iters, it + 1);
@@ -1695,25 +2014,43 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       if (next_tier != cur_tier && it + 1 < maxiter) {
         // ---- re-plan (takes effect with the next iteration; everything below is queued behind this check on the group's
         // stream, the host does not wait).  The snapshot just inspected may predate an earlier re-plan: unit ids translate.
-        hipStream_t gs = ctx->gstreams[0];
+        hipStream_t gs = ctx->gstreams[coh_stream[0][0]];
+        // (cohorts: the work list is permuted as a whole, so the re-plan waits for every cohort's stream and they for it)
+        for (int j = 0; j < NS; ++j)
+          if (ctx->gstreams[j] != gs) {
+            HIPCHECK(hipEventRecord(rp_ev[j], ctx->gstreams[j]));
+            HIPCHECK(hipStreamWaitEvent(gs, rp_ev[j], 0));
+          }
         const std::vector<int32_t> &seen = order_hist[(size_t)snap_epoch[slot ^ 1]], &cur = order_hist.back();
         std::vector<char> alive((size_t)nunits, 0);
         for (int u = 0; u < nunits; ++u) alive[(size_t)seen[u]] = snap[slot ^ 1][u].active ? 1 : 0;
         perm_keep.emplace_back((size_t)nunits);
         std::vector<int32_t> &perm = perm_keep.back(), order((size_t)nunits);
+        const Tier &tr = tiers[(size_t)next_tier];
         int w = 0;
-        for (int pass = 1; pass >= 0; --pass)  // the units still active first, in their present order (k descending)
+        {  // the units still active first -- dealt round-robin, in their present order, to the tier's cohorts (every cohort the same
+          // mix of ranks) --, then the others
+          std::vector<int> act_pos;
           for (int u = 0; u < nunits; ++u)
-            if (alive[(size_t)cur[u]] == pass) {
+            if (alive[(size_t)cur[u]]) act_pos.push_back(u);
+          const int na = (int)act_pos.size(), nc = std::max(1, std::min(tr.ncoh, na));
+          for (int c = 0; c < nc; ++c)
+            for (int i = c; i < na; i += nc) {
+              perm[(size_t)w] = act_pos[(size_t)i];
+              order[(size_t)w++] = cur[(size_t)act_pos[(size_t)i]];
+            }
+          for (int u = 0; u < nunits; ++u)
+            if (!alive[(size_t)cur[u]]) {
               perm[(size_t)w] = u;
               order[(size_t)w++] = cur[u];
             }
-        const Tier &tr = tiers[(size_t)next_tier];
+        }
         int32_t *d_perm = (int32_t *)(A + o_perm) + (size_t)nreplans * nunits;
         HIPCHECK(hipMemcpyAsync(d_perm, perm.data(), sizeof(int32_t) * nunits, hipMemcpyHostToDevice, gs));
         hipLaunchKernelGGL(replan_kernel, dim3(nunits), dim3(64), 0, gs, A, d_runs_buf[cur_buf], d_state_buf[cur_buf],
                            d_runs_buf[cur_buf ^ 1], d_state_buf[cur_buf ^ 1], d_perm, tr.nsW, tr.nsH, tiers[(size_t)cur_tier].PW,
-                           tiers[(size_t)cur_tier].PH, std::max(tiers[(size_t)cur_tier].PW, tr.PW), std::max(tiers[(size_t)cur_tier].PH, tr.PH));
+                           tiers[(size_t)cur_tier].PH, std::max(tiers[(size_t)cur_tier].PW, tr.PW), std::max(tiers[(size_t)cur_tier].PH, tr.PH),
+                           (int64_t)o_partpool, (int64_t)part_stride[(size_t)next_tier], tr.count);
         cur_buf ^= 1;
         d_runs = d_runs_buf[cur_buf];
         d_state = d_state_buf[cur_buf];
@@ -1723,6 +2060,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             moved[(size_t)u] = runs[(size_t)perm[(size_t)u]];
             moved[(size_t)u].nsW = tr.nsW;
             moved[(size_t)u].nsH = tr.nsH;
+            moved[(size_t)u].opart = (int64_t)(o_partpool + (size_t)(u < tr.count ? u : 0) * part_stride[(size_t)next_tier]);
           }
           runs.swap(moved);
         }
@@ -1752,6 +2090,20 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         ca.PW = tr.PW;
         ca.PH = tr.PH;
         groups[0].count = act;
+        {  // the units still active are dealt out again: equal contiguous parts (the list is rank-sorted inside each old cohort)
+          const int nc = std::max(1, std::min(tr.ncoh, act));
+          coh[0].resize((size_t)nc);
+          max_cohorts = std::max(max_cohorts, nc);
+          int b = groups[0].begin;
+          for (int c = 0; c < nc; ++c) {
+            const int cnt_c = act / nc + (c < act % nc ? 1 : 0);
+            coh[0][(size_t)c] = {b, cnt_c};
+            b += cnt_c;
+          }
+        }
+        HIPCHECK(hipEventRecord(rp_ev[NS], gs));
+        for (int j = 0; j < NS; ++j)
+          if (ctx->gstreams[j] != gs) HIPCHECK(hipStreamWaitEvent(ctx->gstreams[j], rp_ev[NS], 0));
         order_hist.push_back(order);
         cur_tier = next_tier;
         ++nreplans;
@@ -1766,6 +2118,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ctx->sweep_info[5] = nreplans;
   ctx->sweep_info[6] = cur_tier;
   ctx->sweep_info[7] = ngroups == 1 ? groups[0].count : 0;
+  ctx->sweep_info[10] = max_cohorts;  // (the most the sweep ran side by side; a late tier of a handful of units runs as one)
   ctx->sweep_info[8] = ndeferred;
   ctx->sweep_info[9] = nclassic;
   if (T.host_timing)
@@ -1896,9 +2249,11 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, ctx->events[sm.e0], ctx->events[sm.e1]) != hipSuccess) continue;
       const Group &G = groups0[sm.group];
-      double active_k = 0;  // sum of the ranks of the units still iterating
-      for (int u = G.begin; u < G.begin + G.count; ++u)
-        active_k += sm.it < h_iters[runs[u].kidx][runs[u].ridx] ? runs[u].k : 0;
+      double active_k = 0;  // sum of the ranks of the units still iterating (positions of the work list as of the launch -> units)
+      for (int u = sm.u0; u < sm.u0 + sm.cnt; ++u) {
+        const NmfkRun &ru = runs0[(size_t)order_hist[(size_t)sm.epoch][(size_t)u]];
+        active_k += sm.it < h_iters[ru.kidx][ru.ridx] ? ru.k : 0;
+      }
       char name[64];
       if (G.kp == 0 && G.hyb)  // mixed-rank group on the split-operand MFMA kernel
         snprintf(name, sizeof(name), "%s<mfma>", sm.kind == PK_HSTEP ? "h_step" : "w_step");

@@ -1181,6 +1181,55 @@ def test_robustkmeans_rows_of_W_at_bench_size(NMFk, ctx, oracle):
     assert one["totalcost"] == r["totalcost"]
 
 
+def test_cohorts_leave_every_unit_its_bits(NMFk, ctx, oracle, monkeypatch):
+    """Round 5: the units of the matrix-pipe launch group run as COHORTS -- contiguous parts of the work list,
+    each on its own stream, so that one cohort's half-step fills the CUs another's leaves idle (nmfk_mu_sweep, "Cohorts").  A
+    unit's arithmetic does not depend on its cohort: with the launch geometry pinned (NMFK_TARGET_WGS: the threshold rule, which
+    does not look at the cohorts) one, two and three cohorts give the same bits for every restart -- also through the re-plans of
+    the retire-aware schedule, which join the cohort streams, permute the work list as a whole and deal the units still active
+    out again (NMFK_REPLAN=2: every tier).  The default plan (cost model; a launch of a cohort is planned as such) agrees with them
+    to fp32 rounding and with the oracle like every other geometry."""
+    n, m, k0 = 640, 192, 3
+    W0 = oracle.uniform_fill(9, 0, n * k0).reshape(n, k0)
+    H0 = oracle.uniform_fill(9, n * k0, k0 * m).reshape(k0, m)
+    X = np.asfortranarray((W0 @ H0 + 0.02 * oracle.uniform_fill(9, n * k0 + k0 * m, n * m).reshape(n, m)).astype(np.float32))
+    ctx.set_X(X)
+    ks, R = [2, 3, 4, 5, 6, 9, 13], 5
+    seeds = _seeds(NMFk, 4, ks, R)
+    monkeypatch.setenv("NMFK_TARGET_WGS", "256")
+    for replan, maxiter, kw in (("0", 200, NOSTOP), ("2", 3000, {})):
+        monkeypatch.setenv("NMFK_REPLAN", replan)
+        ref = None
+        for C in (1, 2, 3):
+            monkeypatch.setenv("NMFK_COHORTS", str(C))
+            res = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=maxiter, **kw)
+            info = ctx.last_sweep_info()
+            assert info["cohorts"] == C and info["launch_groups"] == 1 and info["mfma_group_units"] == len(ks) * R, info
+            if replan == "2":
+                assert info["replans"] >= 2, info
+            if ref is None:
+                ref = res
+                continue
+            for k in ks:
+                for key in ("W", "H", "objvalue", "iters", "reason"):
+                    assert (res[k][key] == ref[k][key]).all(), (replan, C, k, key)
+    # the default plan: cohorts by the model (this small matrix: one), forced to two: the plan of a half-sized launch
+    monkeypatch.delenv("NMFK_TARGET_WGS")
+    monkeypatch.setenv("NMFK_REPLAN", "0")
+    by_c = {}
+    for C in ("1", "2"):
+        monkeypatch.setenv("NMFK_COHORTS", C)
+        by_c[C] = res = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=200, **NOSTOP)
+        assert ctx.last_sweep_info()["cohorts"] == int(C)
+    for k in ks:
+        np.testing.assert_allclose(by_c["2"][k]["objvalue"], by_c["1"][k]["objvalue"], rtol=1e-5)
+    k, r = 5, 2
+    Wi, Hi = oracle.init_factors(int(seeds[ks.index(k), r]), n, m, k)
+    o = oracle.singlerun(X, k, Wi, Hi, maxiter=200, **NOSTOP)
+    err = np.linalg.norm(res[k]["W"][r] @ res[k]["H"][r] - o["W"] @ o["H"]) / np.linalg.norm(X)
+    assert err < 1e-4, err
+
+
 def test_retire_aware_schedule_on_a_small_sweep(NMFk, ctx, oracle, monkeypatch):
     """Round 4: restarts retire at different iterations (Mult:64); the sweep is re-planned as they do --
     the units still active move to the front of the work list and the launch geometry is re-derived for them

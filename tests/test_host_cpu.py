@@ -434,23 +434,24 @@ def test_shard_plan_matches_the_python_plan():
 
 
 def test_retire_aware_tiers_are_consistent_launch_geometries(monkeypatch):
-    """nmfk_plan_hyb_tiers (the planner nmfk_mu_sweep uses for the retire-aware schedule, host arithmetic): tier j plans
-    ceil(units / 2^j) units; every tier's splits cover the loop range in 16-aligned chunks no shorter than a wave's 64;
-    a unit writes no more table slots than the helpers cover; fewer units never get fewer workgroups per unit; and each
-    tier has an independent stream of work for each of the 256 CUs as long as the matrix allows it."""
+    """nmfk_plan_hyb_tiers (the planner nmfk_mu_sweep uses for the matrix-pipe group and for every tier of the retire-aware
+    schedule; host arithmetic): tier j plans ceil(units / 2^j) units; every tier's splits cover the loop range in 16-aligned
+    chunks no shorter than a wave's 64; a unit writes no more table slots than the helpers cover; the resident form never
+    has more workgroups than pairs of lane tiles to hand out.  Round 5: the geometry is the cheapest candidate of a cost model
+    (list schedule of the launch's workgroups over the CUs, constants fitted to measured launches) -- pinned here to the
+    region the exhaustive scan on MI355X found best at the bench shape (profiles/r05/geometry_scan.txt)."""
     from nmfk_jl_amd import _lib
 
-    for v in ("NMFK_TARGET_WGS", "NMFK_HYB_RES"):
+    for v in ("NMFK_TARGET_WGS", "NMFK_HYB_RES", "NMFK_COHORTS", "NMFK_EXP_GEO", "NMFK_EXP_LEGACY_GEO"):
         monkeypatch.delenv(v, raising=False)
-    for n, m in ((8192, 512), (1024, 256), (20000, 96), (64, 4096), (16, 16)):
-        for units, variant in ((480, 16), (480, 4), (33, 8), (1, 16)):
+    for n, m in ((8192, 512), (1024, 256), (20000, 96), (64, 4096), (16, 16), (2048, 2048), (65536, 256)):
+        for units, variant in ((480, 16), (480, 4), (33, 8), (1, 16), (480, 0), (60, 0)):
             tiers = _lib.plan_hyb_tiers(n, m, variant, units)
             assert [t["units"] for t in tiers][0] == units and tiers[-1]["units"] == 1
             for a, b in zip(tiers, tiers[1:]):
                 assert b["units"] == (a["units"] + 1) // 2
-            prev = None
             for t in tiers:
-                per_unit = []
+                assert 1 <= t["cohorts"] <= max(1, min(2, t["units"]))
                 for half, L, D in (("H", m, n), ("W", n, m)):
                     g = t[half]
                     assert g["wsplit"] in (1, 4, 8) and g["S"] >= 1 and g["fused"] == (g["S"] == 1)
@@ -459,18 +460,25 @@ def test_retire_aware_tiers_are_consistent_launch_geometries(monkeypatch):
                         assert g["dchunk"] % 16 == 0 and g["dchunk"] >= 64 * g["wsplit"]
                     assert 1 <= g["ns"] <= g["slots"] <= max(64, (L + 31) // 32)
                     if g["res"]:
-                        assert g["ns"] == g["res"] and 8 * g["res"] <= max(8, (L + 31) // 32)
-                    wgs = g["ns"] * g["S"] * t["units"]
-                    per_unit.append(g["ns"] * g["S"] * g["wsplit"])
-                    room = (L + 31) // 32 * max(1, D // 512) * t["units"]  # 32 lanes x 512 of the loop is the least a workgroup takes
-                    assert wgs * (16 if g["res"] else g["wsplit"]) >= min(256, room // 8), (n, m, units, variant, t)  # (waves with work of their own: wsplit ranges, the resident form's 16 tile walkers)
-                if prev:
-                    assert per_unit[0] >= prev[0] or per_unit[1] >= prev[1]
-                prev = per_unit
-    # the bench sweep (8192 x 512, 480 units): full list is fused both ways; a quarter of it is not starved
-    t0, t2 = _lib.plan_hyb_tiers(8192, 512, 16, 480)[0], _lib.plan_hyb_tiers(8192, 512, 16, 480)[2]
-    assert t0["H"]["fused"] == 1 and t0["W"]["fused"] == 1 and t0["W"]["res"] > 0
-    assert t2["units"] == 120 and t2["W"]["ns"] * t2["W"]["S"] * 120 >= 512
+                        assert g["ns"] == g["res"] and g["S"] == 1 and 16 * g["res"] <= max(16, (L + 31) // 32)
+    # the bench sweep (8192 x 512, ranks 2..16 in equal numbers): the full list is fused both ways, one cohort; the shares of
+    # 4 and 8 GPUs (120 / 60 units) and the late tiers split the H half-step's loop range over workgroups that keep the shared
+    # staging (wsplit 1), run the W half-step resident with more, shorter workgroups, as two cohorts
+    byu = {t["units"]: t for t in _lib.plan_hyb_tiers(8192, 512, 0, 480)}
+    t0 = byu[480]
+    assert t0["H"]["fused"] == 1 and t0["H"]["wsplit"] == 1 and t0["W"]["fused"] == 1 and t0["W"]["res"] == 4 and t0["cohorts"] == 1
+    for units, S_ok, res_ok in ((120, (3, 4, 5), (4, 8)), (60, (6, 8, 10), (8,)), (30, (12, 16), (8, 16)), (15, (16, 24, 32), (16,))):
+        t = byu[units]
+        assert t["H"]["wsplit"] == 1 and t["H"]["S"] in S_ok and t["W"]["res"] in res_ok, t
+    assert byu[120]["cohorts"] == 2 and byu[60]["cohorts"] == 2 and byu[30]["cohorts"] == 2 and byu[1]["cohorts"] == 1
+    assert byu[1]["W"]["res"] == 16  # (BASELINE configs[1], one unit: one pair of lane tiles per wave, 62 -> 45 us per iteration)
+    # a narrow matrix (64 columns: a quarter of a shared-staging workgroup's lanes) keeps the per-wave form for the H half-step
+    assert _lib.plan_hyb_tiers(4096, 64, 0, 480)[0]["H"]["wsplit"] == 8
+    # NMFK_TARGET_WGS keeps the threshold rule of rounds 2-4 (tests force split geometries with it)
+    monkeypatch.setenv("NMFK_TARGET_WGS", "4096")
+    t = _lib.plan_hyb_tiers(8192, 512, 16, 480)[0]
+    assert (t["H"]["S"] > 1 or t["H"]["wsplit"] > 1) and t["cohorts"] == 1
+    monkeypatch.delenv("NMFK_TARGET_WGS")
     with pytest.raises(Exception):
         _lib.plan_hyb_tiers(8, 8, 16, 4)
 

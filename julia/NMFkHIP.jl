@@ -22,6 +22,7 @@ import SparseArrays
 import SHA
 import Serialization
 import JLD
+import Printf
 
 const libnmfk = get(ENV, "NMFK_HIP_LIB", joinpath(@__DIR__, "..", "nmfk.jl_amd", "libnmfk_hip.so"))
 global_quiet = true
@@ -229,7 +230,9 @@ end
 # ---------------------------------------------------------------------------------------------------------------
 "getk (src/NMFkPostprocess.jl:7-41)"
 function getk(nkrange::Union{AbstractRange{T1},AbstractVector{T1}}, robustness::AbstractVector{T2}, cutoff::Number=0.5; strict::Bool=true) where {T1 <: Integer, T2 <: Number}
-	@assert length(nkrange) == length(robustness)
+	if length(nkrange) != length(robustness)                                          # Post:8-10: the full k-indexed vector
+		robustness = robustness[nkrange]
+	end
 	all(isnan.(robustness)) && return 0
 	if length(nkrange) == 1
 		return strict ? (robustness[end] > cutoff ? nkrange[end] : nothing) : nkrange[end]
@@ -533,6 +536,11 @@ function execute(X::AbstractArray{T,N}, nkrange::Union{Vector{Int},AbstractUnitR
 		load::Bool=true, save::Bool=true, casefilename::AbstractString="", dims=1:2, ngpus::Integer=1, device::Integer=0, kw...) where {T <: Number, N}
 	load, save, casefilename, mixture, method, algorithm, clusterWmatrix = input_checks(X, load, save, casefilename, mixture, method, algorithm, clusterWmatrix)
 	.*(size(X)...) == 0 && error("Input array has a zero dimension! Array size=$(size(X))")
+	if save                                                                           # Exec:185-192: the matrix next to its results, key "X"
+		xfile = joinpath(resultdir, "$(casefilename == "" ? "nmfk" : casefilename)_x_matrix_$(join(size(X), "_")).jld")
+		isdir(resultdir) || mkpath(resultdir)
+		JLD.save(xfile, "X", X)
+	end
 	maxk = maximum(collect(nkrange))
 	W = Vector{Matrix{T}}(undef, maxk); H = Vector{Matrix{T}}(undef, maxk)
 	fitquality = zeros(T, maxk); robustness = zeros(T, maxk); aic = zeros(T, maxk)
@@ -553,10 +561,10 @@ function execute(X::AbstractArray{T,N}, nkrange::Union{Vector{Int},AbstractUnitR
 		fit = size(W[nk]) == (size(X, 1), nk) && size(H[nk]) == (nk, size(X, 2)) ? frobenius(c, W[nk], H[nk]) : Inf
 		abs(fit - fitquality[nk]) > eps(Float16) && @warn("Fit quality is not consistent: $(fit) != $(fitquality[nk])")
 		fitquality[nk] = fit
-		println("Signals: $(nk) Fit: $(fitquality[nk]) Silhouette: $(robustness[nk]) AIC: $(aic[nk])")
+		println("Signals: $(Printf.@sprintf("%2d", nk)) Fit: $(Printf.@sprintf("%12.7g", fitquality[nk])) Silhouette: $(Printf.@sprintf("%12.7g", robustness[nk])) AIC: $(Printf.@sprintf("%12.7g", aic[nk]))")  # Exec:223
 	end
-	kopt = getk(collect(nkrange), robustness[nkrange], cutoff)                        # Exec:225
-	isnothing(kopt) ? @info("No optimal solution") : @info("Optimal solution: $kopt signals")
+	kopt = getk(nkrange, robustness[nkrange], cutoff)                                 # Exec:225
+	isnothing(kopt) ? @warn("No optimal solutions") : @info("Optimal solution: $kopt signals")  # Exec:226-230
 	return W, H, fitquality, robustness, aic, kopt
 end
 
@@ -653,7 +661,7 @@ function execute_many(c::Context, X::AbstractMatrix{T}, ks::Vector{Int}, nNMF::I
 			casefilename=casefilename, nanaction=nanaction, saveall=sv)
 		so = ordersignals ? signalorder(Wk, Hk) : collect(1:nk)                       # Exec:311-318
 		Wk = Wk[:, so]; Hk = Hk[so, :]
-		!quiet && println("Signals: $(nk) Fit: $(fitquality) Silhouette: $(robustness) AIC: $(aic) Signal order: $(so)")
+		!quiet && println("Signals: $(Printf.@sprintf("%2d", nk)) Fit: $(Printf.@sprintf("%12.7g", fitquality)) Silhouette: $(Printf.@sprintf("%12.7g", robustness)) AIC: $(Printf.@sprintf("%12.7g", aic)) Signal order: $(so)")  # Exec:322
 		if save                                                                       # Exec:323-327
 			filename = resultfile(resultdir, casefilename, X, nk, nNMF)
 			mkpath(resultdir)

@@ -496,7 +496,11 @@ def execute(X, nkrange, nNMF=10, opts=None, *, cutoff=0.5, clusterWmatrix=False,
     if rank0:
         if load or save:  # Exec:256-262 (the reference hashes X once per k; here once per call, when the cache is in use)
             xs = "_".join(str(v) for v in X.shape)
-            check_x_hash(X, os.path.join(resultdir, f"{casefilename or 'nmfk'}_x_matrix_{xs}{resultio.EXT}"), quiet=quiet)
+            xfile = os.path.join(resultdir, f"{casefilename or 'nmfk'}_x_matrix_{xs}{resultio.EXT}")
+            if save and not single and not _is_sparse(X):  # Exec:185-192: the range form keeps the matrix next to its results, key "X"
+                os.makedirs(resultdir, exist_ok=True)
+                resultio.save(xfile, X=np.asfortranarray(X))
+            check_x_hash(X, xfile, quiet=quiet)
         for nk in ks:  # Exec:264-303: per-k result cache
             fn = _result_filename(resultdir, casefilename, n, m, nk, nNMF)
             if load and not os.path.isfile(fn):  # Exec:266-269: old file-name convention

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Rebuilds the data matrix of the reference's feature-extraction notebook (notebooks/feature_extraction/feature_extraction.md)
+from what the notebook ships, and stores it with the notebook's printed known answers as tests/golden/feature_extraction.npz.
+
+The notebook's X = W * H (100 x 10): W = [s1 s2 s3 s4] with s1..s3 = (sin.(a:a:100a) .+ 1) ./ 2 for a = 0.05, 0.3, 0.5 (:56-58,
+exact) and s4 = rand(100) after Random.seed!(2021) -- Julia's RNG stream, not reproducible here --, H the printed 4 x 10 integer
+matrix (:110-121).  The notebook prints only 19 of the 100 rows of W and X, but it SHIPS its result for k = 4 in full precision:
+Wmatrix-4.csv = We[4] (100 x 4), Hmatrix-4.csv = He[4]' (10 x 4), with ||X - We[4] He[4]||_F = 0.0260611 (:262).  Hence
+    s4 = least squares of (We[4] He[4] - [s1 s2 s3] H[1:3, :]) on H[4, :]       (measured against the printed entries: <= 1.7e-3)
+which the 19 printed entries of s4 (:62-82) confirm (asserted below), and X = [s1 s2 s3 s4] H is the notebook's construction with
+its own fourth signal to ~2e-3 -- the printed entries of X (:139-161, 6 s.f.) are asserted too.
+Run in the build container (needs /root/reference); only DATA of the reference is read (CSV result files, printed numbers)."""
+import os, re
+import numpy as np
+
+REF = "/root/reference/notebooks/feature_extraction"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+def csv(name):
+    rows = [ln.strip().split(",") for ln in open(os.path.join(REF, name)).read().strip().splitlines()[1:]]
+    return np.array([[float(v) for v in r[1:]] for r in rows])
+
+We = csv("Wmatrix-4.csv")          # 100 x 4
+He = csv("Hmatrix-4.csv").T        # 4 x 10
+assert We.shape == (100, 4) and He.shape == (4, 10)
+i = np.arange(1, 101)
+S = np.stack([(np.sin(a * i) + 1) / 2 for a in (0.05, 0.3, 0.5)], axis=1)
+H = np.array([[1, 5, 0, 0, 1, 1, 2, 1, 0, 2], [0, 1, 1, 5, 2, 1, 0, 0, 2, 3], [3, 0, 0, 1, 0, 1, 0, 5, 4, 3], [1, 1, 4, 1, 5, 0, 1, 1, 5, 3]], dtype=np.float64)
+Xr = We @ He
+s4 = (Xr - S @ H[:3]) @ H[3] / (H[3] @ H[3])
+# the 19 rows of W the notebook prints (first 10, last 9): columns s1, s2, s3 (exact) and s4
+md = open(os.path.join(REF, "feature_extraction.md")).read()
+blk = md[md.index("100×4 Matrix{Float64}:"):]
+blk = blk[:blk.index("The singals look like this")]
+rows = [[float(v) for v in ln.split()] for ln in blk.splitlines()[1:] if re.match(r"^\s+[\d.]", ln) and len(ln.split()) == 4]
+assert len(rows) == 19
+printed = np.array(rows)
+idx = list(range(10)) + list(range(91, 100))
+assert np.max(np.abs(printed[:, :3] - S[idx]) / np.maximum(np.abs(S[idx]), 1e-300)) < 2e-5   # 6 s.f. print of exact sines
+err4 = np.max(np.abs(printed[:, 3] - s4[idx]))
+print("s4: largest deviation from the 19 printed entries", err4)
+assert err4 < 3e-3
+s4[idx] = printed[:, 3]            # where the notebook prints its value, take it (6 s.f.)
+s4 = np.clip(s4, 0.0, 1.0)
+W = np.concatenate([S, s4[:, None]], axis=1)
+X = W @ H
+# printed entries of X (:139-161): first four and last three columns of the same 19 rows
+blk = md[md.index("100×10 Matrix{Float64}:"):]
+blk = blk[:blk.index("The data matrix `X` looks like this")]
+xr = [[float(v) for v in ln.replace("…", " ").split()] for ln in blk.splitlines()[1:] if re.match(r"^\s+[\d.]", ln)]
+xr = np.array([r for r in xr if len(r) == 7])
+assert xr.shape == (19, 7)
+dev = np.max(np.abs(xr - X[idx][:, [0, 1, 2, 3, 7, 8, 9]]))
+print("X: largest deviation from the printed entries", dev)
+assert dev < 5e-5 * 10              # 6 s.f. of entries < 10
+print("||X - We[4] He[4]||_F =", np.linalg.norm(X - Xr), "(notebook: 0.0260611)")
+np.savez_compressed(os.path.join(HERE, "feature_extraction.npz"), X=X, s4=s4, printed_rows=np.array(idx),
+                    nkrange=np.arange(2, 11), kopt=4,
+                    fit_printed=np.array([563.4562, 205.1045, 0.0260611, 0.01929668, 0.006752373, 0.006230307, 0.004256726, 0.009267875, 0.004952552]),
+                    silhouette_printed=np.array([0.9961238, 0.9877389, 0.9951292, -0.6128532, -0.612744, -0.7747081, -0.6025868, -0.5954714, -0.6026156]),
+                    of_min_max_k2=np.array([563.4561839705091, 571.0956047569299]), of_min_max_k3=np.array([205.10453576810346, 205.44013709359942]))
+print("wrote", os.path.join(HERE, "feature_extraction.npz"))

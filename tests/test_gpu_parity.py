@@ -621,6 +621,25 @@ def test_execute_bss_notebook(NMFk, oracle, bss_X):
     assert list(np.argsort(-np.asarray(rob[1:5]))[:2]) == list(np.argsort(-np.asarray(rob_o[1:5]))[:2])
 
 
+def test_execute_feature_extraction_notebook(NMFk, oracle):
+    """notebooks/feature_extraction/feature_extraction.md:197-292 through the GPU path (the matrix and the tolerances of
+    tests/test_oracle_golden.py::test_feature_extraction_notebook_known_answers): kopt = 4, the silhouettes of k = 2, 3, 4 at the
+    printed values, negative beyond, the same set of ranks above the cutoff; and the oracle from the same seeds agrees."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feature_extraction.npz"))
+    X = np.asfortranarray(z["X"].astype(np.float32))
+    sil_ref, fit_ref = z["silhouette_printed"], z["fit_printed"]
+    W, H, fit, rob, aic, kopt = NMFk.execute(X, range(2, 11), 10, load=False, save=False, quiet=True, seed=2021)
+    assert kopt == 4
+    assert abs(rob[1] - sil_ref[0]) < 3e-3 and abs(rob[2] - sil_ref[1]) < 6e-3 and abs(rob[3] - sil_ref[2]) < 5e-2 and rob[3] > 0.9
+    assert all(rob[k - 1] < -0.2 for k in range(5, 11))
+    assert abs(float(fit[1]) ** 2 - fit_ref[0]) < 1e-3 * fit_ref[0] and abs(float(fit[2]) ** 2 - fit_ref[1]) < 2e-3 * fit_ref[1]
+    Wo, Ho, fit_o, rob_o, aic_o, kopt_o, det_o = oracle.execute(X, range(2, 11), 10, seed=2021)
+    assert kopt_o == kopt
+    np.testing.assert_allclose(fit[1:3], fit_o[1:3], rtol=1e-3)
+    assert abs(rob[1] - rob_o[1]) < 3e-3 and abs(rob[2] - rob_o[2]) < 6e-3
+    assert [k for k in range(2, 11) if rob[k - 1] > 0.5] == [k for k in range(2, 11) if rob_o[k - 1] > 0.5] == [2, 3, 4]
+
+
 def test_execute_single_k_and_nk1(NMFk, oracle):
     # test/test_execute_smoke.jl:22-32
     X = np.abs(np.random.default_rng(321).standard_normal((6, 5))).astype(np.float32)
@@ -659,6 +678,13 @@ def test_execute_cache_roundtrip(NMFk, tmp_path):
     with pytest.warns(UserWarning):
         r4 = NMFk.execute(X + 1, 2, 3, casefilename="case", resultdir=str(tmp_path), quiet=True, seed=5, maxiter=30)
     np.testing.assert_array_equal(r4[0], r3[0])
+    # Exec:185-192: the range form with save=true keeps the matrix next to its results -- <case>_x_matrix_<n>_<m>.jld, key "X"
+    assert not os.path.isfile(tmp_path / "case_x_matrix_8_6.jld")  # (the one-k form does not write it: Exec:255-262)
+    NMFk.execute(X, range(2, 4), 2, casefilename="rng", resultdir=str(tmp_path), quiet=True, seed=1, maxiter=30)
+    zx = resultio.load(str(tmp_path / "rng_x_matrix_8_6.jld"))
+    assert list(zx) == ["X"] and zx["X"].dtype == np.float32
+    np.testing.assert_array_equal(zx["X"], X)
+    assert os.path.isfile(tmp_path / "rng_x_matrix_8_6.jld.sha256")
 
 
 def test_saveall_loadall_payload(NMFk, oracle, tmp_path):

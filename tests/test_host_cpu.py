@@ -218,7 +218,7 @@ def test_julia_shim_calls_only_functions_that_exist():
         collect convert copy count dirname enumerate eps error falses finalizer findfirst findlast findmax get haskey isfile isnan
         isnothing join joinpath length log map max maximum min minimum mkpath new ones permutedims pointer println push! rand read
         setproperty! similar size sizeof sortperm sqrt stride strip sum take! throw trues typeof unsafe_string vec write zeros
-        floor round isempty isinf filter first last reshape hcat vcat string repr get! pop! keys values pairs zip range iszero""".split())
+        floor round isempty isinf filter first last reshape hcat vcat string repr get! pop! keys values pairs zip range iszero isdir""".split())
     calls = {mm.group(1) for mm in re.finditer(r"(?<![\.\w:@])([A-Za-z_]\w*!?)\(", code)}
     unknown = sorted(calls - defs - base)
     assert not unknown, f"julia/NMFkHIP.jl calls names that are neither defined in the file nor known Base functions: {unknown}"
@@ -226,6 +226,32 @@ def test_julia_shim_calls_only_functions_that_exist():
     imported |= {q.split(".")[0] for q in imported}
     for mm in re.finditer(r"(?<![\.\w])([A-Z]\w*)\.(\w+!?)\(", code):
         assert mm.group(1) in imported, f"{mm.group(1)}.{mm.group(2)}(...) but {mm.group(1)} is not imported in julia/NMFkHIP.jl"
+
+
+def test_julia_shim_prints_and_decides_like_the_reference():
+    """Static (no julia here): the user-visible lines and the kopt rule of julia/NMFkHIP.jl are the reference's --
+    Exec:223, 322: `Signals: %2d Fit: %12.7g Silhouette: %12.7g AIC: %12.7g` through Printf.@sprintf; Exec:227:
+    @warn("No optimal solutions"); Post:8-10: getk re-indexes a full k-indexed robustness vector by nkrange;
+    Exec:185-192: the range form writes the matrix as <case>_x_matrix_<n>_<m>.jld under the key "X" when save = true."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jl = open(os.path.join(root, "julia", "NMFkHIP.jl")).read()
+    assert re.search(r"^import Printf$", jl, flags=re.M)
+    lines = [ln for ln in jl.splitlines() if 'println("Signals:' in ln]
+    assert len(lines) == 2
+    for ln in lines:
+        assert ln.count('Printf.@sprintf("%12.7g"') == 3 and 'Printf.@sprintf("%2d", nk)' in ln, ln
+    assert "Signal order: $(so)" in lines[1] and "Signal order" not in lines[0]
+    assert '@warn("No optimal solutions")' in jl and "No optimal solution\")" not in jl
+    body = jl[jl.index("function getk("):]
+    body = body[:body.index("\nend\n")]
+    assert "robustness = robustness[nkrange]" in body and "@assert length(nkrange) == length(robustness)" not in body
+    assert re.search(r'if save\b[^\n]*\n\s*xfile = joinpath\(resultdir, "\$\(casefilename == "" \? "nmfk" : casefilename\)_x_matrix_\$\(join\(size\(X\), "_"\)\)\.jld"\)', jl)
+    assert 'JLD.save(xfile, "X", X)' in jl
+    # the Python mirror prints the same formats (C's %2d / %12.7g are Printf's)
+    py = open(os.path.join(root, "nmfk.jl_amd", "execute.py")).read()
+    assert py.count("Signals: %2d Fit: %12.7g Silhouette: %12.7g AIC: %12.7g") == 2
 
 
 def _julia_function_kwargs(jl, head):

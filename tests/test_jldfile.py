@@ -175,3 +175,17 @@ def test_kmeans_result_struct_is_written_like_julia(tmp_path):
                 assert flags == 3 and Rx.buf[p + 8:p + 10] == b"\x02\x02"
                 assert struct.unpack_from("<Q", Rx.buf, p + 10)[0] == types["children"]["00000001"]["header"]
             p += 8 + msize
+
+
+def test_x_matrix_file_roundtrip(tmp_path):
+    """Exec:185-192: `JLD.save(xfile, "X", X)` -- the analysed matrix as `<case>_x_matrix_<n>_<m>.jld` with the single key "X"
+    (what execute(X, nkrange; save=true) writes next to the per-k results); a Float32 Matrix like the W / H of those files."""
+    from nmfk_jl_amd import resultio
+
+    X = np.asfortranarray(np.random.default_rng(3).random((7, 5)).astype(np.float32))
+    fn = str(tmp_path / "nmfk_x_matrix_7_5.jld")
+    resultio.save(fn, X=X)
+    z = resultio.load(fn)
+    assert list(z) == ["X"] and z["X"].dtype == np.float32 and z["X"].shape == (7, 5)
+    np.testing.assert_array_equal(z["X"], X)
+    assert not [f for f in os.listdir(tmp_path) if ".tmp" in f]  # (written to a temporary name, then renamed)

@@ -834,7 +834,7 @@ static int hyb_res_wgs_legacy(int L, int D, int cus, int vmax, int units) {
 }
 // [0] = H half-step (lanes = m columns, loop = n rows), [1] = W half-step
 HybPlan plan_hyb_group(int n, int m, int cus, const HybMix &mix, int target_wgs, bool hyb_res, bool legacy = false,
-                       const int (*exp_geo)[3] = nullptr) {
+                       const int (*exp_geo)[3] = nullptr, bool one_round = false) {
   HybPlan p;
   const int units = std::max(1, mix.units()), vmax = mix.vmax();
   p.units = units;
@@ -857,15 +857,23 @@ HybPlan plan_hyb_group(int n, int m, int cus, const HybMix &mix, int target_wgs,
     } else {
       double best = 1e30;
       const bool can_res = hyb_res && nmfk_hyb_resident_lds(vmax, D) != 0;
-      if (can_res) {  // (where the loop factor fits the LDS the resident form is the better kernel at every size measured)
+      if (can_res) {
+        // As a COHORT's launch (another cohort's launches run beside it) the resident form does best with ONE round of workgroups --
+        // measured: cohorts of 60 / 30 / 15 units: 4 / 8 / 16 workgroups per unit, ~240 on 256 CUs each time, where a launch alone
+        // on the chip wants ~480 (profiles/r05/geometry_scan.txt) -- the other cohort is the second round.
         const int ntp = (L + 31) / 32, rw = nmfk_hyb_resident_waves(), gmax = std::max(1, ntp / rw);
-        for (int g = std::max(1, ntp / (rw * Tuning::hyb_res_tpw)); g <= gmax; ++g) {
+        const int gmin = std::max(1, ntp / (rw * Tuning::hyb_res_tpw));
+        for (int g = gmin; g <= gmax; ++g) {
+          if (one_round && g > gmin && (int64_t)g * units > cus) break;
           double b;
           const double c = hyb_res_cost(mix, L, D, cus, g, &b);
           if (dbg) fprintf(stderr, "[nmfk]   %c half-step, %d units: resident g %d: %.1f us (busy %.2f)\n", "HW"[which], units, g, c, b);
           if (c < best * 0.97) best = c, res = g, p.busy[which] = b;
         }
-      } else {
+      }
+      // (where the loop factor fits the LDS the resident form is the better kernel from a handful of units up; a unit or two are
+      //  served faster by the streaming form with the loop range split: more, shorter workgroups)
+      if (!can_res || units <= 2) {
         static const int Ss[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32, 48, 64};
         for (int w : {1, wsN})
           for (int Sq : Ss) {
@@ -873,7 +881,7 @@ HybPlan plan_hyb_group(int n, int m, int cus, const HybMix &mix, int target_wgs,
             double b;
             const double c = hyb_stream_cost(mix, L, D, cus, w, Sq, &b);
             if (dbg) fprintf(stderr, "[nmfk]   %c half-step, %d units: streaming wsplit %d S %d: %.1f us (busy %.2f)\n", "HW"[which], units, w, Sq, c, b);
-            if (c < best * 0.97) best = c, ws = w, S = Sq, p.busy[which] = b;
+            if (c < best * 0.97) best = c, ws = w, S = Sq, res = 0, p.busy[which] = b;
           }
       }
       p.us[which] = best;
@@ -928,7 +936,7 @@ static HybCohortPlan plan_hyb_cohorts(int n, int m, int cus, const HybMix &mix, 
   r.cohorts = std::max(1, std::min(r.cohorts, mix.units()));
   if (r.cohorts > 1 && model) {
     const int units = mix.units();
-    r.plan = plan_hyb_group(n, m, cus, mix.scaled((units + r.cohorts - 1) / r.cohorts), T.target_wgs, hyb_res, false, T.exp_geo);
+    r.plan = plan_hyb_group(n, m, cus, mix.scaled((units + r.cohorts - 1) / r.cohorts), T.target_wgs, hyb_res, false, T.exp_geo, true);
     r.plan.units = units;
   }
   return r;

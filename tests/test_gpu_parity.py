@@ -371,7 +371,7 @@ def test_resident_form_of_the_mfma_half_step(NMFk, ctx, oracle, shape, monkeypat
     n, m = shape
     X = (0.05 + oracle.uniform_fill(37, 0, n * m)).reshape(n, m).astype(np.float32)
     ctx.set_X(X)
-    for ks, R in ((list(range(2, 17)), 3), ([4, 8, 16], 40), ([3], 1)):
+    for ks, R in ((list(range(2, 17)), 3), ([4, 8, 16], 40), ([3], 3)):  # (one or two units: the planner prefers the streaming form, round 5)
         iters = 30
         seeds = _seeds(NMFk, 17, ks, R)
         monkeypatch.setenv("NMFK_HYB", "1")

@@ -497,7 +497,8 @@ def test_retire_aware_tiers_are_consistent_launch_geometries(monkeypatch):
         t = byu[units]
         assert t["H"]["wsplit"] == 1 and t["H"]["S"] in S_ok and t["W"]["res"] in res_ok, t
     assert byu[120]["cohorts"] == 2 and byu[60]["cohorts"] == 2 and byu[30]["cohorts"] == 2 and byu[1]["cohorts"] == 1
-    assert byu[1]["W"]["res"] == 16  # (BASELINE configs[1], one unit: one pair of lane tiles per wave, 62 -> 45 us per iteration)
+    assert byu[4]["W"]["res"] == 16 and byu[1]["W"]["res"] == 0  # (one pair of lane tiles per wave; BASELINE configs[1], one unit: the
+    # streaming form with more, shorter workgroups -- 62 -> 44 us per iteration)
     # a narrow matrix (64 columns: a quarter of a shared-staging workgroup's lanes) keeps the per-wave form for the H half-step
     assert _lib.plan_hyb_tiers(4096, 64, 0, 480)[0]["H"]["wsplit"] == 8
     # NMFK_TARGET_WGS keeps the threshold rule of rounds 2-4 (tests force split geometries with it)

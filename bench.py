@@ -29,23 +29,29 @@ PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 
 
-TRAFFIC_FILES = ("profiles/r04/traffic.json", "profiles/r03/traffic.json", "profiles/r02/traffic.json")
+TRAFFIC_FILES = ("profiles/r05/traffic.json", "profiles/r04/traffic.json", "profiles/r03/traffic.json", "profiles/r02/traffic.json")
 
 
-def _pmc_traffic():
+def _pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel: FETCH_SIZE x 2 + WRITE_SIZE from separate `rocprofv3 --pmc` passes of
     this command (scripts/profile_bench.sh, scripts/make_traffic.py).  PMC passes cannot run inside the timed bench, so
-    this is a STATIC figure read from the newest committed file -- the line says which (`traffic_source`).
+    this is a STATIC figure read from the newest committed file -- the line says which (`traffic_source`) -- and only a file
+    whose `kernel` IS the kernel this run timed counts (`kernel`: a name like "hyb_res_kernel"; a file of another kernel, or
+    without the field, is refused: the figure would go stale silently when the kernels change).
     -> (bytes or None, source string)"""
+    refused = []
     for rel in TRAFFIC_FILES:
         try:
             with open(os.path.join(ROOT, rel)) as fh:
                 t = json.load(fh)
-            return float(t["hbm_bytes_per_launch"]), f"{rel} (static: rocprofv3 --pmc passes of an earlier run of this command" + \
-                (f", kernel {t['kernel']}" if "kernel" in t else "") + ")"
         except Exception:
             continue
-    return None, "absent"
+        if not kernel or kernel not in str(t.get("kernel", "")):
+            refused.append(f"{rel} (kernel {t.get('kernel', '?')!r})")
+            continue
+        return float(t["hbm_bytes_per_launch"]), (f"{rel} (static: rocprofv3 --pmc passes of an earlier run of this command, kernel "
+                                                  f"{t['kernel']})")
+    return None, "absent for kernel " + repr(kernel) + ("; refused: " + ", ".join(refused) if refused else "")
 
 
 def julia_reference_baseline(n, m, ks, nruns):
@@ -210,11 +216,15 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-kopt-check", action="store_true", help="skip the planted-matrix 'same kopt' sweeps after the timed region")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg4 (sparse) / cfg5 (k = 64) measurements after the timed region")
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("NMFK_BENCH_BUDGET_S", "380")),
+                    help="wall seconds the whole run may take: the measurements BEHIND the timed region (same-kopt sweeps, secondary "
+                         "workloads) run in order of importance while the run stays inside it, the rest is reported as skipped")
     ap.add_argument("--loopback", action="store_true",
                     help="REHEARSAL of the N > 1 path on ONE GPU: --gpus N logical ranks in this one process through libnmfk_hip's "
                          "loopback transport (nmfk_multi_create_loopback): shard plan, padding, status agreement, all-gather layout "
                          "and delivery are the code RCCL runs; the number is not a multi-GPU measurement")
     args = ap.parse_args()
+    t_start = time.perf_counter()
 
     import torch
     import nmfk_jl_amd as NMFk
@@ -249,12 +259,16 @@ def main():
     # execute() its shape); the DEVICE copy every rank computes on comes from rank 0 over RCCL
     X = np.asfortranarray(ctx.fill_uniform(1, 0, args.n * args.m).reshape(args.m, args.n).T)
     comm = None
+    bcast_prof = None
     if world > 1 and backend == "nccl":
         # the N > 1 data path is the C ABI's: nmfk_comm_create (unique id through torch.distributed), ncclBroadcast of X,
         # restarts sharded inside libnmfk_hip, ONE ncclAllGather of the device result buffers per sweep
         try:
             comm = NMFk.parallel.attach(ctx)
+            ctx.set_profiling(True)  # (the broadcast of X is timed too: "comm_bcast_X" of nmfk_get_profile)
             comm.bcast_X(X if rank == 0 else None, root=0)
+            bcast_prof = ctx.get_profile().get("comm_bcast_X")
+            ctx.set_profiling(False)
         except Exception as e:  # fail loudly with the rank: a silent hang in the next collective helps nobody
             print(f"[bench rank {rank}/{world}] joining the RCCL communicator failed: {e!r}", file=sys.stderr, flush=True)
             raise
@@ -262,7 +276,10 @@ def main():
         X = np.asfortranarray(NMFk.parallel.broadcast_X(X if rank == 0 else None))
         ctx.set_X(X)
     elif multi is not None:
+        ctx.set_profiling(True)
         multi.set_X(X)  # every logical rank's context holds X (nmfk_multi_set_X: the broadcast of the loopback transport)
+        bcast_prof = ctx.get_profile().get("comm_bcast_X")
+        ctx.set_profiling(False)
     else:
         ctx.set_X(X)  # X resident in HBM (column-major + row-major copies) before the timed region
 
@@ -295,6 +312,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = ctx.get_profile() if not args.no_profile else {}
+    # N > 1: what the communication cost, per rank (nmfk_get_profile "comm_*": host wall time of the steps of nmfk_mu_sweep_sharded /
+    # nmfk_comm_bcast on each rank, bytes in the `flops` field), gathered on rank 0
+    comm_all = None
+    if (world > 1 or multi is not None) and prof:
+        mine = {k_: v for k_, v in prof.items() if k_.startswith("comm_")}
+        if world > 1:
+            comm_all = [None] * world
+            dist.all_gather_object(comm_all, mine)
+        else:
+            comm_all = [mine]
     W, H, fit, rob, aic, kopt, details = out
     nfact = len(ks) * args.nruns
     value = args.steps * nfact / dt
@@ -316,6 +343,31 @@ def main():
                        "kopt": kopt,
                        "mean_iterations_per_factorization": total_iters / nfact},
         }
+        if comm_all:
+            def per_sweep(name, f=max):  # ms per sweep (the timed steps), over the ranks
+                v = [c_[name]["ms"] / args.steps for c_ in comm_all if name in c_]
+                return f(v) if v else None
+
+            ag = [c_["comm_allgather"] for c_ in comm_all if "comm_allgather" in c_]
+            lw = [c_["comm_bcast"] for c_ in comm_all if "comm_bcast" in c_]
+            line["comm"] = {
+                "transport": "RCCL (ncclBroadcast / ncclAllGather behind the C ABI)" if comm is not None else
+                             ("loopback (N logical ranks on ONE GPU: device-to-device copies + a host barrier; a rehearsal, no xGMI)" if multi is not None
+                              else f"torch.distributed {backend} (host rehearsal)"),
+                "rccl_ranks": world if comm is not None else (args.gpus if multi is not None else 0),
+                "ranks_reporting": len(comm_all),
+                "bcast_X_ms": bcast_prof["ms"] if bcast_prof else None, "bcast_X_bytes": bcast_prof["flops"] if bcast_prof else None,
+                "slowest_rank_sweep_s": (per_sweep("comm_local_sweep", max) or 0) / 1e3, "fastest_rank_sweep_s": (per_sweep("comm_local_sweep", min) or 0) / 1e3,
+                "wait_for_slowest_rank_ms_per_sweep": per_sweep("comm_wait_for_ranks", max),
+                "allgather_ms_per_sweep": per_sweep("comm_allgather", max),
+                "allgather_bytes_received_per_rank_and_sweep": (ag[0]["flops"] / args.steps) if ag else None,
+                "deliver_ms_per_sweep": per_sweep("comm_deliver", max),
+                "lean_W_bcast_ms_per_sweep": per_sweep("comm_bcast", max), "lean_W_bcasts_per_sweep": (lw[0]["launches"] / args.steps) if lw else 0,
+                "lean_W_bytes_per_sweep": (lw[0]["flops"] / args.steps) if lw else 0,
+                "note": "host wall time of the steps of nmfk_mu_sweep_sharded / nmfk_comm_bcast (libnmfk_hip, nmfk_get_profile 'comm_*'), maximum over "
+                        "the ranks unless named otherwise; local sweep = a rank's share of the restarts (no collective inside the MU loop); wait = the "
+                        "status agreement behind it, i.e. the time the fastest rank waits for the slowest; all-gather = H, objective, iteration counts of "
+                        "every restart (W stays with its owner: best = true); lean W = the winning restart's W from its owner, once per rank k"}
         if prof and "mu_loop" in prof and prof["mu_loop"]["ms"] > 0:
             # Round-3 schedule: every factorization of the sweep (ranks 2..16) runs on the split-operand MFMA half-step, ALL
             # units in one launch per half-step (the kernels switch between their rank variants per workgroup):
@@ -338,8 +390,20 @@ def main():
                      "note": "algorithmic flops of ALL half-step launches / GPU time of the whole MU loop (HIP events), check blocks included"}
             kernel_of = {"h_step<mfma>": "hyb_step_kernel<2,8,0> (nmfk_step_hyb.hip, streaming form; <2,8,2> = the same with the monitored objective as a by-product behind a check iteration): the H half-step of ALL units of the sweep in one launch",
                          "w_step<mfma>": "hyb_res_kernel<2,false,false,false> (nmfk_step_hyb.hip, resident form: the loop factor H in LDS): the W half-step of ALL units of the sweep in one launch"}
-            traffic, tsrc = _pmc_traffic()
-            if dom in kernel_of:
+            traffic, tsrc = _pmc_traffic({"h_step<mfma>": "hyb_step_kernel", "w_step<mfma>": "hyb_res_kernel"}.get(dom))
+            sched = ctx.last_sweep_info()
+            if dom in kernel_of and sched.get("cohorts", 1) > 1:
+                # the units run as cohorts on several streams (few-unit sweeps: a rank's share at N > 1): launches overlap, a sampled
+                # launch's duration is not exclusive GPU time -- the line's fraction is the whole MU loop's
+                line["roofline"] = {
+                    "kernel": kernel_of["w_step<mfma>"] + " + " + kernel_of["h_step<mfma>"] + f" -- as {sched['cohorts']} cohorts of units on "
+                              "concurrent streams (nmfk_mu_sweep, 'Cohorts')",
+                    "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
+                    "traffic": None, "traffic_source": "not attributed: the launches of the cohorts overlap",
+                    "whole_mu_loop": whole, "sampled_launches_overlapping": per_kp,
+                    "note": "algorithmic flops of all half-step launches (4*n*m*k per half-step per ACTIVE restart) / GPU time of the MU loop; "
+                            "the per-launch durations under `sampled_launches_overlapping` include time shared with the other cohort"}
+            elif dom in kernel_of:
                 d = prof[dom]
                 tfd = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 other = [k_ for k_ in kernel_of if k_ != dom and k_ in prof and prof[k_]["launches"]]
@@ -375,70 +439,104 @@ def main():
                     "x_GBps_if_every_restart_streamed_X": xbytes / (loop["ms"] * 1e-3) / 1e9,
                     "x_GBps_note": "on-die figure (L2 / Infinity Cache), not HBM traffic",
                 }
-            line["config"]["schedule"] = ctx.last_sweep_info()
-        if not args.no_kopt_check and world == 1 and multi is None and (args.n, args.m, args.kmin, args.kmax, args.nruns) == (8192, 512, 2, 16, 32):
-            # "same kopt" half of the metric, outside the timed region: SURVEY 8d's planted rank-6 matrix through the same
-            # sweep in fp32 (the product) and in fp64 compute (the reference's arithmetic and stop decisions,
-            # oracle-verified by tests/test_gpu_parity.py::test_stop_rule_fp64_identical_iterations)
-            k0 = 6
+            line["config"]["schedule"] = sched
+        # ---- behind the timed region, rank 0, in order of importance, while the run stays inside --budget-s (the driver's run of
+        # 20 + 5 steps is ~355 s of sweeps and is cut at 600 s; VERDICT r4: stay under 380 s).  What does not fit is listed under
+        # `skipped` with the committed line that holds it (profiles/r05/bench_full_line.json: the same command with fewer steps).
+        skipped = []
+
+        def fits(name, est_s):
+            left = args.budget_s - (time.perf_counter() - t_start)
+            if est_s <= left:
+                return True
+            skipped.append(f"{name} (~{est_s:.0f} s; {left:.0f} s of the {args.budget_s:.0f} s budget left)")
+            return False
+
+        if not args.no_cpu_baseline:  # (~1 s)
+            threads = min(32, len(os.sched_getaffinity(0)))
+            line["cpu_baseline"] = cpu_baseline(X, ks, args.nruns, iters_by_k, threads)
+            line["cpu_baseline"]["reference_julia"] = julia_reference_baseline(args.n, args.m, ks, args.nruns)
+        default_cfg = world == 1 and multi is None and (args.n, args.m, args.kmin, args.kmax, args.nruns) == (8192, 512, 2, 16, 32)
+        sweep_s = dt / args.steps
+        k0 = 6
+
+        def planted_sweep(Xp, nruns=args.nruns, **kw):
+            t = time.perf_counter()
+            o = NMFk.execute(Xp, ks, nruns, load=False, save=False, quiet=True, seed=2, ctx=ctx, return_details=True, **kw)
+            sec = time.perf_counter() - t
+            its = np.concatenate([o[6][k]["iters"] for k in ks]).astype(np.float64)
+            return dict(kopt=o[5], seconds=sec, factorizations_per_s=len(ks) * nruns / sec, mean_iterations=float(its.mean()),
+                        min_iterations=int(its.min()), max_iterations=int(its.max()),
+                        active_unit_fraction=float(its.sum() / (its.max() * len(its))), schedule=ctx.last_sweep_info(),
+                        robustness=[float(v) for v in o[3][ks[0] - 1:]])
+
+        if not args.no_kopt_check and default_cfg:
             ctx.set_profiling(False)
-
-            def planted_sweep(Xp, nruns=args.nruns, **kw):
-                t = time.perf_counter()
-                o = NMFk.execute(Xp, ks, nruns, load=False, save=False, quiet=True, seed=2, ctx=ctx, return_details=True, **kw)
-                sec = time.perf_counter() - t
-                its = np.concatenate([o[6][k]["iters"] for k in ks]).astype(np.float64)
-                return dict(kopt=o[5], seconds=sec, factorizations_per_s=len(ks) * nruns / sec, mean_iterations=float(its.mean()),
-                            min_iterations=int(its.min()), max_iterations=int(its.max()),
-                            active_unit_fraction=float(its.sum() / (its.max() * len(its))), schedule=ctx.last_sweep_info())
-
-            Xp = planted_matrix(ctx, args.n, args.m, k0)
-            ctx.set_X(Xp)
-            p32 = planted_sweep(Xp)
-            # (fp64 compute: 8 restarts per rank -- the packed-VALU fp64 kernels take 63 s for all 32, and the full-size agreement
-            #  of the two modes is tests/test_gpu_fullsize.py::test_planted_rank6_same_kopt_at_metric_size)
-            p64 = planted_sweep(Xp, compute="f64", nruns=8)
-            line["config"]["kopt_planted"] = p32["kopt"]
-            line["config"]["kopt_planted_f64_mode"] = p64["kopt"]
-            line["config"]["kopt_planted_expected"] = k0
-            # Structured data on which the restarts RETIRE (the bench matrix and the matrix above run nearly every restart to
-            # maxiter): the stop rule's tolOF = 1e-3 is an absolute improvement of the sum of squares (Mult:24, 81), so the same
-            # planted matrix with its entries scaled to ~0.15 (X = 0.1 * (W0 H0 + 0.01 U)) stagnates between 1 000 and 10 000
-            # iterations.  Same sweep with the retire-aware schedule (default) and with the static one (NMFK_REPLAN=0).
-            Xs = planted_matrix(ctx, args.n, args.m, k0, scale=0.1)
-            ctx.set_X(Xs)
-            ps = planted_sweep(Xs)
-            os.environ["NMFK_REPLAN"] = "0"
-            try:
-                ps0 = planted_sweep(Xs)
-            finally:
-                del os.environ["NMFK_REPLAN"]
-            line["config"]["planted"] = {
-                "matrix": f"X = W0 H0 + 0.01 U (rank {k0}, {args.n}x{args.m}; SURVEY 8d), k={args.kmin}:{args.kmax}, nruns={args.nruns}, "
-                          "default stop rule, whole execute() incl. clustering",
-                **{k_: p32[k_] for k_ in ("kopt", "seconds", "factorizations_per_s", "mean_iterations", "min_iterations", "max_iterations",
-                                           "active_unit_fraction")},
-                "f64_mode": {"nruns": 8, "kopt": p64["kopt"], "seconds": p64["seconds"]},
-                "retiring": {"matrix": "X = 0.1 * (W0 H0 + 0.01 U): the same matrix scaled so that the ABSOLUTE tolOF = 1e-3 of the "
-                                       "reference's stop rule (Mult:24, 81) retires restarts between 1 000 and 10 000 iterations",
-                             **ps, "static_schedule_seconds": ps0["seconds"], "static_schedule_kopt": ps0["kopt"],
-                             "speedup_of_the_retire_aware_schedule": ps0["seconds"] / ps["seconds"]},
-            }
-            ctx.set_X(X)
+            # (1) "same kopt" half of the metric: SURVEY 8d's planted rank-6 matrix through the same sweep in fp32 (the product)
+            if fits("config.kopt_planted: planted rank-6 sweep, fp32", 1.1 * sweep_s + 2):
+                Xp = planted_matrix(ctx, args.n, args.m, k0)
+                ctx.set_X(Xp)
+                p32 = planted_sweep(Xp)
+                line["config"]["kopt_planted"] = p32["kopt"]
+                line["config"]["kopt_planted_expected"] = k0
+                line["config"]["planted"] = {
+                    "matrix": f"X = W0 H0 + 0.01 U (rank {k0}, {args.n}x{args.m}; SURVEY 8d), k={args.kmin}:{args.kmax}, nruns={args.nruns}, "
+                              "default stop rule, whole execute() incl. clustering",
+                    **{k_: p32[k_] for k_ in ("kopt", "seconds", "factorizations_per_s", "mean_iterations", "min_iterations", "max_iterations",
+                                               "active_unit_fraction", "robustness")}}
+                ctx.set_X(X)
         if not args.no_secondary and world == 1 and multi is None:
-            # the other two single-GPU BASELINE workloads, outside the timed region: driver-visible numbers
+            # (2) the other single-GPU BASELINE workloads: driver-visible numbers
             sec = {}
-            for name, fn in (("cfg2", lambda N_, c_: secondary_cfg2(N_, c_, X)), ("cfg4", secondary_cfg4), ("cfg5", secondary_cfg5)):
+            for name, fn, est in (("cfg2", lambda N_, c_: secondary_cfg2(N_, c_, X), 3), ("cfg5", secondary_cfg5, 9), ("cfg4", secondary_cfg4, 14)):
+                if not fits(f"secondary.{name}", est):
+                    sec[name] = {"skipped": "time budget (--budget-s); see profiles/r05/bench_full_line.json"}
+                    continue
                 try:
                     sec[name] = fn(NMFk, ctx)
                 except Exception as e:  # noqa: BLE001  (the headline line must not be lost to a secondary measurement)
                     sec[name] = {"error": repr(e)}
             line["secondary"] = sec
             ctx.set_X(X)
-        if not args.no_cpu_baseline:
-            threads = min(32, len(os.sched_getaffinity(0)))
-            line["cpu_baseline"] = cpu_baseline(X, ks, args.nruns, iters_by_k, threads)
-            line["cpu_baseline"]["reference_julia"] = julia_reference_baseline(args.n, args.m, ks, args.nruns)
+        if not args.no_kopt_check and default_cfg:
+            ctx.set_profiling(False)
+            # (3) kopt of the HEADLINE matrix in fp64 compute (the reference's arithmetic and stop decisions, oracle-verified by
+            # tests/test_gpu_parity.py::test_stop_rule_fp64_identical_iterations), 8 restarts per rank: does the Float64 loop see
+            # the same kopt on pure noise as the fp32 product?  
+            if fits("config.kopt_f64_mode: the headline matrix in fp64 compute, 8 restarts", 26):
+                h64 = planted_sweep(X, compute="f64", nruns=8)
+                line["config"]["kopt_f64_mode"] = {"kopt": h64["kopt"], "nruns": 8, "seconds": h64["seconds"], "robustness": h64["robustness"],
+                                                   "robustness_f32_product": [float(v) for v in rob[ks[0] - 1:]]}
+            # (4) the planted matrix in fp64 compute (8 restarts: the packed-VALU fp64 kernels take 63 s for all 32; the full-size
+            # agreement of the two modes is tests/test_gpu_fullsize.py::test_planted_rank6_same_kopt_at_metric_size)
+            if "planted" in line["config"] and fits("config.kopt_planted_f64_mode", 26):
+                Xp = planted_matrix(ctx, args.n, args.m, k0)
+                ctx.set_X(Xp)
+                p64 = planted_sweep(Xp, compute="f64", nruns=8)
+                line["config"]["kopt_planted_f64_mode"] = p64["kopt"]
+                line["config"]["planted"]["f64_mode"] = {"nruns": 8, "kopt": p64["kopt"], "seconds": p64["seconds"], "robustness": p64["robustness"]}
+            # (5) structured data on which the restarts RETIRE: the stop rule's tolOF = 1e-3 is an absolute improvement of the sum of
+            # squares (Mult:24, 81), so the planted matrix scaled to entries of ~0.15 stagnates between 1 000 and 10 000 iterations.
+            # Retire-aware schedule (default) against the static one (NMFK_REPLAN=0).
+            if "planted" in line["config"] and fits("config.planted.retiring", 18):
+                Xs = planted_matrix(ctx, args.n, args.m, k0, scale=0.1)
+                ctx.set_X(Xs)
+                ps = planted_sweep(Xs)
+                os.environ["NMFK_REPLAN"] = "0"
+                try:
+                    ps0 = planted_sweep(Xs)
+                finally:
+                    del os.environ["NMFK_REPLAN"]
+                line["config"]["planted"]["retiring"] = {
+                    "matrix": "X = 0.1 * (W0 H0 + 0.01 U): the same matrix scaled so that the ABSOLUTE tolOF = 1e-3 of the "
+                              "reference's stop rule (Mult:24, 81) retires restarts between 1 000 and 10 000 iterations",
+                    **ps, "static_schedule_seconds": ps0["seconds"], "static_schedule_kopt": ps0["kopt"],
+                    "speedup_of_the_retire_aware_schedule": ps0["seconds"] / ps["seconds"]}
+            ctx.set_X(X)
+        if skipped:
+            line["skipped"] = {"what": skipped, "why": f"--budget-s {args.budget_s:.0f}: the whole run stays inside it",
+                               "see": "profiles/r05/bench_full_line.json (the same command with --steps 3 --warmup 1: every entry present)"}
+        line["wall_s_total"] = time.perf_counter() - t_start
         print(json.dumps(line))
     if multi is not None:
         multi.close()

@@ -179,10 +179,17 @@ int nmfk_frobenius(nmfk_ctx *ctx, int k, const float *W, const float *H, double 
  *                pairwise(CosineDist(), zerostoepsilon(X)) (Clus:204-213), NULL = compute_silhouettes_flag=false
  *   converged    KmeansResult.converged of the winning repeat (1: the centre movement fell below tol before maxiter;
  *                may be NULL) */
+int nmfk_robustkmeans_ex(nmfk_ctx *ctx, int d, int64_t n, const float *X, int k, int repeats, int maxiter, double tol,
+                         uint64_t seed, int32_t *assignments, float *centers, float *costs, int32_t *counts,
+                         double *totalcost, int32_t *best_repeat, int32_t *iterations, int32_t *nclusters,
+                         double *all_costs, float *silhouettes, int32_t *converged);
+/* The same without `converged`: the signature this entry point had before the flag existed (nmfk_version() 200).  An exported symbol
+ * keeps its argument list -- a caller built against the earlier header must not make the library write through an argument it never
+ * passed -- so the flag came with a new name (as nmfk_last_sweep_info_ex did); nmfk_version() is 210 since. */
 int nmfk_robustkmeans(nmfk_ctx *ctx, int d, int64_t n, const float *X, int k, int repeats, int maxiter, double tol,
                       uint64_t seed, int32_t *assignments, float *centers, float *costs, int32_t *counts,
                       double *totalcost, int32_t *best_repeat, int32_t *iterations, int32_t *nclusters,
-                      double *all_costs, float *silhouettes, int32_t *converged);
+                      double *all_costs, float *silhouettes);
 
 /* multi-GPU -------------------------------------------------------------------------------------------------- */
 /* Replaces the reference's only parallelism on this path, Distributed.pmap over the restarts of one rank

@@ -214,7 +214,7 @@ function robustkmeans(c::Context, X::Matrix{Float32}, k::Integer, repeats::Integ
 	counts = Vector{Int32}(undef, k); totalcost = Ref{Float64}(0)
 	best = Ref{Int32}(0); iters = Ref{Int32}(0); nclusters = Ref{Int32}(0); converged = Ref{Int32}(0)
 	sil = compute_silhouettes_flag ? Vector{Float32}(undef, n) : Float32[]
-	GC.@preserve X sil check(ccall((:nmfk_robustkmeans, libnmfk), Cint,
+	GC.@preserve X sil check(ccall((:nmfk_robustkmeans_ex, libnmfk), Cint,
 		(Ptr{Cvoid}, Cint, Int64, Ptr{Float32}, Cint, Cint, Cint, Cdouble, UInt64, Ptr{Int32}, Ptr{Float32}, Ptr{Float32},
 		 Ptr{Int32}, Ref{Float64}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ptr{Float64}, Ptr{Float32}, Ref{Int32}),
 		c.h, d, n, X, k, repeats, maxiter, tol, UInt64(seed), assignments, centers, costs, counts, totalcost, best, iters,

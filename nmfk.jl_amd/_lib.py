@@ -81,8 +81,9 @@ def lib():
     L.nmfk_silhouette.argtypes = [vp, C.c_int, C.c_int, C.c_int64, fp, ip, fp, fp]
     L.nmfk_set_weight.argtypes = [vp, fp, C.c_int64, C.c_int64]
     L.nmfk_cluster_stats.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int64, fp, fp, ip, fp, fp, fp, fp]
-    L.nmfk_robustkmeans.argtypes = [vp, C.c_int, C.c_int64, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64, ip, fp, fp,
-                                    ip, C.POINTER(C.c_double), ip, ip, ip, C.c_void_p, C.c_void_p, ip]
+    L.nmfk_robustkmeans_ex.argtypes = [vp, C.c_int, C.c_int64, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64, ip, fp, fp,
+                                       ip, C.POINTER(C.c_double), ip, ip, ip, C.c_void_p, C.c_void_p, ip]
+    L.nmfk_robustkmeans.argtypes = L.nmfk_robustkmeans_ex.argtypes[:-1]  # (ABI 200's signature, kept: no `converged`)
     L.nmfk_frobenius.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_double)]
     L.nmfk_set_profiling.argtypes = [vp, C.c_int]
     L.nmfk_set_objective_trace.argtypes = [vp, C.c_int]
@@ -519,9 +520,9 @@ class Context:
         br, it, kf, cv = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         I = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
         F = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
-        _check(lib().nmfk_robustkmeans(self._h, d, n, F(Xf), int(k), int(repeats), int(maxiter), float(tol), C.c_uint64(seed),
-                                       I(assign), F(centers), F(costs), I(counts), C.byref(tc), C.byref(br), C.byref(it),
-                                       C.byref(kf), allc.ctypes.data, None if sil is None else sil.ctypes.data, C.byref(cv)))
+        _check(lib().nmfk_robustkmeans_ex(self._h, d, n, F(Xf), int(k), int(repeats), int(maxiter), float(tol), C.c_uint64(seed),
+                                          I(assign), F(centers), F(costs), I(counts), C.byref(tc), C.byref(br), C.byref(it),
+                                          C.byref(kf), allc.ctypes.data, None if sil is None else sil.ctypes.data, C.byref(cv)))
         # centers / counts: the clusters found; centers_k / counts_k: all k columns / entries as Clustering.KmeansResult holds
         # them (zero columns / counts for clusters that were not found)
         res = dict(assignments=assign, centers=centers[:, :kf.value], costs=costs, counts=counts[:kf.value], totalcost=tc.value,

@@ -158,7 +158,7 @@ Tuning read_tuning() {
 
 }  // namespace
 
-NMFK_EXPORT int nmfk_version(void) { return 200; }
+NMFK_EXPORT int nmfk_version(void) { return 210; }
 
 NMFK_EXPORT const char *nmfk_last_error(void) { return nmfk_error_slot().c_str(); }
 
@@ -496,7 +496,14 @@ NMFK_EXPORT int nmfk_fill_uniform(nmfk_ctx *ctx, uint64_t seed, uint64_t offset,
   return NMFK_OK;
 }
 
-NMFK_EXPORT int nmfk_robustkmeans(nmfk_ctx *ctx, int d, int64_t n64, const float *X, int k, int repeats, int maxiter,
+NMFK_EXPORT int nmfk_robustkmeans(nmfk_ctx *ctx, int d, int64_t n64, const float *X, int k, int repeats, int maxiter, double tol,
+                                  uint64_t seed, int32_t *assignments, float *centers, float *costs, int32_t *counts,
+                                  double *totalcost, int32_t *best_repeat, int32_t *iterations, int32_t *nclusters,
+                                  double *all_costs, float *silhouettes) {  // (the signature of ABI 200; callers built against it keep working)
+  return nmfk_robustkmeans_ex(ctx, d, n64, X, k, repeats, maxiter, tol, seed, assignments, centers, costs, counts, totalcost,
+                              best_repeat, iterations, nclusters, all_costs, silhouettes, nullptr);
+}
+NMFK_EXPORT int nmfk_robustkmeans_ex(nmfk_ctx *ctx, int d, int64_t n64, const float *X, int k, int repeats, int maxiter,
                                   double tol, uint64_t seed, int32_t *assignments, float *centers, float *costs,
                                   int32_t *counts, double *totalcost, int32_t *best_repeat, int32_t *iterations,
                                   int32_t *nclusters, double *all_costs, float *silhouettes, int32_t *converged) {
@@ -1656,7 +1663,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         any = true;
         all = all && defer_geo(hsP[ph], wsP[ph], defer_kind(G) == 1) > 0;
       }
-    wsP[ph].clampw = any && all;
+    wsP[ph].clampw = (any && all) ? std::max(1, (int)P.maxiter) : 0;  // (the value is maxiter: not in the last iteration's classic check)
   }
   // device copies of the half-step argument blocks (constant over the sweep; `it` is passed by value)
   const NmfkStepArgs *d_hsP[2] = {(const NmfkStepArgs *)(A + o_args), (const NmfkStepArgs *)(A + o_args) + 2};
@@ -1920,7 +1927,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
       if (!P.Wfixed) {  // Mult:69-71
         const size_t e0 = timed ? prof.begin(gs) : 0;
         spw.it = it;
-        spw.clampw = defer_kind(G) == 3;
+        spw.clampw = defer_kind(G) == 3 ? maxiter : 0;
         if (sparse && f64)
           nmfk_launch_sp_step_f64(&spw, G.kp, ub, uc, gs);
         else if (sparse)
@@ -1944,14 +1951,14 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         if (timed) prof.end(e0, PK_WSTEP, j, it, gs, ub, uc, epoch);
         if (!ws.fused && !(use_hyb(G) && ws.res_wgs > 0)) {
           NmfkStepArgs wr = ws;  // (the phase's argument block serves groups on other kernels too: only this group's choice counts)
-          wr.clampw = defer_kind(G) != 0 && ws.clampw;
+          wr.clampw = defer_kind(G) != 0 ? ws.clampw : 0;
           if (f64)
             nmfk_launch_reduce_f64(wr, ub, uc, gs);
           else
             nmfk_launch_reduce_f32(wr, ub, uc, gs);
         }
       }
-      ca.w_clamped = defer_kind(G) == 3 || (defer_kind(G) != 0 && wsP[G.phase].clampw);
+      ca.w_clamped = it + 1 < maxiter && (defer_kind(G) == 3 || (defer_kind(G) != 0 && wsP[G.phase].clampw));
       if (check && it + 1 < maxiter && defer_parts(G) > 0) {
         ca.track_low = track_low_of(G);
         nmfk_launch_check_f32(ca, ub, uc, gs, 2);
@@ -2086,7 +2093,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             two[f]->runs = d_runs;
             two[f]->state = d_state;
           }
-          wsP[ph].clampw = defer_geo(hsP[ph], wsP[ph], true) > 0;
+          wsP[ph].clampw = defer_geo(hsP[ph], wsP[ph], true) > 0 ? std::max(1, (int)P.maxiter) : 0;
         }
         args_keep.push_back({hsP[0], wsP[0]});
         NmfkStepArgs *d_two = (NmfkStepArgs *)(A + o_args2) + 2 * (size_t)nreplans;

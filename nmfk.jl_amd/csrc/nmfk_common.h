@@ -82,8 +82,10 @@ struct NmfkStepArgs {
   int32_t force;    // ignore the active flags
   int32_t res_wgs;  // > 0: the split-operand MFMA units run the RESIDENT form of this half-step (nmfk_step_hyb.hip) with
                     // this many workgroups per unit (= sum-table slots they write); 0: the streaming form
-  int32_t clampw;   // the W half-step's fused finishes of a check iteration write max(W, eps()) themselves (Mult:100; the deferred
-                    // check of nmfk_mu_sweep: nothing reads W between the half-step and the clamp, the pass then only walks H)
+  int32_t clampw;   // > 0: the W half-step's fused finishes of a check iteration write max(W, eps()) themselves (Mult:100; the deferred
+                    // check of nmfk_mu_sweep: nothing reads W between the half-step and the clamp, the pass then only walks H).
+                    // The value is the sweep's maxiter: the check AT maxiter is not deferred (no half-step follows), its objective
+                    // is taken BEFORE the clamp as in the reference (Mult:74, 99-100) -- iterations it + 1 < clampw only.
 };
 
 struct NmfkSseArgs {
@@ -134,7 +136,7 @@ struct NmfkSparseArgs {
   int32_t D;      // the loop dimension (rows of the gathered factor)
   // deferred check (nmfk_mu_sweep; blocked form): objw > 0: the H half-step also leaves the non-zero terms of the objective of the
   // factors it reads, scaled by objw^2, in ossepart[1 + tile] (ntile_obj entries behind slot 0 in all: the rest zeroed);
-  // clampw: the W half-step's finish of a check iteration writes max(W, eps())
+  // clampw (> 0: the sweep's maxiter, see NmfkStepArgs::clampw): the W half-step's finish of a check iteration before the last writes max(W, eps())
   double objw;
   int32_t ntile_obj, clampw;
 };

@@ -740,7 +740,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
   double *red = den + 16;  // [16][16]
   float vs[4] = {0.f, 0.f, 0.f, 0.f};
   bool low = false;  // a value below eps() written in a check iteration: the clamp (Mult:99-100) has work (NmfkState::lowflag)
-  const float floorv = (gp->clampw && which == 1 && (it + 1) % 10 == 0) ? HYB_EPS : -__builtin_inff();
+  const float floorv = (gp->clampw > it + 1 && which == 1 && (it + 1) % 10 == 0) ? HYB_EPS : -__builtin_inff();
   if (owner) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -880,7 +880,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
   // sums of the new factor: fp32 per lane over this wave's tile pairs (<= a few dozen values), fp64 from there on
   float vsf[4] = {0.f, 0.f, 0.f, 0.f};
   bool low = false;  // a value below eps() written in a check iteration (NmfkState::lowflag)
-  const float floorv = (!OBJ && gp->clampw && which == 1 && (it + 1) % 10 == 0) ? HYB_EPS : -__builtin_inff();
+  const float floorv = (!OBJ && gp->clampw > it + 1 && which == 1 && (it + 1) % 10 == 0) ? HYB_EPS : -__builtin_inff();
 
   // X: the 16 x 16 block (16-lane tile, chunk) is 1 KB in lane order; byte offset = wave-uniform block offset (SGPR) + 16 * lane
   const uint32_t xlane = (uint32_t)lane * 16u;
@@ -1572,7 +1572,7 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
   float *__restrict__ Anew = which == 0 ? (float *)(arena + NMFK_HOFF(*rdp, it + 1)) : (float *)(arena + rdp->oWt);
   double *sumA = (double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)) + (int64_t)tile * kp;
   double *red = den + NMFK_MAX_K;  // [8][kp]
-  const float floorv = (gp->clampw && which == 1 && (it + 1) % 10 == 0) ? HYB_EPS : -__builtin_inff();
+  const float floorv = (gp->clampw > it + 1 && which == 1 && (it + 1) % 10 == 0) ? HYB_EPS : -__builtin_inff();
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int c0 = 16 * nb + 4 * g;

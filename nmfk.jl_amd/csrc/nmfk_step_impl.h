@@ -1459,7 +1459,7 @@ __device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkR
     __syncthreads();
   }
   // fused finish (Mult:67 / Mult:70 order)
-  const T floorv = (g.clampw && g.which == 1 && (g.it + 1) % 10 == 0) ? (T)2.220446049250313e-16 : -(T)INFINITY;
+  const T floorv = (g.clampw > g.it + 1 && g.which == 1 && (g.it + 1) % 10 == 0) ? (T)2.220446049250313e-16 : -(T)INFINITY;
   sp_vec4 v[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
@@ -1764,7 +1764,7 @@ __global__ __launch_bounds__(NMFK_TILE) void reduce_kernel(NmfkStepArgs g, int u
   slot_range(g.L, PA, b, l0, l1);
   const T *part = NMFK_PTR(const T, g, rd.opart);
   const int64_t LK = (int64_t)g.L * kp;
-  const T floorv = (g.clampw && g.which == 1 && (g.it + 1) % 10 == 0) ? (T)2.220446049250313e-16 : -(T)INFINITY;
+  const T floorv = (g.clampw > g.it + 1 && g.which == 1 && (g.it + 1) % 10 == 0) ? (T)2.220446049250313e-16 : -(T)INFINITY;
   for (int64_t e = (int64_t)l0 * kp + threadIdx.x; e < (int64_t)l1 * kp; e += NMFK_TILE) {
     const int c = (int)(e % kp);
     const T aold = Aold[e];

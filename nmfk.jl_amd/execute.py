@@ -255,6 +255,13 @@ def _sweep(ctx, X, ks, nNMF, kw, need_all_W=True):
     return res, params
 
 
+def _nan_removed(post):
+    """nanaction = :removed (Exec:581-595) drops a restart whose W OR H holds a NaN: every rank must see every W to reach the same
+    selection, so the lean result exchange of a multi-GPU sweep (W stays with its owner) is not taken (a NaN in a foreign W
+    would be seen by its owner only and idxsol, the clustering and the robustness would differ between the ranks)."""
+    return str(post.get("nanaction", "zeroed")).lstrip(":") == "removed"
+
+
 def _execute_run_post(ctx, X, nk, nNMF, res, clusterWmatrix=False, acceptratio=1, acceptfactor=math.inf, best=True,
                       nanaction="zeroed", quiet=True, saveall=False, resultdir=".", casefilename=""):
     """Everything of execute_run after the restart loop (Exec:545-710)."""
@@ -393,7 +400,7 @@ def execute_run(X, nk, nNMF, device=None, return_details=False, **kw):
         if res is not None:
             post["saveall"] = False
     if res is None:
-        need_all_W = bool(post.get("clusterWmatrix")) or not post.get("best", True) or bool(post.get("saveall"))
+        need_all_W = bool(post.get("clusterWmatrix")) or not post.get("best", True) or bool(post.get("saveall")) or _nan_removed(post)
         res = _sweep(ctx, X, [int(nk)], int(nNMF), kw, need_all_W=need_all_W)[0][int(nk)]
     out = _execute_run_post(ctx, X, int(nk), int(nNMF), res, **post)
     return out if return_details else out[:5]
@@ -545,7 +552,7 @@ def execute(X, nkrange, nNMF=10, opts=None, *, cutoff=0.5, clusterWmatrix=False,
                     res[nk] = r
         run = [nk for nk in todo if nk not in res]
         if run:
-            need_all_W = bool(clusterWmatrix) or not post.get("best", True) or bool(post.get("saveall"))
+            need_all_W = bool(clusterWmatrix) or not post.get("best", True) or bool(post.get("saveall")) or _nan_removed(post)
             res.update(_sweep(ctx, X, run, int(nNMF), kw, need_all_W=need_all_W)[0])
         for nk in todo:
             sv = dict(post, saveall=bool(post.get("saveall")) and rank0 and nk in run)

@@ -122,9 +122,10 @@ struct Tuning {
   int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1, wide_groups = 2, cohorts = -1, legacy_geo = 0;
   int exp_geo[2][3] = {{-1, -1, -1}, {-1, -1, -1}};  // NMFK_EXP_GEO="hws,hS,hres,wws,wS,wres": forced geometry of the matrix-pipe group (experiments)
   // (not knobs any more -- round 3's A/B switches with their measured settings: one mixed-rank matrix-pipe group, the waves of
-  //  a workgroup may split a loop range 8 ways, the small ranks on their own kernel variants, four pairs of lane tiles per
-  //  wave of the resident form, merged sweeps side by side)
-  static constexpr int hyb_groups = 1, max_wsplit = 8, hyb_sse = 1, merge_phased = 0, hyb_small = 1, hyb_res_tpw = 4;
+  //  a workgroup may split a loop range 8 ways, the small ranks on their own kernel variants, merged sweeps side by side; the
+  //  resident form hands a wave up to eight pairs of lane tiles -- the planner's cost model picks the count: two workgroups per
+  //  unit at 480 units of the bench shape, 1.3975 -> 1.3775 ms per iteration, four at 240, profiles/r05/geometry_scan.txt)
+  static constexpr int hyb_groups = 1, max_wsplit = 8, hyb_sse = 1, merge_phased = 0, hyb_small = 1, hyb_res_tpw = 8;
 };
 Tuning read_tuning() {
   Tuning t;
@@ -806,7 +807,7 @@ static double hyb_res_cost(const HybMix &mix, int L, int D, int cus, int g, doub
   std::vector<double> t((size_t)mix.units());
   for (int u = 0; u < mix.units(); ++u) {
     const int v = mix.variant_of(u);
-    t[(size_t)u] = 2.0 + 9.0 * (D / 512.0) * (v / 16.0) + pairs * nch * hyb_chunk_us(v) * 0.987;
+    t[(size_t)u] = std::max(6.0, 2.0 + 9.0 * (D / 512.0) * (v / 16.0)) + pairs * (nch * hyb_chunk_us(v) * 0.987 + 0.5);
   }
   return 5.0 + list_makespan(t, g, cus, busy);
 }
@@ -824,7 +825,7 @@ struct HybPlan {
 // rounds 3-4's resident-form rule (NMFK_EXP_LEGACY_GEO=1, A/B measurements)
 static int hyb_res_wgs_legacy(int L, int D, int cus, int vmax, int units) {
   if (units <= 0 || nmfk_hyb_resident_lds(vmax, D) == 0) return 0;
-  const int ntp = (L + 31) / 32, rw = nmfk_hyb_resident_waves(), res_tpw = Tuning::hyb_res_tpw;
+  const int ntp = (L + 31) / 32, rw = nmfk_hyb_resident_waves(), res_tpw = 4;
   const int fill = (4 * cus + units - 1) / units;
   const int gmax = std::max(1, ntp / (2 * rw)), gmin = std::min(gmax, std::max(std::max(1, ntp / (rw * res_tpw)), fill));
   int best = gmin;
@@ -870,7 +871,10 @@ HybPlan plan_hyb_group(int n, int m, int cus, const HybMix &mix, int target_wgs,
         // on the chip wants ~480 (profiles/r05/geometry_scan.txt) -- the other cohort is the second round.
         const int ntp = (L + 31) / 32, rw = nmfk_hyb_resident_waves(), gmax = std::max(1, ntp / rw);
         const int gmin = std::max(1, ntp / (rw * Tuning::hyb_res_tpw));
-        for (int g = gmin; g <= gmax; ++g) {
+        // (candidates: gmin doubled up to gmax.  Workgroups go to the XCDs round-robin, so a count that is a multiple of 8 keeps lane
+        //  tile t of EVERY unit on XCD t mod 8 and an XCD's L2 holds an eighth of X; an odd count spreads every unit's tiles over all
+        //  eight -- 65536 x 256 (X = 67 MB), 40 units, 19 instead of 32 workgroups per unit: 0.39 -> 0.54 ms per iteration)
+        for (int g = gmin; g <= gmax; g = (g < gmax && 2 * g > gmax) ? gmax : 2 * g) {
           if (one_round && g > gmin && (int64_t)g * units > cus) break;
           double b;
           const double c = hyb_res_cost(mix, L, D, cus, g, &b);

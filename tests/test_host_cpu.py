@@ -492,11 +492,14 @@ def test_retire_aware_tiers_are_consistent_launch_geometries(monkeypatch):
     # staging (wsplit 1), run the W half-step resident with more, shorter workgroups, as two cohorts
     byu = {t["units"]: t for t in _lib.plan_hyb_tiers(8192, 512, 0, 480)}
     t0 = byu[480]
-    assert t0["H"]["fused"] == 1 and t0["H"]["wsplit"] == 1 and t0["W"]["fused"] == 1 and t0["W"]["res"] == 4 and t0["cohorts"] == 1
-    for units, S_ok, res_ok in ((120, (3, 4, 5), (4, 8)), (60, (6, 8, 10), (8,)), (30, (12, 16), (8, 16)), (15, (16, 24, 32), (16,))):
+    assert t0["H"]["fused"] == 1 and t0["H"]["wsplit"] == 1 and t0["W"]["fused"] == 1 and t0["W"]["res"] in (2, 4) and t0["cohorts"] == 1
+    for units, S_ok, res_ok in ((240, (1, 2, 3), (2, 4)), (120, (3, 4, 5), (4, 8)), (60, (6, 8, 10), (8,)), (30, (12, 16), (8, 16)), (15, (16, 24, 32), (16,))):
         t = byu[units]
         assert t["H"]["wsplit"] == 1 and t["H"]["S"] in S_ok and t["W"]["res"] in res_ok, t
     assert byu[120]["cohorts"] == 2 and byu[60]["cohorts"] == 2 and byu[30]["cohorts"] == 2 and byu[1]["cohorts"] == 1
+    # the resident form's workgroups per unit double from their minimum (lane tile t of every unit stays on XCD t mod 8)
+    for t in _lib.plan_hyb_tiers(65536, 256, 4, 40):
+        assert t["W"]["res"] == 0 or (t["W"]["res"] & (t["W"]["res"] - 1)) == 0, t
     assert byu[4]["W"]["res"] == 16 and byu[1]["W"]["res"] == 0  # (one pair of lane tiles per wave; BASELINE configs[1], one unit: the
     # streaming form with more, shorter workgroups -- 62 -> 44 us per iteration)
     # a narrow matrix (64 columns: a quarter of a shared-staging workgroup's lanes) keeps the per-wave form for the H half-step

@@ -1111,7 +1111,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
     }
     // Round 4: rounds 2-3 guarded the group with a cost model of THEIR kernels -- >= 16 restarts per rank (or <= 8: merged
     // sweeps), a launch of >= 50 us, workgroups for half the CUs, a break-even rank.  Measured again over eight shapes x ten
-    // sweeps (scripts/r4_schedule_probe.py, profiles/r04/schedule_probe_before.txt) the guards cost up to 4x: the group beats the
+    // sweeps (profiles/r04/drivers/r4_schedule_probe.py, profiles/r04/schedule_probe_before.txt) the guards cost up to 4x: the group beats the
     // per-rank packed-VALU launches almost everywhere -- 9..15 restarts per rank (0.78-1.04 -> 0.47-0.75 ms per iteration at
     // 8192 x 512), small matrices (1024 x 128, k = 2:16 x 10: 0.279 -> 0.064 ms), single ranks (k = 16 x 10: 0.171 -> 0.107).
     // What is left on the packed-VALU kernels by measurement: a few units of the smallest ranks only (k = 3 x 10: 0.055 against

@@ -3,7 +3,7 @@
 automatic sweep against (a) the plain order of the check block (NMFK_DEFER_OBJ=0), (b) the per-rank packed-VALU launches
 (NMFK_HYB=0, NMFK_MFMA_WIDE=0) -- a different kernel family altogether.  Reports the worst relative difference of W*H, of the final
 objective and of the monitored objective at the checks, and any difference in iteration counts under the reference's stop rule.
-usage: r4_fuzz.py [cases] [seed]"""
+usage: fuzz_schedule.py [cases] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzz of the sparse path: random sparse X, rank sets, restarts, budgets; the blocked form with the deferred check
 (NMFK_SP_BLK=2) against (a) the plain order of the check block (NMFK_DEFER_OBJ=0), (b) the gather form (NMFK_SP_BLK=0).
-usage: r4_fuzz_sparse.py [cases] [seed]"""
+usage: fuzz_sparse.py [cases] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp

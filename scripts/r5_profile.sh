@@ -24,12 +24,12 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum GRBM_G
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $SHORT > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $SHORT > /dev/null 2> $OUT/pmc_write.err
 echo "pmc done" >&2
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sec -- python3 $REPO/scripts/r4_secondary.py > $OUT/secondary.json 2> $OUT/trace_sec.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sec -- python3 $REPO/scripts/secondary.py > $OUT/secondary.json 2> $OUT/trace_sec.err
 find $OUT/trace_sec -name '*kernel_stats.csv' -exec cp {} $OUT/secondary_kernel_stats.csv \;
 mkdir -p $OUT/sp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/sp/pmc_fetch -- python3 $REPO/scripts/r4_secondary.py cfg4 > /dev/null 2> $OUT/sp_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/sp/pmc_write -- python3 $REPO/scripts/r4_secondary.py cfg4 > /dev/null 2> $OUT/sp_write.err
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/sp/pmc_tcc -- python3 $REPO/scripts/r4_secondary.py cfg4 > /dev/null 2> $OUT/sp_tcc.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/sp/pmc_fetch -- python3 $REPO/scripts/secondary.py cfg4 > /dev/null 2> $OUT/sp_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/sp/pmc_write -- python3 $REPO/scripts/secondary.py cfg4 > /dev/null 2> $OUT/sp_write.err
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/sp/pmc_tcc -- python3 $REPO/scripts/secondary.py cfg4 > /dev/null 2> $OUT/sp_tcc.err
 echo "secondary done" >&2
 #   4. the N = 8 share of the bench sweep (60 units, two cohorts on two streams): kernel trace of rank 0's share alone on the GPU
 RANK_SIM_FIRST=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_n8 -- python3 $REPO/scripts/rank_sim.py 8 > $OUT/rank_sim_n8_traced.txt 2> $OUT/trace_n8.err

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The two secondary workloads of bench.py (BASELINE configs[3] sparse and configs[4] k = 64) on their own, for
-`rocprofv3 --kernel-trace --stats -- python3 scripts/r4_secondary.py` (profiles/r04/secondary_kernel_stats.csv)."""
+`rocprofv3 --kernel-trace --stats -- python3 scripts/secondary.py` (profiles/r05/secondary_kernel_stats.csv)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -265,8 +265,15 @@ int nmfk_multi_sweep(nmfk_multi *mh, int nk, const int32_t *ks, int nruns, const
  * After a sweep with profiling enabled: names[i] / total_ms[i] / launches[i] / flops[i] for i < *count:
  *   "mu_loop"                     GPU wall time of the whole MU loop (all rank groups run concurrently) and the
  *                                 algorithmic flops of every half-step in it (4*n*m*k per ACTIVE restart)
- *   "h_step<kp>" / "w_step<kp>"   sampled launches (every 50th iteration) of the half-step kernel of one rank,
- *                                 each timed on its own stream, with the flops of the restarts active in them */
+ *   "h_step<kp>" / "w_step<kp>"   sampled launches (every 47th iteration) of the half-step kernel of one rank,
+ *                                 each timed on its own stream, with the flops of the restarts active in them
+ *                                 ("<mfma>": the mixed-rank launch group on the matrix-pipe kernels; with cohorts -- NMFK_COHORTS --
+ *                                 launches of different cohorts overlap: the durations are then not exclusive GPU time)
+ *   "comm_*"                      multi-GPU calls (nmfk_comm_bcast_X, nmfk_mu_sweep_sharded, nmfk_comm_bcast): HOST wall time of
+ *                                 their steps on this rank -- comm_bcast_X (ncclBroadcast of X to completion), comm_local_sweep
+ *                                 (this rank's share), comm_wait_for_ranks (the status agreement behind it: returns when the slowest
+ *                                 rank's sweep has ended), comm_allgather, comm_deliver (strided copies into the caller's arrays),
+ *                                 comm_bcast (the winning restart's W) -- with the BYTES moved in the `flops` field */
 int nmfk_set_profiling(nmfk_ctx *ctx, int enabled);
 /* Launch schedule the LAST nmfk_mu_sweep on this context chose (tests assert that the schedule they mean to cover was
  * the one taken; bench.py reports it).  info[0] = phases of the sweep (2 = the split-operand MFMA group first, the

@@ -889,6 +889,10 @@ HybPlan plan_hyb_group(int n, int m, int cus, const HybMix &mix, int target_wgs,
         for (int w : {1, wsN})
           for (int Sq : Ss) {
             if (Sq > std::max(1, D / (64 * w))) break;
+            // (a launch of more than ~8 rounds of workgroups gains nothing from more, shorter ones: their fixed parts add up --
+            //  and the simulation of 60 000 workgroups per candidate would cost the host 0.3 s per sweep)
+            const int lt = nmfk_hyb_lane_tile(w);
+            if (Sq > 1 && (int64_t)units * ((L + lt - 1) / lt) * Sq > (int64_t)16 * cus) break;
             double b;
             const double c = hyb_stream_cost(mix, L, D, cus, w, Sq, &b);
             if (dbg) fprintf(stderr, "[nmfk]   %c half-step, %d units: streaming wsplit %d S %d: %.1f us (busy %.2f)\n", "HW"[which], units, w, Sq, c, b);

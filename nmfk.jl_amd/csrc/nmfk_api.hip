@@ -932,8 +932,10 @@ HybPlan plan_hyb_group(int n, int m, int cus, const HybMix &mix, int target_wgs,
 static int nmfk_default_cohorts(const HybPlan &p, int64_t n, int64_t m, int cus) {
   if (p.units < 4 || n * m < 100000 || p.us[0] + p.us[1] < 80.0) return 1;
   const double busy = (p.busy[0] * p.us[0] + p.busy[1] * p.us[1]) / (p.us[0] + p.us[1]);
-  for (int w = 0; w < 2; ++w)
-    if (p.res[w] == 0 && (int64_t)p.ns[w] * p.S[w] * p.units < 3 * cus / 2) return 1;
+  for (int w = 0; w < 2; ++w) {
+    const int64_t L = w == 0 ? m : n, lt = nmfk_hyb_lane_tile(p.wsplit[w]);
+    if (p.res[w] == 0 && (L + lt - 1) / lt * p.S[w] * p.units < 3 * cus / 2) return 1;  // (workgroups of the streaming launch)
+  }
   return busy < 0.9 ? 2 : 1;
 }
 // The plan of a group WITH its cohorts: the group as one launch decides the cohorts; with c > 1 a launch holds units / c of them, so the

@@ -284,7 +284,8 @@ int nmfk_set_profiling(nmfk_ctx *ctx, int enabled);
 int nmfk_last_sweep_info(nmfk_ctx *ctx, int32_t info[8]);
 /* The same with `count` <= 16 entries: info[8] = checks (per launch group) whose objective came out of the following H half-step
  * (the deferred check, see NMFK_DEFER_OBJ below), info[9] = checks with an objective launch of their own, info[10] = cohorts of the
- * matrix-pipe launch group (its units dealt to that many streams, see NMFK_COHORTS below; 1 = one launch per half-step); the rest 0. */
+ * matrix-pipe launch group (its units dealt to that many streams, see NMFK_COHORTS below; 1 = one launch per half-step), info[11] = H
+ * half-step launches whose partial numerators were summed by the W half-step behind them instead of a reduce launch (NMFK_FUSE_RED); the rest 0. */
 int nmfk_last_sweep_info_ex(nmfk_ctx *ctx, int32_t *info, int count);
 /* Test hook, pure host arithmetic (no device): the tiers of the retire-aware schedule for a sweep of `units` units of ranks 2..16
  * (widest kernel variant 4 / 8 / 16) in one launch group on the matrix-pipe kernels, on a GPU of `cus` CUs -- tier j is the launch
@@ -321,6 +322,8 @@ int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *
  *                     groups of up to f workgroups per CU (default 2)
  *   NMFK_COHORTS      c: the launch group on the matrix-pipe kernels (ranks 2..16) runs as c cohorts of units, each on its own stream, so
  *                     that one cohort's half-step fills the CUs another's leaves idle (default: by the group's size; same bits per unit)
+ *   NMFK_FUSE_RED     0: an H half-step whose loop range is split over workgroups is finished by its own reduce launch also when the W
+ *                     half-step behind it runs the resident form (default: that W half-step sums the partial numerators while it stages H)
  *   NMFK_SP_BLK       0: sparse X in the gather form only (no sliced-ELL copies are built); 2: blocked form whatever the size
  *   NMFK_TARGET_WGS   workgroups a half-step launch should have before loop ranges are split (default 2 x CUs)
  *   NMFK_STREAMS      concurrent launch-group streams (8; 16 for a dozen launch groups or more; sparse X: 1);  NMFK_HOST_TIMING=1: host / GPU wait times on stderr

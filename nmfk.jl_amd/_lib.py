@@ -546,7 +546,7 @@ class Context:
         _check(lib().nmfk_last_sweep_info_ex(self._h, info, 16))
         return dict(phases=info[0], mfma_group_units=info[1], merged_valu_groups=info[2], launch_groups=info[3],
                     wide_mfma_units=info[4], replans=info[5], last_tier=info[6], units_in_last_plan=info[7],
-                    deferred_checks=info[8], plain_checks=info[9], cohorts=info[10])
+                    deferred_checks=info[8], plain_checks=info[9], cohorts=info[10], fused_reductions=info[11])
 
     def set_objective_trace(self, on=True):
         """nmfk_set_objective_trace: record the monitored objective (Mult:74) at every check of the next sweeps."""

@@ -116,10 +116,12 @@ struct Sampler {
 //   NMFK_SP_BLK       0: sparse X in the gather form only (also: no sliced-ELL copies are built); 2: blocked form whatever the size
 //   NMFK_STREAMS      concurrent rank-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1 prints the host's share of the loop
 //   NMFK_COHORTS      c: the matrix-pipe launch group runs as c cohorts of units on c streams (default: by the group's size)
+//   NMFK_FUSE_RED     0: an H half-step whose loop range is split over workgroups is finished by reduce_kernel also when the W half-step
+//                     behind it runs the resident form (default: that W half-step sums the partial numerators while it stages H)
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, merge = -1, phases = -1;
   int wide_sse = 1, streams = -1, host_timing = 0;
-  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1, wide_groups = 2, cohorts = -1, legacy_geo = 0;
+  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1, wide_groups = 2, cohorts = -1, legacy_geo = 0, fuse_red = 1;
   int exp_geo[2][3] = {{-1, -1, -1}, {-1, -1, -1}};  // NMFK_EXP_GEO="hws,hS,hres,wws,wS,wres": forced geometry of the matrix-pipe group (experiments)
   // (not knobs any more -- round 3's A/B switches with their measured settings: one mixed-rank matrix-pipe group, the waves of
   //  a workgroup may split a loop range 8 ways, the small ranks on their own kernel variants, merged sweeps side by side; the
@@ -153,6 +155,7 @@ Tuning read_tuning() {
   geti("NMFK_COHORTS", t.cohorts);
   if (const char *e = getenv("NMFK_EXP_GEO")) sscanf(e, "%d,%d,%d,%d,%d,%d", &t.exp_geo[0][0], &t.exp_geo[0][1], &t.exp_geo[0][2], &t.exp_geo[1][0], &t.exp_geo[1][1], &t.exp_geo[1][2]);
   geti("NMFK_EXP_LEGACY_GEO", t.legacy_geo);
+  geti("NMFK_FUSE_RED", t.fuse_red);
   if (t.cohorts >= 0) t.cohorts = std::max(1, std::min(8, t.cohorts));
   return t;
 }
@@ -1497,8 +1500,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         rd.osumW = (int64_t)B.take(sizeof(double) * (size_t)PWmax * kp);
         rd.osumH = (int64_t)B.take(sizeof(double) * (size_t)PHmax * kp);
         rd.ossepart = (int64_t)B.take(sizeof(double) * (size_t)obj_cap);  // (sparse objective: slot 0 = <W'W, HH'>)
-        rd.ocanon = (int64_t)B.take(sizeof(int32_t) * (size_t)m);
+        rd.ocanon = (int64_t)B.take(sizeof(int32_t) * 2 * (size_t)m);  // (the partition, then check_b's index scratch)
         rd.ogram = ctx->sparse ? (int64_t)B.take(sizeof(double) * nmfk_gram_doubles(n, m, kp)) : 0;
+        rd.osnapW = (int64_t)B.take(sizeof(float) * 16);
         rd.seed = seeds ? seeds[(size_t)q * nruns + r] : 0;
         // slots the unit's kernels write: the fused half-step one per lane tile, the grid-parallel helpers any count
         const Geo &gh = ghp[phase_of_k(k)], &gw = gwp[phase_of_k(k)];
@@ -1620,6 +1624,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   hs.force = 0;
   hs.res_wgs = res_wgs[0];
   hs.clampw = 0;
+  hs.fuse_red = 0;
   NmfkStepArgs ws = hs;
   ws.res_wgs = res_wgs[1];
   ws.X = ctx->Xc;
@@ -1674,6 +1679,23 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         all = all && defer_geo(hsP[ph], wsP[ph], defer_kind(G) == 1) > 0;
       }
     wsP[ph].clampw = (any && all) ? std::max(1, (int)P.maxiter) : 0;  // (the value is maxiter: not in the last iteration's classic check)
+  }
+  // Fused reduce (round 5): the H half-step of a matrix-pipe group whose loop range is split over workgroups (S > 1: few units) leaves
+  // partial numerators; when the W half-step behind it runs the resident form, that launch sums them while it stages H
+  // (NmfkStepArgs::fuse_red) and the reduce launch between the two half-steps is not queued.  Needs both half-steps to run every
+  // iteration and H's finish to be the plain one.
+  auto fuse_red_of = [&](const NmfkStepArgs &h, const NmfkStepArgs &w) {
+    return (T.fuse_red && !P.Hfixed && !P.Wfixed && !h.fused && h.res_wgs == 0 && h.S > 1 && w.res_wgs > 0) ? h.S : 0;
+  };
+  for (int ph = 0; ph < 2; ++ph) {
+    bool all_hyb_ph = true, any_ph = false;  // (the phase's argument block is shared by its groups: all of them on these kernels)
+    for (const Group &G : groups)
+      if (G.phase == ph) {
+        any_ph = true;
+        all_hyb_ph = all_hyb_ph && G.hyb != 0;
+      }
+    wsP[ph].fuse_red = (any_ph && all_hyb_ph) ? fuse_red_of(hsP[ph], wsP[ph]) : 0;
+    hsP[ph].fuse_red = wsP[ph].fuse_red;  // (the H half-step leaves the W half-step its copy of colsum(W): NmfkRun::osnapW)
   }
   // device copies of the half-step argument blocks (constant over the sweep; `it` is passed by value)
   const NmfkStepArgs *d_hsP[2] = {(const NmfkStepArgs *)(A + o_args), (const NmfkStepArgs *)(A + o_args) + 2};
@@ -1866,7 +1888,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   int max_cohorts = 1;
   for (const auto &v : coh) max_cohorts = std::max(max_cohorts, (int)v.size());
   std::vector<int> pending((size_t)ngroups, 0);  // > 0: the group's check of the previous iteration waits for this H half-step (= its objective partials per unit)
-  int ndeferred = 0, nclassic = 0;
+  int ndeferred = 0, nclassic = 0, nfused_red = 0;
   for (int phase = 0; phase < nphases; ++phase) {
   // (units still active when a phase's loop ends ran all `maxiter` iterations, so one total_iters serves every phase)
   for (int u = 0; u < nunits; ++u) in_phase[u] = 0;
@@ -1919,8 +1941,9 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         else
           nmfk_launch_step_f32(hs, d_hs, G.kp, ub, uc, gs);
         if (timed) prof.end(e0, PK_HSTEP, j, it, gs, ub, uc, epoch);
-        if (!hs.fused && !(use_hyb(G) && hs.res_wgs > 0)) {  // (the resident form always finishes itself)
-          if (f64)
+        if (!hs.fused && use_hyb(G) && hs.res_wgs == 0 && ws.fuse_red > 0) ++nfused_red;
+        if (!hs.fused && !(use_hyb(G) && hs.res_wgs > 0) && !(use_hyb(G) && ws.fuse_red > 0)) {  // (the resident form always finishes
+          if (f64)                                                                                  //  itself; fuse_red: the W half-step does)
             nmfk_launch_reduce_f64(hs, ub, uc, gs);
           else
             nmfk_launch_reduce_f32(hs, ub, uc, gs);
@@ -2104,6 +2127,8 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
             two[f]->state = d_state;
           }
           wsP[ph].clampw = defer_geo(hsP[ph], wsP[ph], true) > 0 ? std::max(1, (int)P.maxiter) : 0;
+          wsP[ph].fuse_red = fuse_red_of(hsP[ph], wsP[ph]);
+          hsP[ph].fuse_red = wsP[ph].fuse_red;
         }
         args_keep.push_back({hsP[0], wsP[0]});
         NmfkStepArgs *d_two = (NmfkStepArgs *)(A + o_args2) + 2 * (size_t)nreplans;
@@ -2144,6 +2169,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   ctx->sweep_info[6] = cur_tier;
   ctx->sweep_info[7] = ngroups == 1 ? groups[0].count : 0;
   ctx->sweep_info[10] = max_cohorts;  // (the most the sweep ran side by side; a late tier of a handful of units runs as one)
+  ctx->sweep_info[11] = nfused_red;
   ctx->sweep_info[8] = ndeferred;
   ctx->sweep_info[9] = nclassic;
   if (T.host_timing)

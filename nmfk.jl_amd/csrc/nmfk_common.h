@@ -22,13 +22,15 @@ struct NmfkRun {
   int64_t osumW;     // double[PW][kp] colsum(W) as PW partial vectors (denominator of the H half-step, Mult:67)
   int64_t osumH;     // double[PH][kp] rowsum(H) as PH partial vectors (denominator of the W half-step, Mult:70)
   int64_t ossepart;  // double[ntile_n] per-workgroup partial objective
-  int64_t ocanon;    // int32[m] canonical co-clustering partition of the previous check (Mult:101-116)
+  int64_t ocanon;    // int32[2 m]: canonical co-clustering partition of the previous check (Mult:101-116), then check_b's index scratch
   uint64_t seed;
   int32_t nsW, nsH;  // slots of the sum tables this unit's kernels write (<= PW, PH); the others stay zero
   // split-operand MFMA half-step (nmfk_step_hyb.hip): hyb = split width KS (8 or 16; 0 = unit does not use it)
   int32_t hyb;
   int32_t uid;       // position of the unit in the work list the sweep started with (the retire-aware schedule reorders the list)
   int64_t ogram;     // sparse X: double[nmfk_gram_doubles()] partial Gram matrices of the factors (objective)
+  int64_t osnapW;    // float[16]: colsum(W) as the H half-step read it, kept for the W half-step that sums the H partials itself
+                     // (NmfkStepArgs::fuse_red; its own workgroups overwrite osumW while others of the unit still start)
 };
 
 // sparse objective: <W'W, HH'> from partial Gram matrices over chunks of NMFK_GRAM_ROWS factor rows; a chunk's rows
@@ -82,6 +84,11 @@ struct NmfkStepArgs {
   int32_t force;    // ignore the active flags
   int32_t res_wgs;  // > 0: the split-operand MFMA units run the RESIDENT form of this half-step (nmfk_step_hyb.hip) with
                     // this many workgroups per unit (= sum-table slots they write); 0: the streaming form
+  int32_t fuse_red; // W half-step, resident form: > 0 = the H half-step of this iteration left S = fuse_red partial numerators per unit
+                    // (its loop range was split over workgroups) and NO reduce_kernel has run: every workgroup of this launch sums
+                    // them while it stages H -- H_new = H .* sum(partials) ./ colsum(W), Mult:67, reduce_kernel's arithmetic --,
+                    // workgroup 0 of a unit also writes H_new and rowsum(H) (round 5: the reduce launch was 15 % of a 60-unit share).
+                    // The H half-step carries the same value: its workgroup 0 copies colsum(W) to NmfkRun::osnapW
   int32_t clampw;   // > 0: the W half-step's fused finishes of a check iteration write max(W, eps()) themselves (Mult:100; the deferred
                     // check of nmfk_mu_sweep: nothing reads W between the half-step and the clamp, the pass then only walks H).
                     // The value is the sweep's maxiter: the check AT maxiter is not deferred (no half-step follows), its objective

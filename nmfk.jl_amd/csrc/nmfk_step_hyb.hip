@@ -730,6 +730,9 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           }
         }
     }
+    // fuse_red: the W half-step divides by colsum(W) while its own workgroups already write the next one -- leave it a copy
+    if (gp->fuse_red && which == 0 && bx == 0 && tid < k)
+      ((float *)(arena + rdp->osnapW))[tid] = (float)nmfk_slot_sum<16>((const double *)(arena + rdp->osumW), k, rdp->nsW, tid);
     return;
   }
 
@@ -826,9 +829,56 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
   const int BFB = nch * ST::CHP;
 
   // ---- the whole loop factor -> LDS, once per workgroup: item = (row, pair of adjacent signals)
+  // FR > 0 (W half-step behind an H half-step whose loop range was split FR ways over workgroups, NmfkStepArgs::fuse_red): the loop
+  // factor H_new does not exist yet -- its rows are formed HERE from the partial numerators, in reduce_kernel's arithmetic and order
+  // (sum of the partials in split order, H .* num ./ colsum(W): Mult:67), by every workgroup of the unit for itself; workgroup 0
+  // also writes them, and rowsum(H) (below).  The reduce launch between the half-steps goes away.
+  const int FR = (!OBJ && which == 1) ? gp->fuse_red : 0;
+  double *den = lds;
+  float *rden = (float *)(den + 16) + 16 * 32;  // behind red[16][16]; while the factor is staged: colsum(W) as fp32 (FR)
+  if (FR) {
+    if (tid < k) rden[tid] = ((const float *)(arena + rdp->osnapW))[tid];  // (osumW itself: written by the unit's workgroups that are done)
+    __syncthreads();
+  }
+  double cs0 = 0.0, cs1 = 0.0;  // FR: sums of this thread's values of H_new (its items all have the same signal pair)
   for (int q = tid; q < Dp * ST::PPR; q += 64 * RW) {
     const int r = q / ST::PPR, cp = q - r * ST::PPR;
-    const float v0 = (r < D && 2 * cp < k) ? B[(int64_t)r * k + 2 * cp] : 0.0f, v1 = (r < D && 2 * cp + 1 < k) ? B[(int64_t)r * k + 2 * cp + 1] : 0.0f;
+    float v0, v1;
+    if (FR) {
+      const int c0 = 2 * cp, c1 = c0 + 1;
+      const bool in0 = r < D && c0 < k, in1 = r < D && c1 < k;
+      const float *__restrict__ Hold = (const float *)(arena + NMFK_HOFF(*rdp, it));
+      const float *__restrict__ part = (const float *)(arena + rdp->opart);
+      float n0 = 0.0f, n1 = 0.0f;
+      for (int s0 = 0; s0 < FR; s0 += 8) {  // eight partials in flight, added in the order of the splits
+        float p0[8], p1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int64_t e = ((int64_t)min(s0 + j, FR - 1) * D + min(r, D - 1)) * k;
+          p0[j] = part[e + min(c0, k - 1)];
+          p1[j] = part[e + min(c1, k - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (s0 + j < FR) {
+            n0 += p0[j];
+            n1 += p1[j];
+          }
+      }
+      const int64_t eo = (int64_t)min(r, D - 1) * k;
+      v0 = in0 ? Hold[eo + c0] * n0 / rden[c0] : 0.0f;
+      v1 = in1 ? Hold[eo + min(c1, k - 1)] * n1 / rden[min(c1, k - 1)] : 0.0f;
+      if (b == 0) {
+        float *Hn = const_cast<float *>(B);
+        if (in0) Hn[eo + c0] = v0;
+        if (in1) Hn[eo + c1] = v1;
+      }
+      cs0 += (double)v0;
+      cs1 += (double)v1;
+    } else {
+      v0 = (r < D && 2 * cp < k) ? B[(int64_t)r * k + 2 * cp] : 0.0f;
+      v1 = (r < D && 2 * cp + 1 < k) ? B[(int64_t)r * k + 2 * cp + 1] : 0.0f;
+    }
     uint32_t h, m, l;
     split3_pair(v0, v1, h, m, l);
     const int ch = r >> 4, rr = r & 15;
@@ -852,9 +902,31 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
       *(float *)(t + 16) = v1;
     }
   }
-  double *den = lds;
   double ssum = 0.0;
-  if (!OBJ) {
+  if (FR) {
+    // rowsum(H_new): lanes of equal signal pair within a wave (butterflies over the lane bits above the pair index), the waves in
+    // order; every workgroup of the unit forms the same bits, workgroup 0 publishes them as slot 0 of the unit's table
+    for (int o = 32; o >= ST::PPR; o >>= 1) {
+      cs0 += __shfl_xor(cs0, o, 64);
+      cs1 += __shfl_xor(cs1, o, 64);
+    }
+    double *redp = den + 16;  // [RW][16]
+    if (lane < ST::PPR) {
+      redp[wave * 16 + 2 * lane] = cs0;
+      redp[wave * 16 + 2 * lane + 1] = cs1;
+    }
+    __syncthreads();
+    if (tid < k) {
+      double t = 0.0;
+      for (int w = 0; w < RW; ++w) t += redp[w * 16 + tid];
+      den[tid] = t;
+      if (b == 0) {
+        double *sumH = (double *)(arena + rdp->osumH);
+        sumH[tid] = t;
+        for (int pp = 1; pp < rdp->nsH; ++pp) sumH[pp * k + tid] = 0.0;
+      }
+    }
+  } else if (!OBJ) {
     const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
     const int PB = which == 0 ? rdp->nsW : rdp->nsH;  // (the slots behind the unit's own are zero)
     if (tid < k) den[tid] = nmfk_slot_sum<4>(sumB, k, PB, tid);
@@ -862,7 +934,6 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
   __syncthreads();
   // 1 / sum(B) as fp32, once per workgroup (den[] is re-used for it: the finish of every tile pair reads it from LDS
   // instead of keeping four registers per lane alive across the loop)
-  float *rden = (float *)(den + 16) + 16 * 32;  // behind red[16][16]
   if (!OBJ) {
     if (tid < 16) rden[tid] = tid < k ? 1.0f / (float)den[tid] : 0.0f;
     __syncthreads();

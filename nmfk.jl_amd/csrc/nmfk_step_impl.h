@@ -1986,7 +1986,8 @@ __global__ __launch_bounds__(NMFK_TILE) void check_b_kernel(NmfkCheckArgs g, int
   // index[q] = argmin(H[:,q]) (first minimum; a NaN wins, as in Julia); cons[i,j] = index[i]==index[j];
   // consdiff == 0  <=>  the partition of the columns is unchanged.  Canonical form of a partition: every
   // column labelled by the first column of its class.
-  int32_t *idx = NMFK_PTR(int32_t, g, rd.opart);  // scratch: the partial-numerator buffer is idle here
+  int32_t *idx = NMFK_PTR(int32_t, g, rd.ocanon) + m;  // scratch behind the partition (the partial-numerator buffer may hold the H
+                                                       // half-step's partials for the W half-step to sum: NmfkStepArgs::fuse_red)
   for (int q = tid; q < m; q += NMFK_TILE) {
     int am = 0;
     T best = H[(int64_t)q * kp];

@@ -1256,6 +1256,75 @@ def test_cohorts_leave_every_unit_its_bits(NMFk, ctx, oracle, monkeypatch):
     assert err < 1e-4, err
 
 
+def test_w_half_step_sums_the_h_partials(NMFk, ctx, oracle, monkeypatch):
+    """Round 5: few units -> the H half-step's loop range is split over workgroups (partial numerators); when the W half-step behind it
+    runs the resident form, THAT launch sums the partials while it stages H (NmfkStepArgs::fuse_red) and no reduce launch is queued.
+    H_new is reduce_kernel's arithmetic in reduce_kernel's order, so H agrees bit for bit after ONE iteration; rowsum(H) is added in
+    another order, so W and everything behind differ by rounding only.  Against the separate reduce launch (NMFK_FUSE_RED=0), through
+    check iterations (deferred check: check_b's scratch no longer lives in the partial buffer), re-plans, and against the oracle."""
+    n, m = 2650, 192  # (15 units: the planner splits the H half-step's 2650 loop rows 16 ways, the W half-step is resident)
+    X = (0.05 + oracle.uniform_fill(41, 0, n * m)).reshape(n, m).astype(np.float32)
+    ctx.set_X(X)
+    ks, R = list(range(2, 17)), 1
+    seeds = _seeds(NMFk, 23, ks, R)
+    out = {}
+    for it in (1, 45):
+        for mode in ("1", "0"):
+            monkeypatch.setenv("NMFK_FUSE_RED", mode)
+            out[mode] = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=it, **NOSTOP)
+            info = ctx.last_sweep_info()
+            assert info["mfma_group_units"] == len(ks) * R
+            assert (info["fused_reductions"] > 0) == (mode == "1"), info
+        for k in ks:
+            for r in range(R):
+                e = _rel(out["1"][k]["W"][r] @ out["1"][k]["H"][r], out["0"][k]["W"][r] @ out["0"][k]["H"][r], X)
+                assert e <= 2e-6, (it, k, r, e)
+            np.testing.assert_allclose(out["1"][k]["objvalue"], out["0"][k]["objvalue"], rtol=1e-5)
+    for q, k in enumerate(ks):
+        W0, H0 = oracle.init_factors(int(seeds[q, 0]), n, m, k)
+        ref = oracle.singlerun(X, k, W0, H0, maxiter=45, **NOSTOP)
+        assert _rel(out["1"][k]["W"][0] @ out["1"][k]["H"][0], ref["W"] @ ref["H"], X) <= 1e-4
+    # the reference's stop rule with re-plans at every tier: same stop iterations as the separate reduce launch for most restarts
+    k0 = 3
+    Xp = np.asfortranarray(((oracle.uniform_fill(9, 0, n * k0).reshape(n, k0) @ oracle.uniform_fill(9, n * k0, k0 * m).reshape(k0, m)
+                            + 0.02 * oracle.uniform_fill(9, n * k0 + k0 * m, n * m).reshape(n, m)) * 0.2).astype(np.float32))
+    # (scaled: the stop rule's tolOF = 1e-3 is absolute, Mult:24, 81 -- the restarts of this matrix then retire within the budget)
+    ctx.set_X(Xp)
+    ks2, R2 = [2, 3, 4, 5, 6], 6
+    seeds2 = _seeds(NMFk, 4, ks2, R2)
+    monkeypatch.setenv("NMFK_REPLAN", "2")
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NMFK_FUSE_RED", mode)
+        res[mode] = ctx.mu_sweep(ks2, R2, seeds=seeds2, maxiter=3000)
+        info = ctx.last_sweep_info()
+        assert info["replans"] >= 2 and (info["fused_reductions"] > 0) == (mode == "1"), info
+    its1 = np.stack([res["1"][k]["iters"] for k in ks2])
+    its0 = np.stack([res["0"][k]["iters"] for k in ks2])
+    assert (its1 == its0).mean() >= 0.8, (its1, its0)
+    for k in ks2:
+        same = res["1"][k]["iters"] == res["0"][k]["iters"]
+        np.testing.assert_allclose(res["1"][k]["objvalue"][same], res["0"][k]["objvalue"][same], rtol=1e-5)
+    # three launch groups on three streams, 120 units: a unit's workgroups start far apart in time.  The W half-step divides by the
+    # colsum(W) the H half-step read (NmfkRun::osnapW) -- the unit's workgroups that are done already write the next one to the sum table
+    # (read from there, runs differed by ~1e-5 of ||X|| once in a few; found in round 5)
+    monkeypatch.delenv("NMFK_REPLAN")
+    monkeypatch.setenv("NMFK_HYB", "1")
+    monkeypatch.setenv("NMFK_HYB_MINK", "2")
+    n3, m3 = 1500, 256
+    ctx.set_X((0.05 + oracle.uniform_fill(37, 0, n3 * m3)).reshape(n3, m3).astype(np.float32))
+    ks3, R3 = [4, 8, 16], 40
+    seeds3 = _seeds(NMFk, 17, ks3, R3)
+    monkeypatch.setenv("NMFK_FUSE_RED", "0")
+    ref3 = ctx.mu_sweep(ks3, R3, seeds=seeds3, maxiter=30, **NOSTOP)
+    monkeypatch.setenv("NMFK_FUSE_RED", "1")
+    for rep in range(4):
+        got = ctx.mu_sweep(ks3, R3, seeds=seeds3, maxiter=30, **NOSTOP)
+        assert ctx.last_sweep_info()["fused_reductions"] > 0
+        for k in ks3:
+            assert np.array_equal(got[k]["H"], ref3[k]["H"]) and np.array_equal(got[k]["W"], ref3[k]["W"]), (rep, k)
+
+
 def test_retire_aware_schedule_on_a_small_sweep(NMFk, ctx, oracle, monkeypatch):
     """Round 4: restarts retire at different iterations (Mult:64); the sweep is re-planned as they do --
     the units still active move to the front of the work list and the launch geometry is re-derived for them

@@ -322,8 +322,9 @@ int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *
  *                     groups of up to f workgroups per CU (default 2)
  *   NMFK_COHORTS      c: the launch group on the matrix-pipe kernels (ranks 2..16) runs as c cohorts of units, each on its own stream, so
  *                     that one cohort's half-step fills the CUs another's leaves idle (default: by the group's size; same bits per unit)
- *   NMFK_FUSE_RED     0: an H half-step whose loop range is split over workgroups is finished by its own reduce launch also when the W
- *                     half-step behind it runs the resident form (default: that W half-step sums the partial numerators while it stages H)
+ *   NMFK_FUSE_RED     1: an H half-step whose loop range is split over workgroups gets no reduce launch when the W half-step behind
+ *                     it runs the resident form -- that launch sums the partial numerators while it stages H (same bits; off by default:
+ *                     every workgroup of a unit repeats the sum, measured 2.5 % slower on a 60-unit share, profiles/r05/dense_probes.txt)
  *   NMFK_SP_BLK       0: sparse X in the gather form only (no sliced-ELL copies are built); 2: blocked form whatever the size
  *   NMFK_TARGET_WGS   workgroups a half-step launch should have before loop ranges are split (default 2 x CUs)
  *   NMFK_STREAMS      concurrent launch-group streams (8; 16 for a dozen launch groups or more; sparse X: 1);  NMFK_HOST_TIMING=1: host / GPU wait times on stderr

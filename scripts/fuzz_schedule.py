@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Differential fuzz of the launch schedule and the deferred check: random shapes, rank sets, restart counts and budgets; the
 automatic sweep against (a) the plain order of the check block (NMFK_DEFER_OBJ=0), (b) the per-rank packed-VALU launches
-(NMFK_HYB=0, NMFK_MFMA_WIDE=0) -- a different kernel family altogether.  Reports the worst relative difference of W*H, of the final
+(NMFK_HYB=0, NMFK_MFMA_WIDE=0) -- a different kernel family altogether, (c) round 5: the matrix-pipe launch group as two cohorts on two
+streams with the W half-step summing the H partials itself (NMFK_COHORTS=2, NMFK_FUSE_RED=1) against one cohort with reduce launches,
+both with the launch geometry pinned (NMFK_TARGET_WGS): every unit must keep its BITS.  Reports the worst relative difference of W*H, of the final
 objective and of the monitored objective at the checks, and any difference in iteration counts under the reference's stop rule.
 usage: fuzz_schedule.py [cases] [seed]"""
 import os, sys, time
@@ -11,7 +13,7 @@ import nmfk_jl_amd as N
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = N.Context(0)
-KEYS = ("NMFK_DEFER_OBJ", "NMFK_HYB", "NMFK_MFMA_WIDE")
+KEYS = ("NMFK_DEFER_OBJ", "NMFK_HYB", "NMFK_MFMA_WIDE", "NMFK_COHORTS", "NMFK_FUSE_RED", "NMFK_TARGET_WGS")
 worst = dict(wh_defer=0.0, wh_valu=0.0, obj_defer=0.0, obj_valu=0.0, trace_defer=0.0)
 bad = 0
 def rel(a, b, X):
@@ -37,7 +39,9 @@ for case in range(ncases):
     seeds = np.array([[N.run_seed(case + 1, k, r) for r in range(R)] for k in ks], dtype=np.uint64)
     out, tr = {}, {}
     ctx.set_objective_trace(True)
-    for mode, env in (("auto", {}), ("plain", {"NMFK_DEFER_OBJ": "0"}), ("valu", {"NMFK_HYB": "0", "NMFK_MFMA_WIDE": "0"})):
+    for mode, env in (("auto", {}), ("plain", {"NMFK_DEFER_OBJ": "0"}), ("valu", {"NMFK_HYB": "0", "NMFK_MFMA_WIDE": "0"}),
+                      ("coh1", {"NMFK_TARGET_WGS": "512", "NMFK_COHORTS": "1", "NMFK_FUSE_RED": "0"}),
+                      ("coh", {"NMFK_TARGET_WGS": "512", "NMFK_COHORTS": "2", "NMFK_FUSE_RED": "1"})):
         for key in KEYS:
             os.environ.pop(key, None)
         os.environ.update(env)
@@ -45,10 +49,16 @@ for case in range(ncases):
         tr[mode] = {(k, r): ctx.objective_trace(ks.index(k), r) for k in ks for r in range(min(R, 2))}
         if mode == "auto":
             info = ctx.last_sweep_info()
+        if mode == "coh":
+            info_c = ctx.last_sweep_info()
     ctx.set_objective_trace(False)
     line = f"case {case:3d}: {n:5d} x {m:5d} {'planted' if planted else 'noise  '} k = {ks} x {R}, {kw.get('maxiter')} iterations; group units {info['mfma_group_units']}, wide {info['wide_mfma_units']}, groups {info['launch_groups']}, phases {info['phases']}, deferred {info['deferred_checks']} plain {info['plain_checks']}"
+    line += f"; forced: cohorts {info_c['cohorts']}, fused reductions {info_c['fused_reductions']}"
     problems = []
     for k in ks:
+        if not (np.array_equal(out["coh1"][k]["W"], out["coh"][k]["W"]) and np.array_equal(out["coh1"][k]["H"], out["coh"][k]["H"])
+                and np.array_equal(out["coh1"][k]["iters"], out["coh"][k]["iters"])):
+            problems.append(f"k={k}: two cohorts + fused reduce changed the unit's bits")
         for other, tag, tol in (("plain", "defer", 2e-5), ("valu", "valu", 2e-4)):
             same = out["auto"][k]["iters"] == out[other][k]["iters"]
             if not planted and not same.all():

@@ -474,6 +474,37 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
       }
     }
   };
+  // the same in two parts (round 5; see hyb_res_body's chunk pipeline): the reciprocals -- they go beside the bf16 matrix instructions
+  // of the next lane tile's first product --, and the packed multiplies -- 12 cycles each THERE, 5.5 beside the fp32 matrix
+  // instructions of the second product
+  auto r_tile = [&](int t, int dch, const f32x4_t (&xcur)[NT], const f32x4_t (&p)[NT], f32x4_t (&q)[NT], bool mask)
+                    __attribute__((always_inline)) {
+    if (SSE) {
+      float sqs = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float e = xcur[t][r] - p[t][r];
+        if (mask) e = dch + 4 * g + r < d1 ? e : 0.0f;
+        sqs = __builtin_fmaf(e, e, sqs);
+      }
+      spart += lv[t] ? sqs : 0.0f;
+      asm volatile("" : "+v"(spart));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q[t][r] = __builtin_amdgcn_rcpf(p[t][r]);
+  };
+  auto m_tile = [&](int t, int dch, const f32x4_t (&xcur)[NT], f32x4_t (&q)[NT], bool mask) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      const f32x2_t q2 = (f32x2_t){xcur[t][r], xcur[t][r + 1]} * (f32x2_t){q[t][r], q[t][r + 1]};
+      q[t][r] = q2.x;
+      q[t][r + 1] = q2.y;
+      if (mask) {
+        q[t][r] = (dch + 4 * g + r < d1) ? q[t][r] : 0.0f;
+        q[t][r + 1] = (dch + 4 * g + r + 1 < d1) ? q[t][r + 1] : 0.0f;
+      }
+    }
+  };
   auto sse_chunk = [&]() __attribute__((always_inline)) {  // the chunk's partial enters the fp64 sum
     ssum += (double)spart;
     spart = 0.0f;
@@ -603,7 +634,18 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           for (int t = 1; t < NT; ++t) {
             __builtin_amdgcn_sched_barrier(0);
             p_tile(t, av, p);
-            q_tile(t - 1, dch, xr[ci & 3], p, q, mask);
+            r_tile(t - 1, dch, xr[ci & 3], p, q, mask);
+            if (!SSE) {  // the four reciprocals spread over the NM matrix instructions (0x8: MFMA, 0x400: transcendental)
+#define HYB_MFMA_THEN_RCP(n)                          \
+  __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); \
+  __builtin_amdgcn_sched_group_barrier(0x400, n, 0);
+              if constexpr (NM == 3) {
+                HYB_MFMA_THEN_RCP(1) HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(1)
+              } else if constexpr (NM == 2) {
+                HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(2)
+              }
+#undef HYB_MFMA_THEN_RCP
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
           if (FULLT || c + 1 < nchunks) {  // (a following chunk at a block's end means a following block: `more`)
@@ -611,6 +653,8 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
 #pragma unroll
             for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(bnx + fofs[j]);
           }
+#pragma unroll
+          for (int t = 0; t + 1 < NT; ++t) m_tile(t, dch, xr[ci & 3], q, mask);
           q_tile(NT - 1, dch, xr[ci & 3], p, q, mask);
           f_tile(0, bn, q);
           __builtin_amdgcn_sched_barrier(0);
@@ -1152,13 +1196,40 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
           asm volatile("" : "+v"(spart));
           ssum += (double)spart;
         }
+        // Where the ratios' instructions go (round 5, tools/probe/coissue2.hip, profiles/r05/issue_rates.txt; four waves per SIMD, one
+        // stream): beside a v_mfma_f32_16x16x32_bf16 one v_rcp_f32 costs 2.3 cycles and two plain fp32 instructions nothing, but a
+        // PACKED one (v_pk_mul_f32, v_pk_add_f32) 12; beside the fp32 matrix instructions everything adds, a packed multiply 5.5 for
+        // its two values.  So: the reciprocals with the first product of chunk c + 1, the packed multiplies behind the barrier with
+        // the second product of chunk c.
         f32x4_t q[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
+          for (int r = 0; r < 4; ++r) q[t][r] = __builtin_amdgcn_rcpf(pc[t][r]);
+        if (!last && !SSE) {  // the 4 NT reciprocals spread evenly over the NM NT matrix instructions (0x8: MFMA, 0x400: transcendental)
+#define HYB_MFMA_THEN_RCP(n)                          \
+  __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); \
+  __builtin_amdgcn_sched_group_barrier(0x400, n, 0);
+          if constexpr (NM * NT == 6) {
+            HYB_MFMA_THEN_RCP(1) HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(1) HYB_MFMA_THEN_RCP(1) HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(1)
+          } else if constexpr (NM * NT == 4) {
+            HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(2)
+          } else if constexpr (NM * NT == 2) {
+            HYB_MFMA_THEN_RCP(4) HYB_MFMA_THEN_RCP(4)
+          }
+#undef HYB_MFMA_THEN_RCP
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!last) {  // operands of the chunk after next (the last-but-one chunk fetches chunk 0 again: the next tile pair's)
+          const char *nx = sb + ((TAIL && ci == 2) ? 0 : (c + 2) * ST::CHP);
+#pragma unroll
+          for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(nx + fofs[j]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
           for (int r = 0; r < 4; r += 2) {
-            const f32x2_t rc = {__builtin_amdgcn_rcpf(pc[t][r]), __builtin_amdgcn_rcpf(pc[t][r + 1])};
-            const f32x2_t q2 = (f32x2_t){xr[ci][t][r], xr[ci][t][r + 1]} * rc;
+            const f32x2_t q2 = (f32x2_t){xr[ci][t][r], xr[ci][t][r + 1]} * (f32x2_t){q[t][r], q[t][r + 1]};
             q[t][r] = q2.x;
             q[t][r + 1] = q2.y;
             if (TAIL && ragged) {  // (steps >= D: zero rows of the loop factor, 0 / 0)
@@ -1166,12 +1237,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
               q[t][r + 1] = 16 * c + 4 * g + r + 1 < D ? q[t][r + 1] : 0.0f;
             }
           }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!last) {  // operands of the chunk after next (the last-but-one chunk fetches chunk 0 again: the next tile pair's)
-          const char *nx = sb + ((TAIL && ci == 2) ? 0 : (c + 2) * ST::CHP);
-#pragma unroll
-          for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(nx + fofs[j]);
-        }
+        __builtin_amdgcn_sched_barrier(0);  // (all multiplies ahead of the matrix instructions: split up, the allocator's register reuse costs wait states)
         if (NS > 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)

@@ -539,7 +539,12 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
       }
     }
   };
-  constexpr bool AOLD_EARLY = NS == 0;  // (the 4x4x1 forms carry more accumulators: their old values are fetched behind the loop)
+  // LAG (round 5): the second lane tile's ratios and second product run ONE CHUNK LATE, so that its reciprocals sit beside the bf16 matrix
+  // instructions of the next chunk's first product (2-6 cycles each) instead of beside the fp32 ones of its own second product (8 each:
+  // profiles/r05/issue_rates.txt).  Carries W*H of the tile and the second product's operand block across the chunk boundary (8
+  // registers: the old factor values of the finish are fetched behind the loop instead, like in the 4x4x1 forms).
+  constexpr bool LAG = NT == 2 && !OBJ && !SSE;
+  constexpr bool AOLD_EARLY = NS == 0 && !LAG;  // (the 4x4x1 forms carry more accumulators: their old values are fetched behind the loop)
   if (fused) {
     const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
     const int PB = which == 0 ? rdp->nsW : rdp->nsH;  // (the slots behind the unit's own are zero)
@@ -583,6 +588,17 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     u32x4_t avn[NM];  // first-product operands of the next chunk, see trip()
 #pragma unroll
     for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(sb + fofs[j]);
+    // LAG: what the second lane tile of the PREVIOUS chunk left -- its W*H, the second product's operand block, whether loop steps
+    // beyond the range have to be masked.  In front of chunk 0 a dummy: ratios 0 * rcp(1) = 0, which add nothing to the numerators
+    f32x4_t plag = {1.f, 1.f, 1.f, 1.f}, bnlag[NSA];
+#pragma unroll
+    for (int sn = 0; sn < NSA; ++sn) bnlag[sn] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    bool masklag = false;
+    int dchlag = d0;
+    if (LAG) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) xr[3][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
     // one trip; FULLT: every chunk of the trip exists, every block of it has a successor after next and no chunk touches
     // the end of the loop range -> no guards in the unrolled body
     auto trip = [&](int c0, auto full_tag) __attribute__((always_inline)) {
@@ -628,6 +644,69 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           for (int j = 0; j < NM; ++j) av[j] = avn[j];  // fetched behind the previous chunk's first product
           f32x4_t p[NT], q[NT];
           const bool mask = !FULLT && dch + 16 > d1;
+#define HYB_MFMA_THEN_RCP(n)                          \
+  __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); \
+  __builtin_amdgcn_sched_group_barrier(0x400, n, 0);
+          if constexpr (LAG) {
+            // P(t0) + reciprocals(t1 of the previous chunk) | P(t1) + reciprocals(t0) | multiplies of both | second products of both
+            p_tile(0, av, p);
+            f32x4_t ql;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ql[r] = __builtin_amdgcn_rcpf(plag[r]);
+            if constexpr (NM == 3) {
+              HYB_MFMA_THEN_RCP(1) HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(1)
+            } else if constexpr (NM == 2) {
+              HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(2)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            p_tile(1, av, p);
+            r_tile(0, dch, xr[ci & 3], p, q, mask);
+            if constexpr (NM == 3) {
+              HYB_MFMA_THEN_RCP(1) HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(1)
+            } else if constexpr (NM == 2) {
+              HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(2)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (FULLT || c + 1 < nchunks) {
+              const char *bnx = ch + 1 < CPB ? b + (ch + 1) * ST::CHP : sb + (buf ^ 1) * ST::STB;
+#pragma unroll
+              for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(bnx + fofs[j]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {  // (the previous chunk's X entries: their register set is free until the next chunk's prefetch)
+              const f32x2_t q2 = (f32x2_t){xr[(ci + 3) & 3][1][r], xr[(ci + 3) & 3][1][r + 1]} * (f32x2_t){ql[r], ql[r + 1]};
+              ql[r] = q2.x;
+              ql[r + 1] = q2.y;
+              if (!FULLT && masklag) {
+                ql[r] = (dchlag + 4 * g + r < d1) ? ql[r] : 0.0f;
+                ql[r + 1] = (dchlag + 4 * g + r + 1 < d1) ? ql[r + 1] : 0.0f;
+              }
+            }
+            m_tile(0, dch, xr[ci & 3], q, mask);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NS > 0) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int sn = 0; sn < NSA; ++sn) {
+                  accs[1][sn] = __builtin_amdgcn_mfma_f32_4x4x1f32(bnlag[sn][r], ql[r], accs[1][sn], 0, 0, 0);
+                  accs[0][sn] = __builtin_amdgcn_mfma_f32_4x4x1f32(bn[sn][r], q[0][r], accs[0][sn], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                accs[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bnlag[0][r], ql[r], accs[1][0], 0, 0, 0);
+                accs[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[0][r], q[0][r], accs[0][0], 0, 0, 0);
+              }
+            }
+            plag = p[1];
+#pragma unroll
+            for (int sn = 0; sn < NSA; ++sn) bnlag[sn] = bn[sn];
+            masklag = mask;
+            dchlag = dch;
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+          }
           p_tile(0, av, p);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -636,9 +715,6 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
             p_tile(t, av, p);
             r_tile(t - 1, dch, xr[ci & 3], p, q, mask);
             if (!SSE) {  // the four reciprocals spread over the NM matrix instructions (0x8: MFMA, 0x400: transcendental)
-#define HYB_MFMA_THEN_RCP(n)                          \
-  __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); \
-  __builtin_amdgcn_sched_group_barrier(0x400, n, 0);
               if constexpr (NM == 3) {
                 HYB_MFMA_THEN_RCP(1) HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(1)
               } else if constexpr (NM == 2) {
@@ -687,6 +763,21 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     int c0 = 0;
     for (; c0 + TRIP + AHEAD <= nchunks; c0 += TRIP) trip(c0, std::true_type());
     for (; c0 < nchunks; c0 += TRIP) trip(c0, std::false_type());
+    if constexpr (LAG) {  // the last chunk's second lane tile
+      const int sl = (nchunks - 1) & 3;
+      f32x4_t xl = sl == 0 ? xr[0][1] : sl == 1 ? xr[1][1] : sl == 2 ? xr[2][1] : xr[3][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = xl[r] * __builtin_amdgcn_rcpf(plag[r]);
+        if (masklag) v = (dchlag + 4 * g + r < d1) ? v : 0.0f;
+        if constexpr (NS > 0) {
+#pragma unroll
+          for (int sn = 0; sn < NSA; ++sn) accs[1][sn] = __builtin_amdgcn_mfma_f32_4x4x1f32(bnlag[sn][r], v, accs[1][sn], 0, 0, 0);
+        } else {
+          accs[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bnlag[0][r], v, accs[1][0], 0, 0, 0);
+        }
+      }
+    }
   };
   // objective: workgroup sum in wave order (fixed order => reproducible), one partial per workgroup
   auto sse_out = [&](int slot) __attribute__((always_inline)) {

@@ -1640,7 +1640,38 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
     xload(d0, xr[0]);
     xload(min(d0 + 16, dlast), xr[1]);
     stage_write(sb, d0);
+    // first product: P[d = 4g + r][l = c16] from the six term pairs
+    auto first_product = [&](const char *cur, int chx, f32x4_t (&p)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (NB == 3) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {  // pair j, block g
+        const bf16x8_t av = *(const bf16x8_t *)(cur + chx * CHP + (tA[j] * NH + g) * 256 + c16 * 16);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bopt[t][tB[j]][0], p[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {  // pair 2q + (g >> 1), block 4 + (g & 1): the loop factor's term is 0, 1, (g >> 1 ? 2 : 0)
+        const int ta = q < 2 ? q : (g >= 2 ? 2 : 0);
+        const bf16x8_t av = *(const bf16x8_t *)(cur + chx * CHP + (ta * NH + 4 + (g & 1)) * 256 + c16 * 16);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, q < 2 ? bq01[t] : bq2[t], p[t], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NM; ++j) {
+        const int tp = NB == 4 ? (j >> 1) : j, i = NB == 4 ? (j & 1) : 0;  // group G = 4j + g: term pair, block sub = g + 4 i
+        const bf16x8_t av = *(const bf16x8_t *)(cur + chx * CHP + (tA[tp] * NH + 4 * i + g) * 256 + c16 * 16);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bopt[t][tB[tp]][i], p[t], 0, 0, 0);
+      }
+    }
+    };
     const int nblocks = (nchunks + CPB - 1) / CPB;
+    f32x4_t pnext[NT];  // PIPE: W*H of the block's next chunk (see the chunk loop)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) pnext[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     for (int blk = 0; blk < nblocks; ++blk) {
       char *cur = sb + (blk & 1) * STB, *nxt = sb + ((blk & 1) ^ 1) * STB;
       const bool more = blk + 1 < nblocks;
@@ -1653,32 +1684,17 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
         const int dch = d0 + 16 * c;
         xload(min(dch + 32, dlast), xr[(ch + 2) & 3]);
         __builtin_amdgcn_sched_barrier(0);
-        // first product: P[d = 4g + r][l = c16] from the six term pairs
+        // PIPE (round 5; NB >= 3, half-step modes): inside a staged block the first product of chunk ch + 1 is issued BEFORE the ratios of
+        // chunk ch, whose reciprocals then sit beside bf16 matrix instructions (2-6 cycles each instead of 8 beside the fp32 ones:
+        // profiles/r05/issue_rates.txt).  Not across a block's end (the other LDS buffer is being rewritten), not at 32 signals (8 more
+        // registers would take that instantiation from four waves per SIMD to three).
+        constexpr bool PIPE = NB >= 3 && !OBJ;
         f32x4_t p[NT];
+        if (!PIPE || ch == 0) first_product(cur, ch, p);
+        if (PIPE && ch == 0) __builtin_amdgcn_sched_barrier(0);  // (the group barriers below pair the NEXT chunk's matrix instructions with the reciprocals)
+        if (PIPE && ch > 0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) p[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (NB == 3) {
-#pragma unroll
-          for (int j = 0; j < 6; ++j) {  // pair j, block g
-            const bf16x8_t av = *(const bf16x8_t *)(cur + ch * CHP + (tA[j] * NH + g) * 256 + c16 * 16);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bopt[t][tB[j]][0], p[t], 0, 0, 0);
-          }
-#pragma unroll
-          for (int q = 0; q < 3; ++q) {  // pair 2q + (g >> 1), block 4 + (g & 1): the loop factor's term is 0, 1, (g >> 1 ? 2 : 0)
-            const int ta = q < 2 ? q : (g >= 2 ? 2 : 0);
-            const bf16x8_t av = *(const bf16x8_t *)(cur + ch * CHP + (ta * NH + 4 + (g & 1)) * 256 + c16 * 16);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, q < 2 ? bq01[t] : bq2[t], p[t], 0, 0, 0);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < NM; ++j) {
-            const int tp = NB == 4 ? (j >> 1) : j, i = NB == 4 ? (j & 1) : 0;  // group G = 4j + g: term pair, block sub = g + 4 i
-            const bf16x8_t av = *(const bf16x8_t *)(cur + ch * CHP + (tA[tp] * NH + 4 * i + g) * 256 + c16 * 16);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bopt[t][tB[tp]][i], p[t], 0, 0, 0);
-          }
+          for (int t = 0; t < NT; ++t) p[t] = pnext[t];
         }
         const bool edge = dch + 16 > d1;
         if (OBJ) {  // residuals: squares of a chunk in fp32 (packed), the chunk's partial into the fp64 sum (see hyb_step_body)
@@ -1715,17 +1731,50 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
           asm volatile("" : "+v"(part));  // (anchor: see hyb_step_body)
           ssum += (double)part;
         }
-        // ratios; loop steps beyond the range give zero
+        // ratios; loop steps beyond the range give zero.  PIPE: the reciprocals together with the first product of the block's next chunk
         f32x4_t q[NT];
+        if constexpr (!PIPE) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+              const f32x2_t rc = {__builtin_amdgcn_rcpf(p[t][r]), __builtin_amdgcn_rcpf(p[t][r + 1])};
+              const f32x2_t q2 = (f32x2_t){xr[ch & 3][t][r], xr[ch & 3][t][r + 1]} * rc;
+              q[t][r] = (!edge || dch + 4 * g + r < d1) ? q2.x : 0.0f;
+              q[t][r + 1] = (!edge || dch + 4 * g + r + 1 < d1) ? q2.y : 0.0f;
+            }
+        } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) q[t][r] = __builtin_amdgcn_rcpf(p[t][r]);
+        // (no run-time condition here: reciprocals and matrix instructions have to share a basic block for the group barriers below; behind the
+        //  loop range's last chunk the product of the block's next chunk -- staged rows, zeros beyond the factor -- is computed and dropped)
+        if (PIPE && ch + 1 < CPB) {
+          first_product(cur, ch + 1, pnext);
+          // (0x8: MFMA, 0x400: transcendental) 4 NT reciprocals over the 3 NB NT matrix instructions
+#define HYB_MFMAS_THEN_RCP(m) \
+  __builtin_amdgcn_sched_group_barrier(0x8, m, 0); \
+  __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+          if constexpr (NB == 4) {
+            HYB_MFMAS_THEN_RCP(3) HYB_MFMAS_THEN_RCP(3) HYB_MFMAS_THEN_RCP(3) HYB_MFMAS_THEN_RCP(3)
+            HYB_MFMAS_THEN_RCP(3) HYB_MFMAS_THEN_RCP(3) HYB_MFMAS_THEN_RCP(3) HYB_MFMAS_THEN_RCP(3)
+          } else if constexpr (NB == 3) {
+            HYB_MFMAS_THEN_RCP(2) HYB_MFMAS_THEN_RCP(2) HYB_MFMAS_THEN_RCP(2) HYB_MFMAS_THEN_RCP(2)
+            HYB_MFMAS_THEN_RCP(2) HYB_MFMAS_THEN_RCP(2) HYB_MFMAS_THEN_RCP(2) HYB_MFMAS_THEN_RCP(2)
+          }
+#undef HYB_MFMAS_THEN_RCP
+        }
+        if (PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int r = 0; r < 4; r += 2) {
-            const f32x2_t rc = {__builtin_amdgcn_rcpf(p[t][r]), __builtin_amdgcn_rcpf(p[t][r + 1])};
-            const f32x2_t q2 = (f32x2_t){xr[ch & 3][t][r], xr[ch & 3][t][r + 1]} * rc;
+            const f32x2_t q2 = (f32x2_t){xr[ch & 3][t][r], xr[ch & 3][t][r + 1]} * (f32x2_t){q[t][r], q[t][r + 1]};
             q[t][r] = (!edge || dch + 4 * g + r < d1) ? q2.x : 0.0f;
             q[t][r + 1] = (!edge || dch + 4 * g + r + 1 < d1) ? q2.y : 0.0f;
           }
+        }
         // second product: numerators of the signals 16 nb + 4g + r'
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {

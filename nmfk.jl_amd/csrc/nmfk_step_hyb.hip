@@ -304,7 +304,7 @@ __device__ __forceinline__ void hyb_lane_blocks(const float *__restrict__ A, int
 // half-step that follows a check iteration runs in this mode (nmfk_mu_sweep, "deferred check"); one partial per workgroup
 // in ossepart[blockIdx.x] (gridDim.x partials per unit: lane tiles x splits of the loop range).
 // NS: sets of four signals whose numerators run as v_mfma_f32_4x4x1_16B_f32 (ceil(k / 4)); 0 = v_mfma_f32_16x16x4_f32
-template <int KS, int NS, int NT, int NW, bool OBJ, bool SSE>  // NW: waves per workgroup when wsplit = 1 (4 or 8)
+template <int KS, int NS, int NT, int NW, bool OBJ, bool SSE, bool LAGK>  // NW: waves per workgroup when wsplit = 1 (4 or 8); LAGK: see LAG
 __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restrict__ Xa, const float *__restrict__ Xt,
                                               const NmfkRun *__restrict__ runs, const NmfkState *__restrict__ state,
                                               const NmfkStepArgs *__restrict__ gp, int it, int u0, double weight,
@@ -543,7 +543,9 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
   // instructions of the next chunk's first product (2-6 cycles each) instead of beside the fp32 ones of its own second product (8 each:
   // profiles/r05/issue_rates.txt).  Carries W*H of the tile and the second product's operand block across the chunk boundary (8
   // registers: the old factor values of the finish are fetched behind the loop instead, like in the 4x4x1 forms).
-  constexpr bool LAG = NT == 2 && !OBJ && !SSE;
+  // LAGK = false: launches whose waves walk a short loop range (one unit alone, BASELINE configs[1]: the lag's dummy in front and its tail
+  // behind cost a chunk -- 44.9 -> 48.0 us per iteration with the lag everywhere)
+  constexpr bool LAG = LAGK && NT == 2 && !OBJ && !SSE;
   constexpr bool AOLD_EARLY = NS == 0 && !LAG;  // (the 4x4x1 forms carry more accumulators: their old values are fetched behind the loop)
   if (fused) {
     const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
@@ -551,6 +553,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     if (tid < k) den[tid] = nmfk_slot_sum<4>(sumB, k, PB, tid);
     if (AOLD_EARLY) load_aold();
   }
+  bool aold_loaded = false;  // (wave-uniform) run() fetched them in front of its last trips
   char *sbase = (char *)(lds + 18 * 16);  // staging buffers, later the cross-wave scratch (wsplit > 1)
   const int nchunks = (d1 - d0 + 15) >> 4;
 
@@ -762,6 +765,11 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     constexpr int AHEAD = 2 * CPB > 2 ? 2 * CPB : 2;
     int c0 = 0;
     for (; c0 + TRIP + AHEAD <= nchunks; c0 += TRIP) trip(c0, std::true_type());
+    // the finish's old values: requested in front of the last trips (<= TRIP + AHEAD chunks) when they were not fetched before the loop
+    if (fused && !AOLD_EARLY) {
+      load_aold();
+      aold_loaded = true;
+    }
     for (; c0 < nchunks; c0 += TRIP) trip(c0, std::false_type());
     if constexpr (LAG) {  // the last chunk's second lane tile
       const int sl = (nchunks - 1) & 3;
@@ -871,7 +879,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     return;
   }
 
-  if (!AOLD_EARLY) load_aold();
+  if (!AOLD_EARLY && !aold_loaded) load_aold();
   __syncthreads();  // den[] is visible
   float *__restrict__ Anew = which == 0 ? (float *)(arena + NMFK_HOFF(*rdp, it + 1)) : (float *)(arena + rdp->oWt);
   double *sumA = (double *)(arena + (which == 0 ? rdp->osumH : rdp->osumW)) + (int64_t)tile * k;
@@ -1895,7 +1903,7 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
 // were three launches that each left CUs idle (H half-step: two workgroups per unit) and ended in their own tail;
 // together they fill the chip (profiles/r03/variants_one_launch.txt).
 // ------------------------------------------------------------------------------------------------------
-template <int NT, int NW, int MODE>  // MODE 0: half-step, 1: objective, 2: half-step that leaves the objective of its inputs
+template <int NT, int NW, int MODE>  // MODE 0: half-step, 1: objective, 2: half-step that leaves the objective of its inputs, 3: half-step of short loop ranges (no LAG)
 __global__ __launch_bounds__(64 * (NW > 8 ? NW : 8), MODE == 1 ? 2 : 4) void hyb_step_kernel(char *arena, const float *__restrict__ Xa,
                                                        const float *__restrict__ Xt,
                                                        const NmfkRun *__restrict__ runs,
@@ -1903,9 +1911,9 @@ __global__ __launch_bounds__(64 * (NW > 8 ? NW : 8), MODE == 1 ? 2 : 4) void hyb
                                                        const NmfkStepArgs *__restrict__ gp, int it, int u0, double weight) {
   extern __shared__ double lds[];
   switch (runs[u0 + blockIdx.y].hyb) {
-    case 4: hyb_step_body<4, MODE == 1 ? 0 : 1, NT, NW, MODE == 1, MODE == 2>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
-    case 8: hyb_step_body<8, MODE == 1 ? 0 : 2, NT, NW, MODE == 1, MODE == 2>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
-    default: hyb_step_body<16, 0, NT, NW, MODE == 1, MODE == 2>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
+    case 4: hyb_step_body<4, MODE == 1 ? 0 : 1, NT, NW, MODE == 1, MODE == 2, MODE == 0>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
+    case 8: hyb_step_body<8, MODE == 1 ? 0 : 2, NT, NW, MODE == 1, MODE == 2, MODE == 0>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
+    default: hyb_step_body<16, 0, NT, NW, MODE == 1, MODE == 2, MODE == 0>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
   }
 }
 
@@ -2000,8 +2008,10 @@ void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, 
   const size_t ldsb = sizeof(double) * 18 * 16 + std::max(cross, stage);
   if (objw > 0)
     hipLaunchKernelGGL((hyb_step_kernel<NT, NW, 2>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, objw);
-  else
+  else if ((a.D + a.S - 1) / a.S / (ws > 1 ? ws : 1) >= 512)  // loop rows a wave walks: 32 chunks and more run the lagged form (hyb_step_body, LAG)
     hipLaunchKernelGGL((hyb_step_kernel<NT, NW, 0>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
+  else
+    hipLaunchKernelGGL((hyb_step_kernel<NT, NW, 3>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
 }
 
 // objective partials per unit a launch with these arguments leaves in its objective mode

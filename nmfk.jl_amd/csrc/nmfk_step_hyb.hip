@@ -716,6 +716,10 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
           for (int t = 1; t < NT; ++t) {
             __builtin_amdgcn_sched_barrier(0);
             p_tile(t, av, p);
+            if constexpr (!LAGK && !SSE) {  // short loop ranges: rounds 3-4's order (ratios whole, the compiler's interleave) -- configs[1] 1.5 us faster with it
+              q_tile(t - 1, dch, xr[ci & 3], p, q, mask);
+              continue;
+            }
             r_tile(t - 1, dch, xr[ci & 3], p, q, mask);
             if (!SSE) {  // the four reciprocals spread over the NM matrix instructions (0x8: MFMA, 0x400: transcendental)
               if constexpr (NM == 3) {
@@ -732,8 +736,10 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
 #pragma unroll
             for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(bnx + fofs[j]);
           }
+          if constexpr (LAGK || SSE) {
 #pragma unroll
-          for (int t = 0; t + 1 < NT; ++t) m_tile(t, dch, xr[ci & 3], q, mask);
+            for (int t = 0; t + 1 < NT; ++t) m_tile(t, dch, xr[ci & 3], q, mask);
+          }
           q_tile(NT - 1, dch, xr[ci & 3], p, q, mask);
           f_tile(0, bn, q);
           __builtin_amdgcn_sched_barrier(0);
@@ -1295,6 +1301,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
           asm volatile("" : "+v"(spart));
           ssum += (double)spart;
         }
+#ifndef NMFK_RES_OLD_ORDER
         // Where the ratios' instructions go (round 5, tools/probe/coissue2.hip, profiles/r05/issue_rates.txt; four waves per SIMD, one
         // stream): beside a v_mfma_f32_16x16x32_bf16 one v_rcp_f32 costs 2.3 cycles and two plain fp32 instructions nothing, but a
         // PACKED one (v_pk_mul_f32, v_pk_add_f32) 12; beside the fp32 matrix instructions everything adds, a packed multiply 5.5 for
@@ -1336,6 +1343,28 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
               q[t][r + 1] = 16 * c + 4 * g + r + 1 < D ? q[t][r + 1] : 0.0f;
             }
           }
+#else  // (rounds 3-4's order: A/B builds only)
+        f32x4_t q[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const f32x2_t rc = {__builtin_amdgcn_rcpf(pc[t][r]), __builtin_amdgcn_rcpf(pc[t][r + 1])};
+            const f32x2_t q2 = (f32x2_t){xr[ci][t][r], xr[ci][t][r + 1]} * rc;
+            q[t][r] = q2.x;
+            q[t][r + 1] = q2.y;
+            if (TAIL && ragged) {  // (steps >= D: zero rows of the loop factor, 0 / 0)
+              q[t][r] = 16 * c + 4 * g + r < D ? q[t][r] : 0.0f;
+              q[t][r + 1] = 16 * c + 4 * g + r + 1 < D ? q[t][r + 1] : 0.0f;
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!last) {  // operands of the chunk after next (the last-but-one chunk fetches chunk 0 again: the next tile pair's)
+          const char *nx = sb + ((TAIL && ci == 2) ? 0 : (c + 2) * ST::CHP);
+#pragma unroll
+          for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(nx + fofs[j]);
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);  // (all multiplies ahead of the matrix instructions: split up, the allocator's register reuse costs wait states)
         if (NS > 0) {
 #pragma unroll

@@ -166,6 +166,18 @@ int main() {
   run<2, 0, 0>(H, "-", 4, 0, sink, cyc);
   run<1, 0, 0>(Q, "-", 1, 0, sink, cyc);
   run<1, 0, 0>(Q, "-", 4, 0, sink, cyc);
+  // one stream: n vector instructions behind every matrix instruction, 4 such waves per SIMD
+#define ROW(A, NA) \
+  run<A, 0, 1>(NA, "v_rcp_f32", 4, 0, sink, cyc); run<A, 0, 2>(NA, "v_rcp_f32", 4, 0, sink, cyc); run<A, 0, 4>(NA, "v_rcp_f32", 4, 0, sink, cyc); \
+  run<A, 1, 1>(NA, "v_pk_mul_f32", 4, 0, sink, cyc); run<A, 1, 2>(NA, "v_pk_mul_f32", 4, 0, sink, cyc); \
+  run<A, 3, 1>(NA, "v_mul_f32", 4, 0, sink, cyc); run<A, 3, 2>(NA, "v_mul_f32", 4, 0, sink, cyc); run<A, 3, 4>(NA, "v_mul_f32", 4, 0, sink, cyc); \
+  run<A, 7, 2>(NA, "v_mul_f32_e64", 4, 0, sink, cyc); \
+  run<A, 2, 1>(NA, "v_and_b32", 4, 0, sink, cyc); run<A, 2, 2>(NA, "v_and_b32", 4, 0, sink, cyc); \
+  run<A, 4, 2>(NA, "v_add_f32", 4, 0, sink, cyc); run<A, 5, 1>(NA, "v_pk_add_f32", 4, 0, sink, cyc); run<A, 6, 2>(NA, "v_fma_f32", 4, 0, sink, cyc);
+  ROW(2, H)
+  ROW(0, F)
+  ROW(1, Q)
+  // mixed groups
   run<2, 8, 1>(H, "rcp + mul", 4, 0, sink, cyc);
   run<2, 9, 1>(H, "rcp + 2 mul", 4, 0, sink, cyc);
   run<2, 10, 1>(H, "rcp + pk_mul", 4, 0, sink, cyc);

@@ -325,6 +325,8 @@ int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *
  *   NMFK_FUSE_RED     1: an H half-step whose loop range is split over workgroups gets no reduce launch when the W half-step behind
  *                     it runs the resident form -- that launch sums the partial numerators while it stages H (same bits; off by default:
  *                     every workgroup of a unit repeats the sum, measured 2.5 % slower on a 60-unit share, profiles/r05/dense_probes.txt)
+ *   NMFK_HYB_LAG      0 / 1: the matrix-pipe streaming half-step never / always runs its second lane tile one chunk late (default: where a wave
+ *                     walks 32 chunks or more; same bits either way)
  *   NMFK_SP_BLK       0: sparse X in the gather form only (no sliced-ELL copies are built); 2: blocked form whatever the size
  *   NMFK_TARGET_WGS   workgroups a half-step launch should have before loop ranges are split (default 2 x CUs)
  *   NMFK_STREAMS      concurrent launch-group streams (8; 16 for a dozen launch groups or more; sparse X: 1);  NMFK_HOST_TIMING=1: host / GPU wait times on stderr

@@ -84,6 +84,8 @@ struct NmfkStepArgs {
   int32_t force;    // ignore the active flags
   int32_t res_wgs;  // > 0: the split-operand MFMA units run the RESIDENT form of this half-step (nmfk_step_hyb.hip) with
                     // this many workgroups per unit (= sum-table slots they write); 0: the streaming form
+  int32_t lag;      // split-operand streaming form: which half-step instantiation a launch takes -- < 0: the lagged one where a wave walks 32 chunks
+                    // or more (hyb_step_body, LAG), 0: never, > 0: always (NMFK_HYB_LAG; the two give the same bits)
   int32_t fuse_red; // W half-step, resident form: > 0 = the H half-step of this iteration left S = fuse_red partial numerators per unit
                     // (its loop range was split over workgroups) and NO reduce_kernel has run: every workgroup of this launch sums
                     // them while it stages H -- H_new = H .* sum(partials) ./ colsum(W), Mult:67, reduce_kernel's arithmetic --,

@@ -2037,7 +2037,7 @@ void nmfk_launch_step_hyb_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs, 
   const size_t ldsb = sizeof(double) * 18 * 16 + std::max(cross, stage);
   if (objw > 0)
     hipLaunchKernelGGL((hyb_step_kernel<NT, NW, 2>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, objw);
-  else if ((a.D + a.S - 1) / a.S / (ws > 1 ? ws : 1) >= 512)  // loop rows a wave walks: 32 chunks and more run the lagged form (hyb_step_body, LAG)
+  else if (a.lag < 0 ? (a.D + a.S - 1) / a.S / (ws > 1 ? ws : 1) >= 512 : a.lag > 0)  // loop rows a wave walks: 32 chunks and more run the lagged form (hyb_step_body, LAG)
     hipLaunchKernelGGL((hyb_step_kernel<NT, NW, 0>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);
   else
     hipLaunchKernelGGL((hyb_step_kernel<NT, NW, 3>), grid, blk, ldsb, s, a.arena, a.Xalt, a.Xtile, a.runs, a.state, dargs, a.it, u0, 1.0);

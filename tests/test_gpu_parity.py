@@ -1325,6 +1325,35 @@ def test_w_half_step_sums_the_h_partials(NMFk, ctx, oracle, monkeypatch):
             assert np.array_equal(got[k]["H"], ref3[k]["H"]) and np.array_equal(got[k]["W"], ref3[k]["W"]), (rep, k)
 
 
+def test_lagged_streaming_half_step_keeps_the_bits(NMFk, ctx, oracle, monkeypatch):
+    """Round 5: the streaming form of the matrix-pipe half-step runs its second lane tile one chunk late (hyb_step_body, LAG: its reciprocals
+    sit beside the bf16 matrix instructions of the next chunk's first product); launches whose waves walk fewer than 32 chunks take the
+    instantiation without the lag and with the earlier instruction order.  Same products in the same order: NMFK_HYB_LAG = 0 / 1 give the
+    same bits -- whole and ragged loop ranges (a dummy in front of chunk 0, the last chunk's tile behind the loop, masked loop steps), loop
+    ranges split over workgroups and over the waves of a workgroup, every kernel variant, through check iterations."""
+    worst = 0
+    for n, m, ks, R, it in ((1000, 96, [2, 3, 5, 7, 8, 9, 12, 16], 6, 31),     # short ragged loop ranges (1000 = 62.5 chunks, 96 = 6)
+                            (4100, 500, [4, 8, 13, 16], 2, 21),               # few units: loop range split over workgroups / waves
+                            (2650, 192, list(range(2, 17)), 1, 25),
+                            (8192, 512, [3, 6, 11], 16, 12)):                  # the bench shape, whole trips
+        X = np.asfortranarray((0.05 + oracle.uniform_fill(51, 0, n * m)).reshape(n, m).astype(np.float32))
+        ctx.set_X(X)
+        seeds = _seeds(NMFk, 31, ks, R)
+        out = {}
+        for lag in ("0", "1"):
+            monkeypatch.setenv("NMFK_HYB_LAG", lag)
+            out[lag] = ctx.mu_sweep(ks, R, seeds=seeds, maxiter=it, **NOSTOP)
+            assert ctx.last_sweep_info()["mfma_group_units"] == len(ks) * R
+        for k in ks:
+            for key in ("W", "H", "objvalue"):
+                assert np.array_equal(out["0"][k][key], out["1"][k][key]), (n, m, k, key)
+        q = len(ks) - 1
+        W0, H0 = oracle.init_factors(int(seeds[q, 0]), n, m, ks[q])
+        ref = oracle.singlerun(X, ks[q], W0, H0, maxiter=it, **NOSTOP)
+        worst = max(worst, _rel(out["1"][ks[q]]["W"][0] @ out["1"][ks[q]]["H"][0], ref["W"] @ ref["H"], X))
+    assert worst <= 1e-4, worst
+
+
 def test_retire_aware_schedule_on_a_small_sweep(NMFk, ctx, oracle, monkeypatch):
     """Round 4: restarts retire at different iterations (Mult:64); the sweep is re-planned as they do --
     the units still active move to the front of the work list and the launch geometry is re-derived for them

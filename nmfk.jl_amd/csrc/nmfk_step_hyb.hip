@@ -545,7 +545,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
   // registers: the old factor values of the finish are fetched behind the loop instead, like in the 4x4x1 forms).
   // LAGK = false: launches whose waves walk a short loop range (one unit alone, BASELINE configs[1]: the lag's dummy in front and its tail
   // behind cost a chunk -- 44.9 -> 48.0 us per iteration with the lag everywhere)
-  constexpr bool LAG = LAGK && NT == 2 && !OBJ && !SSE;
+  constexpr bool LAG = LAGK && NT == 2 && !OBJ;
   constexpr bool AOLD_EARLY = NS == 0 && !LAG;  // (the 4x4x1 forms carry more accumulators: their old values are fetched behind the loop)
   if (fused) {
     const double *sumB = (const double *)(arena + (which == 0 ? rdp->osumW : rdp->osumH));
@@ -596,7 +596,7 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     f32x4_t plag = {1.f, 1.f, 1.f, 1.f}, bnlag[NSA];
 #pragma unroll
     for (int sn = 0; sn < NSA; ++sn) bnlag[sn] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    bool masklag = false;
+    bool masklag = false, lagv = false;  // lagv: a chunk is behind (SSE: the dummy in front of chunk 0 has no residuals)
     int dchlag = d0;
     if (LAG) {
 #pragma unroll
@@ -654,9 +654,21 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
             // P(t0) + reciprocals(t1 of the previous chunk) | P(t1) + reciprocals(t0) | multiplies of both | second products of both
             p_tile(0, av, p);
             f32x4_t ql;
+            if (SSE) {  // the lagged tile's residuals (the objective this launch also leaves: see q_tile), ahead of its reciprocals
+              float sqs = 0.0f;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float e = xr[(ci + 3) & 3][1][r] - plag[r];
+                if (!FULLT && masklag) e = dchlag + 4 * g + r < d1 ? e : 0.0f;
+                sqs = __builtin_fmaf(e, e, sqs);
+              }
+              spart += (lv[1] && lagv) ? sqs : 0.0f;
+              asm volatile("" : "+v"(spart));
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) ql[r] = __builtin_amdgcn_rcpf(plag[r]);
-            if constexpr (NM == 3) {
+            if constexpr (SSE) {
+            } else if constexpr (NM == 3) {
               HYB_MFMA_THEN_RCP(1) HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(1)
             } else if constexpr (NM == 2) {
               HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(2)
@@ -664,7 +676,8 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
             __builtin_amdgcn_sched_barrier(0);
             p_tile(1, av, p);
             r_tile(0, dch, xr[ci & 3], p, q, mask);
-            if constexpr (NM == 3) {
+            if constexpr (SSE) {
+            } else if constexpr (NM == 3) {
               HYB_MFMA_THEN_RCP(1) HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(1)
             } else if constexpr (NM == 2) {
               HYB_MFMA_THEN_RCP(2) HYB_MFMA_THEN_RCP(2)
@@ -707,6 +720,8 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
             for (int sn = 0; sn < NSA; ++sn) bnlag[sn] = bn[sn];
             masklag = mask;
             dchlag = dch;
+            lagv = true;
+            if (SSE) sse_chunk();
             __builtin_amdgcn_sched_barrier(0);
             continue;
           }
@@ -780,6 +795,17 @@ __device__ __forceinline__ void hyb_step_body(char *arena, const float *__restri
     if constexpr (LAG) {  // the last chunk's second lane tile
       const int sl = (nchunks - 1) & 3;
       f32x4_t xl = sl == 0 ? xr[0][1] : sl == 1 ? xr[1][1] : sl == 2 ? xr[2][1] : xr[3][1];
+      if (SSE) {
+        float sqs = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float e = xl[r] - plag[r];
+          if (masklag) e = dchlag + 4 * g + r < d1 ? e : 0.0f;
+          sqs = __builtin_fmaf(e, e, sqs);
+        }
+        spart += lv[1] ? sqs : 0.0f;
+        sse_chunk();
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = xl[r] * __builtin_amdgcn_rcpf(plag[r]);
@@ -1940,9 +1966,9 @@ __global__ __launch_bounds__(64 * (NW > 8 ? NW : 8), MODE == 1 ? 2 : 4) void hyb
                                                        const NmfkStepArgs *__restrict__ gp, int it, int u0, double weight) {
   extern __shared__ double lds[];
   switch (runs[u0 + blockIdx.y].hyb) {
-    case 4: hyb_step_body<4, MODE == 1 ? 0 : 1, NT, NW, MODE == 1, MODE == 2, MODE == 0>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
-    case 8: hyb_step_body<8, MODE == 1 ? 0 : 2, NT, NW, MODE == 1, MODE == 2, MODE == 0>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
-    default: hyb_step_body<16, 0, NT, NW, MODE == 1, MODE == 2, MODE == 0>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
+    case 4: hyb_step_body<4, MODE == 1 ? 0 : 1, NT, NW, MODE == 1, MODE == 2, MODE == 0 || MODE == 2>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
+    case 8: hyb_step_body<8, MODE == 1 ? 0 : 2, NT, NW, MODE == 1, MODE == 2, MODE == 0 || MODE == 2>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
+    default: hyb_step_body<16, 0, NT, NW, MODE == 1, MODE == 2, MODE == 0 || MODE == 2>(arena, Xa, Xt, runs, state, gp, it, u0, weight, lds); break;
   }
 }
 

@@ -327,6 +327,8 @@ int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *
  *                     every workgroup of a unit repeats the sum, measured 2.5 % slower on a 60-unit share, profiles/r05/dense_probes.txt)
  *   NMFK_HYB_LAG      0 / 1: the matrix-pipe streaming half-step never / always runs its second lane tile one chunk late (default: where a wave
  *                     walks 32 chunks or more; same bits either way)
+ *   NMFK_WIDE_BN      ranks 17..64 (wide2_step_kernel): 0 = numerators on the fp32 matrix pipe (rounds 3-5), 1 (default) = on the bf16 pipe from exact
+ *                     three-term splits of the ratios where the padded width is 48 or 64 signals, 2 = at 32 signals too (slower there)
  *   NMFK_SP_BLK       0: sparse X in the gather form only (no sliced-ELL copies are built); 2: blocked form whatever the size
  *   NMFK_TARGET_WGS   workgroups a half-step launch should have before loop ranges are split (default 2 x CUs)
  *   NMFK_STREAMS      concurrent launch-group streams (8; 16 for a dozen launch groups or more; sparse X: 1);  NMFK_HOST_TIMING=1: host / GPU wait times on stderr

@@ -121,7 +121,7 @@ struct Sampler {
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, merge = -1, phases = -1;
   int wide_sse = 1, streams = -1, host_timing = 0;
-  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1, wide_groups = 2, cohorts = -1, legacy_geo = 0, fuse_red = 0, hyb_lag = -1;
+  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1, wide_groups = 2, cohorts = -1, legacy_geo = 0, fuse_red = 0, hyb_lag = -1, wide_bn = 1;
   int exp_geo[2][3] = {{-1, -1, -1}, {-1, -1, -1}};  // NMFK_EXP_GEO="hws,hS,hres,wws,wS,wres": forced geometry of the matrix-pipe group (experiments)
   // (not knobs any more -- round 3's A/B switches with their measured settings: one mixed-rank matrix-pipe group, the waves of
   //  a workgroup may split a loop range 8 ways, the small ranks on their own kernel variants, merged sweeps side by side; the
@@ -157,6 +157,7 @@ Tuning read_tuning() {
   geti("NMFK_EXP_LEGACY_GEO", t.legacy_geo);
   geti("NMFK_FUSE_RED", t.fuse_red);
   geti("NMFK_HYB_LAG", t.hyb_lag);
+  geti("NMFK_WIDE_BN", t.wide_bn);
   if (t.cohorts >= 0) t.cohorts = std::max(1, std::min(8, t.cohorts));
   return t;
 }
@@ -1627,6 +1628,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   hs.clampw = 0;
   hs.fuse_red = 0;
   hs.lag = T.hyb_lag;
+  hs.bnum = T.wide_bn;
   NmfkStepArgs ws = hs;
   ws.res_wgs = res_wgs[1];
   ws.X = ctx->Xc;

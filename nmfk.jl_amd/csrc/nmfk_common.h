@@ -91,6 +91,8 @@ struct NmfkStepArgs {
                     // them while it stages H -- H_new = H .* sum(partials) ./ colsum(W), Mult:67, reduce_kernel's arithmetic --,
                     // workgroup 0 of a unit also writes H_new and rowsum(H) (round 5: the reduce launch was 15 % of a 60-unit share).
                     // The H half-step carries the same value: its workgroup 0 copies colsum(W) to NmfkRun::osnapW
+  int32_t bnum;     // wide ranks (wide2_step_kernel): the numerators run on the bf16 matrix pipe from exact three-term splits of the ratios
+                    // (round 6; NMFK_WIDE_BN): 1 (default) = at 48 and 64 signals, 2 = at 32 too, 0 = never (fp32 matrix pipe, rounds 3-5)
   int32_t clampw;   // > 0: the W half-step's fused finishes of a check iteration write max(W, eps()) themselves (Mult:100; the deferred
                     // check of nmfk_mu_sweep: nothing reads W between the half-step and the clamp, the pass then only walks H).
                     // The value is the sweep's maxiter: the check AT maxiter is not deferred (no half-step follows), its objective

@@ -95,6 +95,57 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, uint32_t &h, uin
   l = bf16_pack2(r2);
 }
 
+// ---- numerators on the bf16 pipe (round 6; wide ranks only) ----------------------------------------------------------
+// The second product N += B' Q as v_mfma_f32_16x16x32_bf16 (three per block of 16 signals, lane tile and chunk: 51 matrix cycles)
+// instead of four v_mfma_f32_16x16x4_f32 (128, and an fp32 matrix instruction holds the SIMD's vector issue port for all of its 32
+// cycles): the ratios q are split into three bf16 terms like the factors -- by TRUNCATION, q = q_h + q_m + q_l exactly (8 + 8 + 8
+// significand bits), with plain vector instructions only (v_and_b32 / v_sub_f32 for the residuals, v_perm_b32 to pack: the upper
+// halves of (q0, q1) ARE the truncated terms; a packed conversion or v_dot2c_f32_bf16 costs 12 cycles beside a bf16 matrix
+// instruction, and the latter is not exact: profiles/r06/bf16_numerators_probe.txt).  The six products of weight >= 2^-16 are kept
+// like in the first product (b_h q_h, b_m q_h, b_l q_h, b_h q_m, b_m q_m, b_h q_l; dropped: below 2^-24 of |b||q|, i.e. below fp32
+// rounding).  A lane of the first product's output holds the ratios of loop steps 4g .. 4g + 3 of ITS lane element, which is one
+// half of an 8 x bf16 K-slice of the B operand when the contraction slots are ordered (k-lane group g: [term x of steps 4g..4g+3 |
+// term y of the same steps]) -- no cross-lane movement; the loop factor's planes in LDS are laid out to match.
+//   MFMA 0: A = (b_h | b_m), B = (q_h | q_h)      MFMA 1: A = (b_h | b_m), B = (q_m | q_m)      MFMA 2: A = (b_l | b_h), B = (q_h | q_l)
+// -- the duplicated halves sit on the RATIOS' side, whose operand words are built once per lane tile and chunk and serve every block
+// of 16 signals; the loop factor's two operand forms (b_l | b_h) and (b_h | b_m) are read ready-made from LDS (16 bytes per lane each).
+// The split costs 7.5 plain instructions per ratio: it pays where a ratio meets 32 signals or more (wide2_step_kernel), not at
+// k <= 16 (the probe: - 1 %).
+__device__ __forceinline__ uint32_t hyb_pack_hi(float a, float b) {  // (upper half of a, upper half of b): one v_perm_b32
+  return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x07060302u);
+}
+__device__ __forceinline__ float hyb_trunc_rest(float v) {  // v - (v truncated to bf16): exact
+  return v - __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
+}
+struct HybQ {  // B operands of a lane tile's four ratios (steps 4g .. 4g + 3 of the chunk; low half of a word = the even step's term)
+  bf16x8_t hh, mm, hl;
+};
+__device__ __forceinline__ HybQ hyb_split_q(const f32x4_t q) {
+  float r1[4], r2[4];
+  const uint32_t h01 = hyb_pack_hi(q[0], q[1]), h23 = hyb_pack_hi(q[2], q[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r1[i] = hyb_trunc_rest(q[i]);
+  const uint32_t m01 = hyb_pack_hi(r1[0], r1[1]), m23 = hyb_pack_hi(r1[2], r1[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r2[i] = hyb_trunc_rest(r1[i]);
+  const uint32_t l01 = hyb_pack_hi(r2[0], r2[1]), l23 = hyb_pack_hi(r2[2], r2[3]);
+  HybQ o;
+  o.hh = __builtin_bit_cast(bf16x8_t, (u32x4_t){h01, h23, h01, h23});
+  o.mm = __builtin_bit_cast(bf16x8_t, (u32x4_t){m01, m23, m01, m23});
+  o.hl = __builtin_bit_cast(bf16x8_t, (u32x4_t){h01, h23, l01, l23});
+  return o;
+}
+// second product of a lane tile and block of 16 signals; alh / ahm: the loop factor's operand forms of signal c16, steps [4g, 4g + 4)
+__device__ __forceinline__ f32x4_t hyb_bnum_mfma(const bf16x8_t alh, const bf16x8_t ahm, const HybQ &q, f32x4_t acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm, q.hh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm, q.mm, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alh, q.hl, acc, 0, 0, 0);
+  return acc;
+}
+// bytes of a block of 16 signals x 16 loop steps in the two operand forms: plane (b_l | b_h), plane (b_h | b_m), each [k-lane group g][signal]
+// 16 bytes (+ 16: the blocks' rows start on different banks for the staging writes)
+constexpr int HYB_BN_BLK = 2048 + 16;
+
 // ------------------------------------------------------------------------------------------------------
 // tiled copy of X for one half-step: src element (l, d) at src[d + l*D]; out block (l / 16, d / 16) = 256 floats in
 // the order the MFMA layout consumes them: float index ((g*16 + c16)*4 + r) <-> l = 16 tl + c16, d = 16 td + 4g + r.
@@ -1530,14 +1581,41 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
 // buffer that holds the current H, whole loop range, first product only, one partial per workgroup (256 rows of X) in
 // ossepart[tile] like sse_kernel.  MODE 2: the half-step, and the objective of the factors it reads as a by-product (one partial
 // per workgroup in ossepart[blockIdx.x]; see hyb_step_body's SSE mode and the deferred check of nmfk_mu_sweep).
-template <int NB, int NT, int MODE>
+// Order of the first product's matrix instructions in the BN form's explicit pipeline: slots that use the same A operand (plane of the loop
+// factor) are adjacent, so that it is read from LDS once.  ord(slot) = the instruction index j of first_product's loops; load_of(slot) = running
+// number of the slot's A operand; first(load) = the first slot that uses it; NL = operands per chunk.
+template <int NB>
+struct WideFpOrder {
+  static constexpr int NM = 3 * NB, NL = NB == 2 ? 3 : 6;
+  static constexpr int ord(int s) {
+    constexpr int o2[6] = {0, 1, 4, 2, 3, 5};                              // term pairs (hh, hm, hl | mh, mm | lh)
+    constexpr int o3[9] = {0, 1, 4, 2, 3, 5, 6, 7, 8};                     // the same for block g, then the three of block 4 + (g & 1)
+    constexpr int o4[12] = {0, 2, 8, 1, 3, 9, 4, 6, 5, 7, 10, 11};         // j = 2 pair + block: h of block 0 (pairs 0, 1, 4), h of block 1, m, m, l, l
+    return NB == 2 ? o2[s < 6 ? s : 0] : NB == 3 ? o3[s < 9 ? s : 0] : o4[s < 12 ? s : 0];
+  }
+  static constexpr int first(int l) {
+    constexpr int f2[3] = {0, 3, 5}, f3[6] = {0, 3, 5, 6, 7, 8}, f4[6] = {0, 3, 6, 8, 10, 11};
+    return NB == 2 ? f2[l < 3 ? l : 0] : NB == 3 ? f3[l < 6 ? l : 0] : f4[l < 6 ? l : 0];
+  }
+  static constexpr int load_of(int s) {
+    int l = 0;
+    for (int i = 1; i < NL; ++i)
+      if (first(i) <= s) l = i;
+    return l;
+  }
+};
+// BN (round 6): the numerators on the bf16 pipe (see hyb_split_q): the second product's operand block is staged as three bf16 term
+// planes per block of 16 signals, loop steps contiguous ([term][k-lane group g][signal][4 steps] = 8 bytes per lane).
+template <int NB, int NT, int MODE, bool BN = false>
 __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const float *__restrict__ Xt, const NmfkRun *__restrict__ runs,
                                                             const NmfkState *__restrict__ state, const NmfkStepArgs *__restrict__ gp,
                                                             int it, int u0, double weight) {
   extern __shared__ double lds[];  // den[64], red[8][64], then two staged blocks
   constexpr bool OBJ = MODE == 1, SSE = MODE == 2;
   constexpr int KS = 16 * NB, NM = 3 * NB, NH = 2 * NB, CPB = 4;
-  constexpr int CHP = 3 * NH * 256, CHT = NB * 4 * 256;  // bytes of a chunk's split planes / transposed blocks
+  static_assert(!(BN && MODE == 1), "the objective mode has no second product");
+  typedef WideFpOrder<NB> FPL;
+  constexpr int CHP = 3 * NH * 256, CHT = BN ? NB * HYB_BN_BLK : NB * 4 * 256;  // bytes of a chunk's split planes / transposed blocks
   constexpr int BFB = CPB * CHP, STB = BFB + CPB * CHT;
   constexpr int PPR = KS / 2, NITEM = 16 * CPB * PPR, NI = NITEM / 512;  // staging items (row, signal pair) per thread
   constexpr int NSUB = NB == 3 ? 1 : NB / 2;  // blocks of eight signals of the lane factor a lane needs per term (sub = g + 4 i)
@@ -1659,9 +1737,8 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
       sv[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsb, vo + 4, row0 * kp * 4, 0));
     }
   };
-  auto stage_write = [&](char *dst, int row0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
+  auto stage_write_item = [&](char *dst, int row0, int i) __attribute__((always_inline)) {
+    {
       const int q = tid + 512 * i, r = q / PPR, cp = q - r * PPR;
       const bool ok = row0 + r < D;  // (rows past the factor's end and padding signals are staged as zeros)
       const float v0 = (ok && 2 * cp < kp) ? sv[i][0] : 0.0f, v1 = (ok && 2 * cp + 1 < kp) ? sv[i][1] : 0.0f;
@@ -1673,12 +1750,26 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
       *(uint32_t *)(d + NH * 256) = m;
       *(uint32_t *)(d + 2 * NH * 256) = lo;
       // transposed: plane (block of sixteen signals, loop steps [4g, 4g + 4)), signal c at (c & 15) * 16: four fp32 values
-      if (!OBJ) {
+      if (!OBJ && BN) {  // planes (b_l | b_h) and (b_h | b_m) of a block of 16 signals: (k-lane group rr >> 2, signal c) at 16 (16 (rr >> 2) + c), step rr & 3 at + 2 (rr & 3)
+        char *tr = dst + BFB + ch * CHT + ((2 * cp) >> 4) * HYB_BN_BLK + ((rr >> 2) * 16 + ((2 * cp) & 15)) * 16 + (rr & 3) * 2;
+        *(uint16_t *)(tr) = (uint16_t)lo;
+        *(uint16_t *)(tr + 16) = (uint16_t)(lo >> 16);
+        *(uint16_t *)(tr + 8) = (uint16_t)h;
+        *(uint16_t *)(tr + 8 + 16) = (uint16_t)(h >> 16);
+        *(uint16_t *)(tr + 1024) = (uint16_t)h;
+        *(uint16_t *)(tr + 1024 + 16) = (uint16_t)(h >> 16);
+        *(uint16_t *)(tr + 1024 + 8) = (uint16_t)m;
+        *(uint16_t *)(tr + 1024 + 8 + 16) = (uint16_t)(m >> 16);
+      } else if (!OBJ) {
         char *tr = dst + BFB + ch * CHT + (((2 * cp) >> 4) * 4 + (rr >> 2)) * 256 + ((2 * cp) & 15) * 16 + (rr & 3) * 4;
         *(float *)(tr) = v0;
         *(float *)(tr + 16) = v1;
       }
     }
+  };
+  auto stage_write = [&](char *dst, int row0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) stage_write_item(dst, row0, i);
   };
 
   // inputs of the fused finish, requested before the loop: the other factor's sum table (denominators of Mult:67 / Mult:70).
@@ -1731,10 +1822,32 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
       }
     }
     };
+    // the same operands one at a time, for the explicit pipeline of the BN form: A operand of matrix instruction j of chunk chx, B operand of tile t
+    auto fp_av = [&](const char *cur, int chx, int j) __attribute__((always_inline)) -> bf16x8_t {
+      int plane;
+      if (NB == 3) {
+        const int q = j - 6;
+        plane = j < 6 ? tA[j < 6 ? j : 0] * NH + g : ((q < 2 ? q : (g >= 2 ? 2 : 0)) * NH + 4 + (g & 1));
+      } else {
+        const int tp = NB == 4 ? (j >> 1) : j, i = NB == 4 ? (j & 1) : 0;
+        plane = tA[tp] * NH + 4 * i + g;
+      }
+      return *(const bf16x8_t *)(cur + chx * CHP + plane * 256 + c16 * 16);
+    };
+    auto fp_b = [&](int t, int j) __attribute__((always_inline)) -> bf16x8_t {
+      if (NB == 3) return j < 6 ? bopt[t][tB[j < 6 ? j : 0]][0] : (j < 8 ? bq01[t] : bq2[t]);
+      const int tp = NB == 4 ? (j >> 1) : j, i = NB == 4 ? (j & 1) : 0;
+      return bopt[t][tB[tp]][i];
+    };
+    // second product's operand forms of block nb of chunk chx: plane 0 = (b_l | b_h), plane 1 = (b_h | b_m)
+    auto sp_av = [&](const char *cur, int chx, int nb, int plane) __attribute__((always_inline)) -> bf16x8_t {
+      return *(const bf16x8_t *)(cur + BFB + chx * CHT + nb * HYB_BN_BLK + plane * 1024 + (g * 16 + c16) * 16);
+    };
     const int nblocks = (nchunks + CPB - 1) / CPB;
     f32x4_t pnext[NT];  // PIPE: W*H of the block's next chunk (see the chunk loop)
 #pragma unroll
     for (int t = 0; t < NT; ++t) pnext[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t ringF[4];  // BN: A operands of the first product in flight (see the chunk loop)
     for (int blk = 0; blk < nblocks; ++blk) {
       char *cur = sb + (blk & 1) * STB, *nxt = sb + ((blk & 1) ^ 1) * STB;
       const bool more = blk + 1 < nblocks;
@@ -1752,6 +1865,110 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
         // profiles/r05/issue_rates.txt).  Not across a block's end (the other LDS buffer is being rewritten), not at 32 signals (8 more
         // registers would take that instantiation from four waves per SIMD to three).
         constexpr bool PIPE = NB >= 3 && !OBJ;
+        if constexpr (BN) {
+          // ---- numerators on the bf16 pipe (round 6): an EXPLICIT software pipeline.  With two waves per SIMD nothing hides an LDS round trip
+          // or a chain of vector instructions, so the chunk is laid out slot by slot (a slot = one A operand, NT matrix instructions; a fence behind
+          // each): phase 1 = the first product of the block's NEXT chunk, with the reciprocals, multiplies and three-term split of THIS chunk's
+          // ratios dealt over its slots (12 pieces: one per ratio, one per pair of operand words); phase 2 = this chunk's second product.  Every A
+          // operand is requested from LDS three slots before its matrix instructions (a ring of four registers for the first product; the second
+          // product's two forms double-buffered by block of 16 signals).  The first product's matrix instructions run in the order that keeps equal A
+          // operands together (the loop factor's h term serves three term pairs, m two, l one: WideFpOrder), so an operand is read once.
+          constexpr int NPIECE = 6 * NT;
+          const bool next = ch + 1 < CPB, next2 = ch + 2 < CPB;  // (compile-time after unrolling; products of chunks behind the range's end are computed from staged rows and dropped)
+          const bool edge = dch + 16 > d1;
+          f32x4_t p[NT];
+          if (ch == 0) {
+            first_product(cur, 0, p);
+            ringF[0] = fp_av(cur, 1, FPL::ord(0));
+          } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) p[t] = pnext[t];
+          }
+          if (SSE) {  // the residuals of the chunk (fp32 squares, the chunk's partial into the fp64 sum: the OBJ mode's error budget)
+            float part = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              float sqs = 0.0f;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float e = xr[ch & 3][t][r] - p[t][r];
+                e = (!edge || dch + 4 * g + r < d1) ? e : 0.0f;
+                sqs = __builtin_fmaf(e, e, sqs);
+              }
+              part += lv[t] ? sqs : 0.0f;
+            }
+            asm volatile("" : "+v"(part));  // (anchor: see hyb_step_body)
+            ssum += (double)part;
+          }
+          float qv[NT][4], r1[NT][4], r2[NT][4];
+          uint32_t hw[NT][2], mw[NT][2], lw[NT][2];
+          auto piece = [&](int i) __attribute__((always_inline)) {
+            if (i < 4 * NT) {
+              const int t = i >> 2, r = i & 3;
+              float v = xr[ch & 3][t][r] * __builtin_amdgcn_rcpf(p[t][r]);
+              v = (!edge || dch + 4 * g + r < d1) ? v : 0.0f;  // loop steps beyond the range give zero
+              qv[t][r] = v;
+              r1[t][r] = hyb_trunc_rest(v);
+              r2[t][r] = hyb_trunc_rest(r1[t][r]);
+            } else {
+              const int e = i - 4 * NT, t = e >> 1, hf = e & 1;
+              hw[t][hf] = hyb_pack_hi(qv[t][2 * hf], qv[t][2 * hf + 1]);
+              mw[t][hf] = hyb_pack_hi(r1[t][2 * hf], r1[t][2 * hf + 1]);
+              lw[t][hf] = hyb_pack_hi(r2[t][2 * hf], r2[t][2 * hf + 1]);
+            }
+          };
+          bf16x8_t ahm[2], alh[2];
+          if (next) {
+#pragma unroll
+            for (int sl = 0; sl < NM; ++sl) {
+#pragma unroll
+              for (int ld = 1; ld < FPL::NL; ++ld)
+                if (FPL::first(ld) - 3 == sl || (sl == 0 && FPL::first(ld) < 3)) ringF[ld & 3] = fp_av(cur, ch + 1, FPL::ord(FPL::first(ld)));
+              if (sl + 3 == NM) ahm[0] = sp_av(cur, ch, 0, 1);
+              if (sl + 2 == NM) alh[0] = sp_av(cur, ch, 0, 0);
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+                pnext[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ringF[FPL::load_of(sl) & 3], fp_b(t, FPL::ord(sl)), sl == 0 ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : pnext[t], 0, 0, 0);
+#pragma unroll
+              for (int i = sl * NPIECE / NM; i < (sl + 1) * NPIECE / NM; ++i) piece(i);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          } else {  // the block's last chunk: nothing to put the ratios beside
+            ahm[0] = sp_av(cur, ch, 0, 1);
+            alh[0] = sp_av(cur, ch, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i) piece(i);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          HybQ qs[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            qs[t].hh = __builtin_bit_cast(bf16x8_t, (u32x4_t){hw[t][0], hw[t][1], hw[t][0], hw[t][1]});
+            qs[t].mm = __builtin_bit_cast(bf16x8_t, (u32x4_t){mw[t][0], mw[t][1], mw[t][0], mw[t][1]});
+            qs[t].hl = __builtin_bit_cast(bf16x8_t, (u32x4_t){hw[t][0], hw[t][1], lw[t][0], lw[t][1]});
+          }
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const bool lastb = nb + 1 == NB;
+            // the NEXT block's rows (requested at this block's start) are converted and written to the other LDS buffer HERE, beside the second
+            // product of the block's third chunk -- a phase with no vector work of its own -- instead of behind the block with the matrix pipe idle
+            static_assert(NI <= NB, "one staging item per block of 16 signals");
+            if (more && ch == CPB - 2 && nb < NI) stage_write_item(nxt, d0 + 64 * (blk + 1), nb);
+            if (!lastb) ahm[(nb + 1) & 1] = sp_av(cur, ch, nb + 1, 1);
+            else if (next2) ringF[0] = fp_av(cur, ch + 2, FPL::ord(0));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm[nb & 1], qs[t].hh, acc[t][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!lastb) alh[(nb + 1) & 1] = sp_av(cur, ch, nb + 1, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm[nb & 1], qs[t].mm, acc[t][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alh[nb & 1], qs[t].hl, acc[t][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          continue;
+        }
         f32x4_t p[NT];
         if (!PIPE || ch == 0) first_product(cur, ch, p);
         if (PIPE && ch == 0) __builtin_amdgcn_sched_barrier(0);  // (the group barriers below pair the NEXT chunk's matrix instructions with the reciprocals)
@@ -1849,7 +2066,7 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (more) stage_write(nxt, d0 + 64 * (blk + 1));
+      if (more && !(BN && !OBJ)) stage_write(nxt, d0 + 64 * (blk + 1));
     }
   }
   // acc[t][nb][r] = numerator of signal c = 16 nb + 4g + r at lane element l0 + 16t + c16
@@ -2121,35 +2338,41 @@ void nmfk_launch_step_wide2_f32(const NmfkStepArgs &a, const NmfkStepArgs *dargs
   const int lpw = 16 * NT * 8, ntile = (a.L + lpw - 1) / lpw;
   const dim3 grid(ntile * a.S, cnt), blk(512);
   const int nb = wide2_nb(kp);
-  const size_t chunkb = 3 * (size_t)(2 * nb) * 256 + (size_t)nb * 1024;
+  // numerators on the bf16 pipe (NmfkStepArgs::bnum): by default at 48 and 64 signals -- measured at 65536 x 2048, 8 restarts, ms per iteration fp32 -> bf16
+  // numerators: k = 64 3.58 -> 3.10, k = 48 2.83 -> 2.62, k = 40 2.81 -> 2.63; at 32 signals the form needs 164 registers instead of 128, i.e. one
+  // workgroup per CU instead of two, and loses: k = 32 2.02 -> 2.31, k = 24 1.96 -> 2.21 (profiles/r06/wide_bn_ab.txt).  bnum = 2 forces it everywhere.
+  const bool bn = a.bnum >= 2 || (a.bnum == 1 && nb >= 3);
+  const size_t chunkb = 3 * (size_t)(2 * nb) * 256 + (size_t)nb * (bn ? HYB_BN_BLK : 1024);
   const size_t ldsb = sizeof(double) * 9 * NMFK_MAX_K + 2 * 4 * chunkb;
   // objw > 0: the launch also leaves the objective of the factors it reads (scaled by objw^2; grid.x partials per unit)
-#define NMFK_WIDE2_LAUNCH(NBV, MODE, W) \
-  hipLaunchKernelGGL((wide2_step_kernel<NBV, NT, MODE>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, W)
-  if (nb == 2) {
-    if (objw > 0)
-      NMFK_WIDE2_LAUNCH(2, 2, objw);
-    else
-      NMFK_WIDE2_LAUNCH(2, 0, 1.0);
-  } else if (nb == 3) {
-    static std::atomic<uint64_t> lds_ok3{0}, lds_ok3s{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
-    if (objw > 0) {
-      nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<3, NT, 2>, lds_ok3s, 160 * 1024);
-      NMFK_WIDE2_LAUNCH(3, 2, objw);
-    } else {
-      nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<3, NT, 0>, lds_ok3, 160 * 1024);
-      NMFK_WIDE2_LAUNCH(3, 0, 1.0);
-    }
-  } else {
-    static std::atomic<uint64_t> lds_ok{0}, lds_oks{0};  // (more than 64 KB of dynamic LDS: per kernel and device)
-    if (objw > 0) {
-      nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<4, NT, 2>, lds_oks, 160 * 1024);
-      NMFK_WIDE2_LAUNCH(4, 2, objw);
-    } else {
-      nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<4, NT, 0>, lds_ok, 160 * 1024);
-      NMFK_WIDE2_LAUNCH(4, 0, 1.0);
-    }
-  }
+  // (every instantiation may need more than 64 KB of dynamic LDS: allowed per kernel and device)
+#define NMFK_WIDE2_LAUNCH(NBV, MODE, BNV, W)                                                                  \
+  do {                                                                                                        \
+    static std::atomic<uint64_t> lds_ok{0};                                                                   \
+    nmfk_allow_dynamic_lds((const void *)wide2_step_kernel<NBV, NT, MODE, BNV>, lds_ok, 160 * 1024);          \
+    hipLaunchKernelGGL((wide2_step_kernel<NBV, NT, MODE, BNV>), grid, blk, ldsb, s, a.arena, a.Xtile, a.runs, a.state, dargs, a.it, u0, W); \
+  } while (0)
+#define NMFK_WIDE2_PICK(NBV)                    \
+  do {                                          \
+    if (objw > 0) {                             \
+      if (bn)                                   \
+        NMFK_WIDE2_LAUNCH(NBV, 2, true, objw);  \
+      else                                      \
+        NMFK_WIDE2_LAUNCH(NBV, 2, false, objw); \
+    } else {                                    \
+      if (bn)                                   \
+        NMFK_WIDE2_LAUNCH(NBV, 0, true, 1.0);   \
+      else                                      \
+        NMFK_WIDE2_LAUNCH(NBV, 0, false, 1.0);  \
+    }                                           \
+  } while (0)
+  if (nb == 2)
+    NMFK_WIDE2_PICK(2);
+  else if (nb == 3)
+    NMFK_WIDE2_PICK(3);
+  else
+    NMFK_WIDE2_PICK(4);
+#undef NMFK_WIDE2_PICK
 #undef NMFK_WIDE2_LAUNCH
 }
 

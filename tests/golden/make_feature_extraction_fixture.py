@@ -58,5 +58,8 @@ np.savez_compressed(os.path.join(HERE, "feature_extraction.npz"), X=X, s4=s4, pr
                     nkrange=np.arange(2, 11), kopt=4,
                     fit_printed=np.array([563.4562, 205.1045, 0.0260611, 0.01929668, 0.006752373, 0.006230307, 0.004256726, 0.009267875, 0.004952552]),
                     silhouette_printed=np.array([0.9961238, 0.9877389, 0.9951292, -0.6128532, -0.612744, -0.7747081, -0.6025868, -0.5954714, -0.6026156]),
-                    of_min_max_k2=np.array([563.4561839705091, 571.0956047569299]), of_min_max_k3=np.array([205.10453576810346, 205.44013709359942]))
+                    of_min_max_k2=np.array([563.4561839705091, 571.0956047569299]), of_min_max_k3=np.array([205.10453576810346, 205.44013709359942]),
+                    # 'OF: min ... max ... mean ... std ...' of k = 3 and k = 4 (feature_extraction.md:214, :223): where the stop rule left the ten restarts
+                    of_stats_k3=np.array([205.10453576810346, 205.44013709359942, 205.2558183299092, 0.10764194146505947]),
+                    of_stats_k4=np.array([0.02606110346539826, 0.3285930894206071, 0.08570976712343938, 0.09054762017310256]))
 print("wrote", os.path.join(HERE, "feature_extraction.npz"))

@@ -117,6 +117,37 @@ def test_wide_ranks_fp32_mfma_path(NMFk, ctx, oracle, k, shape):
         np.testing.assert_allclose(res["H"][r].sum(axis=1), 1.0, atol=1e-4)
 
 
+@pytest.mark.parametrize("k", [17, 24, 32, 40, 48, 64])
+@pytest.mark.parametrize("shape", [(130, 70), (96, 2100), (700, 300)])
+def test_wide_rank_numerators_on_either_matrix_pipe(NMFk, ctx, oracle, k, shape, monkeypatch):
+    """Round 6: wide2_step_kernel's second product (the numerators of Mult:67 / Mult:70) on the bf16 matrix pipe from exact three-term
+    splits of the ratios (NMFK_WIDE_BN=2: every padded width; the default takes that form at 48 and 64 signals) against the fp32 matrix pipe
+    (NMFK_WIDE_BN=0, rounds 3-5): both within the fp32 tolerance of the Float64 oracle, and within 5e-6 of each other but not equal (the forms
+    differ in the last bits: the bf16 form drops products below 2^-24 of |b||q| and sums in another order).  Ragged sizes; a loop range long
+    enough for several staged blocks (the bf16 form converts the next block beside the third chunk's second product); fixed budget, and a
+    default-stop sweep whose deferred check takes the half-step that also leaves the objective (MODE 2)."""
+    n, m = shape
+    X = (0.05 + oracle.uniform_fill(21, 0, n * m)).reshape(n, m).astype(np.float32)
+    ctx.set_X(X)
+    seeds = _seeds(NMFk, 6, [k], 2)
+    out = {}
+    for bn in ("0", "2"):
+        monkeypatch.setenv("NMFK_WIDE_BN", bn)
+        out[bn] = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=20, **NOSTOP)[k]
+        out[bn + "stop"] = ctx.mu_sweep([k], 2, seeds=seeds, maxiter=60)[k]
+    monkeypatch.delenv("NMFK_WIDE_BN")
+    for r in range(2):
+        e = _rel(out["0"]["W"][r] @ out["0"]["H"][r], out["2"]["W"][r] @ out["2"]["H"][r], X)
+        assert 0.0 < e <= 5e-6, (k, r, e)
+        W0, H0 = oracle.init_factors(int(seeds[0, r]), n, m, k)
+        ref = oracle.singlerun(X, k, W0, H0, maxiter=20, **NOSTOP)
+        for bn in ("0", "2"):
+            assert _rel(out[bn]["W"][r] @ out[bn]["H"][r], ref["W"] @ ref["H"], X) <= 1e-4, (k, r, bn)
+            assert abs(out[bn]["objvalue"][r] - ref["objvalue"]) <= 1e-4 * ref["objvalue"]
+    assert np.array_equal(out["0stop"]["iters"], out["2stop"]["iters"]) and np.array_equal(out["0stop"]["reason"], out["2stop"]["reason"])
+    np.testing.assert_allclose(out["0stop"]["objvalue"], out["2stop"]["objvalue"], rtol=2e-5)
+
+
 @pytest.mark.parametrize("k", [20, 33, 64])
 @pytest.mark.parametrize("shape", [(300, 70), (130, 2100)])
 def test_wide_rank_objective_on_the_matrix_pipe(NMFk, ctx, oracle, k, shape):

@@ -146,7 +146,10 @@ def test_feature_extraction_notebook_known_answers(oracle):
     for seed in (2021, 3):
         W, H, fit, rob, aic, kopt, det = oracle.execute(X, range(2, 11), 10, seed=seed)
         assert kopt == int(z["kopt"]) == 4
-        assert abs(rob[1] - sil_ref[0]) < 3e-3 and abs(rob[2] - sil_ref[1]) < 6e-3 and abs(rob[3] - sil_ref[2]) < 5e-2 and rob[3] > 0.9
+        assert abs(rob[1] - sil_ref[0]) < 3e-3 and abs(rob[2] - sil_ref[1]) < 6e-3
+        # k = 4: NOT a pin of today's stop rule -- the offset (-0.017 .. -0.038 over four seeds) goes with an objective offset, see
+        # test_feature_extraction_notebook_objective_distributions: the notebook's older NMFk left its restarts closer to the exact fit
+        assert 0.95 < rob[3] < sil_ref[2]
         assert all(-0.9 < rob[k - 1] < -0.3 for k in range(5, 11)) and all(-0.9 < v < -0.3 for v in sil_ref[3:])
         # the notebook's criterion: the ranks above the cutoff are exactly 2, 3, 4, and their ORDER by robustness is the notebook's
         assert [k for k in ks if rob[k - 1] > 0.5] == [2, 3, 4] == [k for k, v in zip(ks, sil_ref) if v > 0.5]
@@ -154,6 +157,43 @@ def test_feature_extraction_notebook_known_answers(oracle):
         of2 = np.sort(det[2]["objvalue"].astype(np.float64) ** 2)
         assert of2[0] > 0.999 * z["of_min_max_k2"][0] and of2[-1] < 1.01 * z["of_min_max_k2"][1]  # 'OF: min ... max ...', :206
         assert float(fit[3]) ** 2 < 0.1  # k = 4 reproduces X (print: 0.0260611)
+
+
+def test_feature_extraction_notebook_objective_distributions(oracle):
+    """Where the stop rule leaves the ten restarts: the notebook's 'OF: min / max / mean' lines of k = 3 and k = 4
+    (notebooks/feature_extraction/feature_extraction.md:214, :223; sum of squares in that notebook's convention, like its 'Fit') against
+    the oracle's ten restarts over four seeds (round 5 verdict, weak #2: does the k = 4 silhouette offset -- oracle 0.9575..0.9780
+    against the printed 0.9951, four of four seeds below -- go with an objective offset?).
+
+    Measured (round 6):                 notebook                     oracle, seeds 2021 / 3 / 1 / 2
+      k = 3   min                       205.1045                     204.93 .. 205.02        (X is rebuilt to ~2e-3 of its entries)
+              mean                      205.2558                     205.07 .. 205.14
+              max                       205.4401                     205.16 .. 205.85
+      k = 4   min                       0.02606                      0.0228 .. 0.0317        -- the best restart ends where the notebook's does
+              mean                      0.0857                       0.158 .. 0.231          -- 1.8 .. 2.7 x the notebook's, four of four seeds
+              max                       0.3286                       0.555 .. 0.786
+    At k = 3 (a unique optimum the rule reaches from everywhere) the distributions agree to 1e-3.  At k = 4 -- an exactly rank-4 X,
+    the objective keeps falling and the ten solutions differ only by where the stagnation test (Mult:79-98: maxbaditers = 10 checks
+    without an improvement of tolOF = 1e-3) cuts them off -- the best restart agrees, the TYPICAL restart of today's rule stops
+    ~2 x farther out than the notebook's did: the silhouette offset at k = 4 does go with an objective offset.  The notebook was
+    produced by an older NMFk (its log prints src/NMFkExecute.jl:15 / :23 for lines that sit elsewhere today), so its k = 4
+    silhouette is evidence about THAT version's stop rule; it pins today's rule only through kopt, the ranks above the cutoff, and
+    the k = 2, 3 values (tests/golden/README.md says so).  The bands below are the measured ones with a margin."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feature_extraction.npz"))
+    X = z["X"]
+    k3, k4 = z["of_stats_k3"], z["of_stats_k4"]  # min, max, mean, std
+    ratios = []
+    for seed in (2021, 3, 1, 2):
+        W, H, fit, rob, aic, kopt, det = oracle.execute(X, range(3, 5), 10, seed=seed)
+        of3 = np.asarray(det[3]["objvalue"], dtype=np.float64) ** 2
+        of4 = np.asarray(det[4]["objvalue"], dtype=np.float64) ** 2
+        assert abs(of3.min() - k3[0]) < 1.5e-3 * k3[0] and abs(of3.mean() - k3[2]) < 1.5e-3 * k3[2] and of3.max() < 1.005 * k3[1], (seed, of3)
+        assert 0.8 * k4[0] < of4.min() < 1.3 * k4[0], (seed, of4.min())       # the best restart: where the notebook's best is
+        assert 1.5 * k4[2] < of4.mean() < 3.2 * k4[2], (seed, of4.mean())     # the typical restart: stops farther out than the notebook's
+        assert 1.4 * k4[1] < of4.max() < 2.8 * k4[1], (seed, of4.max())
+        assert 0.95 < rob[3] < z["silhouette_printed"][2]                     # ... and the k = 4 silhouette sits below the printed 0.9951
+        ratios.append(of4.mean() / k4[2])
+    assert min(ratios) > 1.5  # four of four seeds: an offset, not scatter
 
 
 def test_readme_construction_kopt(oracle):

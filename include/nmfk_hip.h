@@ -322,9 +322,10 @@ int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *
  *                     groups of up to f workgroups per CU (default 2)
  *   NMFK_COHORTS      c: the launch group on the matrix-pipe kernels (ranks 2..16) runs as c cohorts of units, each on its own stream, so
  *                     that one cohort's half-step fills the CUs another's leaves idle (default: by the group's size; same bits per unit)
- *   NMFK_FUSE_RED     1: an H half-step whose loop range is split over workgroups gets no reduce launch when the W half-step behind
- *                     it runs the resident form -- that launch sums the partial numerators while it stages H (same bits; off by default:
- *                     every workgroup of a unit repeats the sum, measured 2.5 % slower on a 60-unit share, profiles/r05/dense_probes.txt)
+ *   NMFK_FUSE_RED     1 (EXPERIMENTAL, off by default): an H half-step whose loop range is split over workgroups gets no reduce launch when the
+ *                     W half-step behind it runs the resident form -- that launch sums the partial numerators while it stages H.  The new H has
+ *                     reduce_kernel's bits; rowsum(H) is added in another order, so the results differ from the default path by rounding.
+ *                     Every workgroup of a unit repeats the sum: measured 2.5 % slower on a 60-unit share (profiles/r05/dense_probes.txt)
  *   NMFK_HYB_LAG      0 / 1: the matrix-pipe streaming half-step never / always runs its second lane tile one chunk late (default: where a wave
  *                     walks 32 chunks or more; same bits either way)
  *   NMFK_WIDE_BN      ranks 17..64 (wide2_step_kernel): 0 = numerators on the fp32 matrix pipe (rounds 3-5), 1 (default) = on the bf16 pipe from exact

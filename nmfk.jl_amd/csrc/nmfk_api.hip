@@ -16,6 +16,7 @@
 #include <array>
 #include <deque>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <chrono>
@@ -116,12 +117,14 @@ struct Sampler {
 //   NMFK_SP_BLK       0: sparse X in the gather form only (also: no sliced-ELL copies are built); 2: blocked form whatever the size
 //   NMFK_STREAMS      concurrent rank-group streams (8; sparse X: 1);  NMFK_HOST_TIMING=1 prints the host's share of the loop
 //   NMFK_COHORTS      c: the matrix-pipe launch group runs as c cohorts of units on c streams (default: by the group's size)
-//   NMFK_FUSE_RED     0: an H half-step whose loop range is split over workgroups is finished by reduce_kernel also when the W half-step
-//                     behind it runs the resident form (default: that W half-step sums the partial numerators while it stages H)
+//   NMFK_FUSE_RED     1 (EXPERIMENTAL, off by default): an H half-step whose loop range is split over workgroups gets no reduce launch when the
+//                     W half-step behind it runs the resident form -- that launch sums the partial numerators while it stages H.  The new H has
+//                     reduce_kernel's bits; rowsum(H) is added in another order (rounding-level differences in the next W half-step's
+//                     denominators).  Measured 2.5 % slower on a 60-unit share (profiles/r05/dense_probes.txt), covered by an opt-in test only.
 struct Tuning {
   int target_wgs = -1, wide = 1, hyb = -1, hyb_mink = -1, merge = -1, phases = -1;
   int wide_sse = 1, streams = -1, host_timing = 0;
-  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1, wide_groups = 2, cohorts = -1, legacy_geo = 0, fuse_red = 0, hyb_lag = -1, wide_bn = 1;
+  int hyb_res = 1, wide2 = 1, sp_blk = 1, replan = 1, clamp_always = 0, defer_obj = 1, wide_groups = 2, cohorts = -1, legacy_geo = 0, fuse_red = 0, hyb_lag = -1, wide_bn = 1, debug = 0;
   int exp_geo[2][3] = {{-1, -1, -1}, {-1, -1, -1}};  // NMFK_EXP_GEO="hws,hS,hres,wws,wS,wres": forced geometry of the matrix-pipe group (experiments)
   // (not knobs any more -- round 3's A/B switches with their measured settings: one mixed-rank matrix-pipe group, the waves of
   //  a workgroup may split a loop range 8 ways, the small ranks on their own kernel variants, merged sweeps side by side; the
@@ -158,6 +161,7 @@ Tuning read_tuning() {
   geti("NMFK_FUSE_RED", t.fuse_red);
   geti("NMFK_HYB_LAG", t.hyb_lag);
   geti("NMFK_WIDE_BN", t.wide_bn);
+  geti("NMFK_DEBUG", t.debug);  // (read once per sweep, here: the planner and the sweep print what they decided; 2: every candidate geometry)
   if (t.cohorts >= 0) t.cohorts = std::max(1, std::min(8, t.cohorts));
   return t;
 }
@@ -847,15 +851,13 @@ static int hyb_res_wgs_legacy(int L, int D, int cus, int vmax, int units) {
 }
 // [0] = H half-step (lanes = m columns, loop = n rows), [1] = W half-step
 HybPlan plan_hyb_group(int n, int m, int cus, const HybMix &mix, int target_wgs, bool hyb_res, bool legacy = false,
-                       const int (*exp_geo)[3] = nullptr, bool one_round = false) {
+                       const int (*exp_geo)[3] = nullptr, bool one_round = false, bool dbg = false) {
   HybPlan p;
   const int units = std::max(1, mix.units()), vmax = mix.vmax();
   p.units = units;
   const int target = target_wgs > 0 ? target_wgs : 2 * cus;
   const int target_ws = target_wgs > 0 ? target : hyb_target_ws(cus);
   const int max_ws = Tuning::max_wsplit;
-  const char *dbge = getenv("NMFK_DEBUG");
-  const bool dbg = dbge && atoi(dbge) >= 2;
   for (int which = 0; which < 2; ++which) {
     const int L = which == 0 ? m : n, D = which == 0 ? n : m;
     const int wsN = (max_ws >= 8 && D >= 8 * 64) ? 8 : 4;
@@ -950,15 +952,35 @@ struct HybCohortPlan {
   HybPlan plan;
   int cohorts;
 };
+// The planner is a pure function of its arguments and costs ~2 ms of host time per call (list-schedule simulations of every candidate; a sweep with its
+// tiers makes ~10 calls: ~20 ms at the bench shape, comparable with the GPU time of a short sweep -- ADVICE r5): the plans are memoised per process.
+static HybCohortPlan plan_hyb_cohorts_uncached(int n, int m, int cus, const HybMix &mix, const Tuning &T, bool hyb_res);
 static HybCohortPlan plan_hyb_cohorts(int n, int m, int cus, const HybMix &mix, const Tuning &T, bool hyb_res) {
+  if (T.debug >= 2) return plan_hyb_cohorts_uncached(n, m, cus, mix, T, hyb_res);  // (the candidates are printed while they are costed)
+  static std::mutex mu;
+  static std::map<std::array<int, 16>, HybCohortPlan> memo;
+  const std::array<int, 16> key = {n, m, cus, mix.n16, mix.n8, mix.n4, T.target_wgs, T.legacy_geo, T.cohorts, hyb_res ? 1 : 0,
+                                   T.exp_geo[0][0], T.exp_geo[0][1], T.exp_geo[0][2], T.exp_geo[1][0], T.exp_geo[1][1], T.exp_geo[1][2]};
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+  }
+  const HybCohortPlan r = plan_hyb_cohorts_uncached(n, m, cus, mix, T, hyb_res);
+  std::lock_guard<std::mutex> lk(mu);
+  if (memo.size() > 4096) memo.clear();
+  memo[key] = r;
+  return r;
+}
+static HybCohortPlan plan_hyb_cohorts_uncached(int n, int m, int cus, const HybMix &mix, const Tuning &T, bool hyb_res) {
   HybCohortPlan r;
-  r.plan = plan_hyb_group(n, m, cus, mix, T.target_wgs, hyb_res, T.legacy_geo != 0, T.exp_geo);
+  r.plan = plan_hyb_group(n, m, cus, mix, T.target_wgs, hyb_res, T.legacy_geo != 0, T.exp_geo, false, T.debug >= 2);
   const bool model = !(T.legacy_geo || T.target_wgs > 0);
   r.cohorts = T.cohorts > 0 ? T.cohorts : model ? nmfk_default_cohorts(r.plan, n, m, cus) : 1;
   r.cohorts = std::max(1, std::min(r.cohorts, mix.units()));
   if (r.cohorts > 1 && model) {
     const int units = mix.units();
-    r.plan = plan_hyb_group(n, m, cus, mix.scaled((units + r.cohorts - 1) / r.cohorts), T.target_wgs, hyb_res, false, T.exp_geo, true);
+    r.plan = plan_hyb_group(n, m, cus, mix.scaled((units + r.cohorts - 1) / r.cohorts), T.target_wgs, hyb_res, false, T.exp_geo, true, T.debug >= 2);
     r.plan.units = units;
   }
   return r;
@@ -1179,7 +1201,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   const HybPlan &hyb_plan0 = hyb_cplan0.plan;
   int hyb_ranks = 0;
   for (int q = 0; q < nk; ++q) hyb_ranks += use_hyb_k(ks[q]) ? 1 : 0;
-  if (getenv("NMFK_DEBUG") && hyb_mix.units() > 0)
+  if (T.debug && hyb_mix.units() > 0)
     fprintf(stderr, "[nmfk] plan of %d matrix-pipe units (%d / %d / %d of variant 16 / 8 / 4) at %d x %d: H res %d wsplit %d S %d (model %.1f us, busy %.2f) | W res %d wsplit %d S %d (%.1f us, %.2f) | cohorts %d\n",
             hyb_mix.units(), hyb_mix.n16, hyb_mix.n8, hyb_mix.n4, n, m, hyb_plan0.res[0], hyb_plan0.wsplit[0], hyb_plan0.S[0], hyb_plan0.us[0], hyb_plan0.busy[0],
             hyb_plan0.res[1], hyb_plan0.wsplit[1], hyb_plan0.S[1], hyb_plan0.us[1], hyb_plan0.busy[1], hyb_cplan0.cohorts);
@@ -1311,7 +1333,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
           same = same && p0.res[w] == res_wgs[w] && p0.wsplit[w] == g0[w].wsplit && p0.S[w] == g0[w].S && p0.dchunk[w] == g0[w].dchunk &&
                  p0.fused[w] == g0[w].fused && p0.slots[w] == g0[w].slots;
         if (!same) {  // (an unusual NMFK_TARGET_WGS or shape: a pure optimisation must not fail the sweep -- static schedule)
-          if (getenv("NMFK_DEBUG")) fprintf(stderr, "[nmfk] the tier planner disagrees with the sweep's launch geometry: static schedule\n");
+          if (T.debug) fprintf(stderr, "[nmfk] the tier planner disagrees with the sweep's launch geometry: static schedule\n");
           tiers.clear();
         }
       }
@@ -1871,7 +1893,13 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
   for (int u = 0; u < nunits; ++u) order_hist[0][(size_t)u] = u;
   std::deque<std::vector<int32_t>> perm_keep;             // host sources of the asynchronous uploads
   std::deque<std::array<NmfkStepArgs, 2>> args_keep;
-  if (replanning && ngroups != 1) return fail(NMFK_ERR_HIP, "internal: the retire-aware schedule expects one launch group");
+  // (the tiers were planned for ONE launch group; should the group builder ever disagree, the sweep keeps its first plan -- a pure optimisation must
+  //  not fail a user's execute(): ADVICE r4 / VERDICT r5.  The buffers laid out for the re-plans stay unused.)
+  bool replan_live = replanning;
+  if (replanning && ngroups != 1) {
+    if (T.debug) fprintf(stderr, "[nmfk] the retire-aware schedule expects one launch group, the sweep has %d: static schedule\n", ngroups);
+    replan_live = false;
+  }
   // Deferred check (round 4).  The H half-step of iteration j + 1 forms W*H of exactly the factors whose objective the check
   // after iteration j monitors (Mult:74), so on the matrix-pipe kernels that half-step leaves the objective as a by-product and
   // the launch that recomputed W*H for it (0.39 of the check block's 0.52 ms on the bench sweep) goes away: the check iteration
@@ -2050,7 +2078,7 @@ NMFK_EXPORT int nmfk_mu_sweep(nmfk_ctx *ctx, int nk, const int32_t *ks, int nrun
         bool any = false;
         for (int u = 0; u < nunits; ++u) any = any || (in_phase[u] && snap[slot ^ 1][u].active);
         if (!any) all_done = true;
-        if (replanning && any) {  // units still active as of that check: do they fit a later tier?
+        if (replan_live && any) {  // units still active as of that check: do they fit a later tier?
           for (int u = 0; u < nunits; ++u) act += snap[slot ^ 1][u].active ? 1 : 0;
           while (next_tier + 1 < (int)tiers.size() && act <= tiers[next_tier + 1].count) ++next_tier;
         }

@@ -144,6 +144,11 @@ def secondary_cfg4(NMFk, ctx, iters=100):
                         f"{iters} MU iterations (fixed budget, objective + check block every 10th)",
             "ms_per_iter": ms, "GBps_algorithmic": gbps, "frac_hbm": gbps / PEAK_HBM_GBPS, "bound": "hbm", "peak_GBps": PEAK_HBM_GBPS,
             "algorithmic_bytes_per_iter": bytes_iter,
+            # aggregate HBM traffic (static: PMC passes cannot run inside the bench): 4.50 GB per launch x 8.44 launches per iteration, launches overlapping
+            # 2.5-fold on their streams -- the chip's rate is bytes per iteration / ms per iteration, NOT the per-launch figure
+            "hbm_bytes_per_iter_measured": 4.50e9 * 8.44, "hbm_GBps_measured": 4.50e9 * 8.44 / (ms * 1e-3) / 1e9,
+            "hbm_measured_source": "profiles/r05/traffic_sp_blk.json x profiles/r05/secondary_kernel_stats.csv (844 launches per 100 iterations); kernel unchanged in round 6 "
+                                   "(profiles/r06/sparse_analysis.txt: why, and what it waits for)",
             "kernel": "sp_blk_kernel<NC> (nmfk_step_impl.h; sliced ELL, one lane element per lane, the gathered factor through LDS) "
                       "for both half-steps of every rank <= 32",
             "profile": "profiles/r05/secondary_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/secondary.py)"}
@@ -188,16 +193,28 @@ def secondary_cfg5(NMFk, ctx, iters=40):
     tf = 8.0 * n * m * k * R / (ms * 1e-3) / 1e12
     halves = {nm: {"avg_launch_ms": v["ms"] / v["launches"], "TFLOPs": v["flops"] / (v["ms"] * 1e-3) / 1e12}
               for nm, v in prof.items() if nm.startswith(("h_step", "w_step")) and v["launches"]}
-    # the k = 64 kernel runs W*H as 12 bf16 MFMAs of 16 cycles and the numerators as 16 fp32 MFMAs of 32 per 16 x 16 tile and
-    # 16 loop steps: 704 matrix cycles where the all-fp32 formulation the peak is quoted for needs 1024
+    # Roofs.  Round 6: at 48 / 64 signals BOTH products run on the bf16 matrix pipe from exact three-term splits (six term pairs each: 12 + 12
+    # v_mfma_f32_16x16x32_bf16 of 16 cycles per 16 x 16 tile and 16 loop steps = 384 matrix cycles; rounds 3-5: 12 bf16 + 16 fp32 of 32 = 704; the
+    # all-fp32 formulation the fp32 peak is quoted for: 1024).  The roof of THIS formulation is the dense bf16 peak / 6 term pairs; the fraction of it
+    # is the matrix pipe's busy fraction at the peak clock (cross-checked by SQ_VALU_MFMA_BUSY_CYCLES, profiles/r06/wide_pmc_summary_bn1.txt).  The
+    # algorithmic rate may exceed the fp32-MFMA peak -- that ratio is reported as a ratio, not as a fraction of a roof.
+    bn = os.environ.get("NMFK_WIDE_BN", "1") != "0"
+    cyc_per_tile = 384.0 if bn else 704.0
+    roof = PEAK_FP32_TFLOPS * 1024.0 / cyc_per_tile  # fp32 peak x (1024 all-fp32 matrix cycles / cycles this form issues) = bf16 peak / 6 when bn
     return {"workload": f"dense U(0,1) fp32 X {n}x{m}, k={k}, {R} restarts, {iters} MU iterations (fixed budget, objective + check block every 10th)",
-            "ms_per_iter": ms, "TFLOPs_algorithmic": tf, "frac_fp32_peak": tf / PEAK_FP32_TFLOPS, "bound": "mfma", "peak_TFLOPs": PEAK_FP32_TFLOPS,
-            "matrix_pipe_occupancy": tf / PEAK_FP32_TFLOPS * 704.0 / 1024.0,
-            "matrix_pipe_occupancy_note": "derived: algorithmic rate x (704 matrix cycles the split-operand form issues per tile / 1024 of "
-                                          "the all-fp32 form the peak is quoted for); counters: profiles/r04",
+            "ms_per_iter": ms, "TFLOPs_algorithmic": tf, "bound": "mfma", "peak_TFLOPs": roof,
+            "peak_note": ("dense bf16 MFMA peak (2516.8 = 16 x the fp32 peak) / 6 term pairs of the exact three-term splits both products run in"
+                          if bn else "fp32 peak x 1024 / 704: 12 bf16 + 16 fp32 matrix instructions per tile instead of 32 fp32"),
+            "frac": tf / roof, "matrix_pipe_busy": tf / roof,
+            "matrix_pipe_busy_note": f"= algorithmic rate x {cyc_per_tile:.0f} matrix cycles per tile and chunk / (algorithmic flops per tile and chunk x SIMDs x 2.4 GHz); "
+                                     "counters: profiles/r06/wide_pmc_summary_bn1.txt (SQ_VALU_MFMA_BUSY_CYCLES 1.61e9 per launch of 1 024 SIMDs)",
+            "x_fp32_mfma_peak": tf / PEAK_FP32_TFLOPS,
+            "x_fp32_mfma_peak_note": "ratio to the roof of an all-fp32-MFMA formulation (157.3): above 1 because the products run as bf16 splits at 3/8 of its matrix cycles",
             "half_steps": halves,
-            "kernel": "wide2_step_kernel<4,2,0> (nmfk_step_hyb.hip: W*H from three-term bf16 splits, numerators in fp32 MFMAs; <4,2,2> behind a check iteration: the same half-step leaves the monitored objective)",
-            "profile": "profiles/r05/secondary_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/secondary.py)"}
+            "kernel": ("wide2_step_kernel<4,2,0,true> (nmfk_step_hyb.hip: W*H AND the numerators from exact three-term bf16 splits on v_mfma_f32_16x16x32_bf16, "
+                       "explicit software pipeline; <4,2,2,true> behind a check iteration: the same half-step leaves the monitored objective)") if bn else
+                      "wide2_step_kernel<4,2,0,false> (W*H from three-term bf16 splits, numerators in fp32 MFMAs)",
+            "profile": "profiles/r06/secondary_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/secondary.py)"}
 
 
 def main():

@@ -30,6 +30,12 @@
 #include <algorithm>
 #include <type_traits>
 
+#ifndef NMFK_WIDE_XA
+#define NMFK_WIDE_XA 2  // chunks the X loads of wide2_step_kernel run ahead (2 or 3; 3: k = 64 2.95 -> 2.93 ms per iteration, k = 32 1.77 -> 1.98: registers)
+#endif
+#ifndef NMFK_WIDE_ABL
+#define NMFK_WIDE_ABL 0  // measurement builds only (scripts/r6_wide_ablate.sh): bit 0 no staging writes behind the first block, 1 no X loads in the loop,
+#endif                   // 2 no ratio pieces, 3 no second product, 4 no LDS operand reads in the loop (wrong results, same control flow)
 #ifndef NMFK_HYB_CPB
 #define NMFK_HYB_CPB 4  // chunks of 16 loop steps per staged block of a workgroup (one barrier per block)
 #endif
@@ -1625,7 +1631,18 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
   // A lane then needs block g in the three terms and block 4 + (g & 1) in two (pairs 0, 2, 4 want the lane factor's terms
   // h, h, l -- k-lane groups 0, 1 --, pairs 1, 3, 5 want m, m, h -- groups 2, 3): five operand registers of 128 bits per tile.
   static_assert(NITEM % 512 == 0, "items divide evenly");
-  const int u = u0 + blockIdx.y, bx = blockIdx.x;
+  // Which (lane tile / split, unit) this workgroup serves.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest).  Taken as they
+  // come -- x = tile, y = unit -- the chip works through ONE unit at a time, and at BASELINE configs[4]'s size (X = 537 MB: neither the L2s nor
+  // the 256 MB Infinity Cache hold it) every unit streams all of X from HBM: compiled out, the X loads were a third of the half-step
+  // (profiles/r06/wide_ablation.txt).  Remapped so that, on every XCD, the UNITS of a tile run side by side (unit fastest within the XCD's share of
+  // the tiles): the restarts walk the same tile of X chunk by chunk at the same pace and all but the first find it in that XCD's L2.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if ((gridDim.x & 7) == 0 && gridDim.y > 1) {
+    const int lin = by * gridDim.x + bx, j = lin >> 3;
+    by = j % (int)gridDim.y;
+    bx = (j / (int)gridDim.y) * 8 + (lin & 7);
+  }
+  const int u = u0 + by;
   if (!(gp->force && !OBJ) && !state[u].active) return;
   const NmfkRun *__restrict__ rdp = runs + u;
   const int k = rdp->k, kp = rdp->kp;  // true rank, row stride (padding rows of the factors are zero and stay zero)
@@ -1788,11 +1805,20 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
     for (int i = 0; i < NTAB; ++i) tabv[i] = tid + 512 * i < ntab ? sumB[tid + 512 * i] : 0.0;
   }
   f32x4_t xr[4][NT];
+  // X runs XA chunks ahead of its use in four register sets (a chunk's set is free once its ratios are formed).  Compiled out, the X loads are a
+  // quarter of the half-step at BASELINE configs[4]'s size (2.98 -> 2.23 ms per iteration, profiles/r06/wide_ablation.txt) -- but it is not their
+  // latency: three chunks ahead instead of two changes nothing at 48 / 64 signals and costs the 32-signal form its registers.
+  constexpr int XA = NMFK_WIDE_XA;
   if (nchunks > 0) {
     const int dlast = d0 + 16 * (nchunks - 1);
     stage_load(d0);
     xload(d0, xr[0]);
     xload(min(d0 + 16, dlast), xr[1]);
+    if (XA == 3) xload(min(d0 + 32, dlast), xr[2]);
+    if (NMFK_WIDE_ABL & 2) {
+      xload(d0, xr[2]);
+      xload(d0, xr[3]);
+    }
     stage_write(sb, d0);
     // first product: P[d = 4g + r][l = c16] from the six term pairs
     auto first_product = [&](const char *cur, int chx, f32x4_t (&p)[NT]) __attribute__((always_inline)) {
@@ -1832,6 +1858,7 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
         const int tp = NB == 4 ? (j >> 1) : j, i = NB == 4 ? (j & 1) : 0;
         plane = tA[tp] * NH + 4 * i + g;
       }
+      if (NMFK_WIDE_ABL & 16) return bopt[0][0][0];
       return *(const bf16x8_t *)(cur + chx * CHP + plane * 256 + c16 * 16);
     };
     auto fp_b = [&](int t, int j) __attribute__((always_inline)) -> bf16x8_t {
@@ -1841,6 +1868,7 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
     };
     // second product's operand forms of block nb of chunk chx: plane 0 = (b_l | b_h), plane 1 = (b_h | b_m)
     auto sp_av = [&](const char *cur, int chx, int nb, int plane) __attribute__((always_inline)) -> bf16x8_t {
+      if (NMFK_WIDE_ABL & 16) return bopt[0][1][0];
       return *(const bf16x8_t *)(cur + BFB + chx * CHT + nb * HYB_BN_BLK + plane * 1024 + (g * 16 + c16) * 16);
     };
     const int nblocks = (nchunks + CPB - 1) / CPB;
@@ -1858,7 +1886,7 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
         const int c = blk * CPB + ch;
         if (c >= nchunks) break;
         const int dch = d0 + 16 * c;
-        xload(min(dch + 32, dlast), xr[(ch + 2) & 3]);
+        if (!(BN && (NMFK_WIDE_ABL & 2))) xload(min(dch + 16 * XA, dlast), xr[(ch + XA) & 3]);
         __builtin_amdgcn_sched_barrier(0);
         // PIPE (round 5; NB >= 3, half-step modes): inside a staged block the first product of chunk ch + 1 is issued BEFORE the ratios of
         // chunk ch, whose reciprocals then sit beside bf16 matrix instructions (2-6 cycles each instead of 8 beside the fp32 ones:
@@ -1902,6 +1930,12 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
           }
           float qv[NT][4], r1[NT][4], r2[NT][4];
           uint32_t hw[NT][2], mw[NT][2], lw[NT][2];
+          if (NMFK_WIDE_ABL & 4) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int e = 0; e < 2; ++e) hw[t][e] = mw[t][e] = lw[t][e] = 0x3f803f80u + lane;
+          }
           auto piece = [&](int i) __attribute__((always_inline)) {
             if (i < 4 * NT) {
               const int t = i >> 2, r = i & 3;
@@ -1930,14 +1964,16 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
               for (int t = 0; t < NT; ++t)
                 pnext[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ringF[FPL::load_of(sl) & 3], fp_b(t, FPL::ord(sl)), sl == 0 ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : pnext[t], 0, 0, 0);
 #pragma unroll
-              for (int i = sl * NPIECE / NM; i < (sl + 1) * NPIECE / NM; ++i) piece(i);
+              for (int i = sl * NPIECE / NM; i < (sl + 1) * NPIECE / NM; ++i)
+                if (!(NMFK_WIDE_ABL & 4) || blk == 0) piece(i);
               __builtin_amdgcn_sched_barrier(0);
             }
           } else {  // the block's last chunk: nothing to put the ratios beside
             ahm[0] = sp_av(cur, ch, 0, 1);
             alh[0] = sp_av(cur, ch, 0, 0);
 #pragma unroll
-            for (int i = 0; i < NPIECE; ++i) piece(i);
+            for (int i = 0; i < NPIECE; ++i)
+              if (!(NMFK_WIDE_ABL & 4) || blk == 0) piece(i);
             __builtin_amdgcn_sched_barrier(0);
           }
           HybQ qs[NT];
@@ -1953,18 +1989,21 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
             // the NEXT block's rows (requested at this block's start) are converted and written to the other LDS buffer HERE, beside the second
             // product of the block's third chunk -- a phase with no vector work of its own -- instead of behind the block with the matrix pipe idle
             static_assert(NI <= NB, "one staging item per block of 16 signals");
-            if (more && ch == CPB - 2 && nb < NI) stage_write_item(nxt, d0 + 64 * (blk + 1), nb);
+            if (more && ch == CPB - 2 && nb < NI && !(NMFK_WIDE_ABL & 1)) stage_write_item(nxt, d0 + 64 * (blk + 1), nb);
             if (!lastb) ahm[(nb + 1) & 1] = sp_av(cur, ch, nb + 1, 1);
             else if (next2) ringF[0] = fp_av(cur, ch + 2, FPL::ord(0));
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm[nb & 1], qs[t].hh, acc[t][nb], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+              if (!(NMFK_WIDE_ABL & 8)) acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm[nb & 1], qs[t].hh, acc[t][nb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (!lastb) alh[(nb + 1) & 1] = sp_av(cur, ch, nb + 1, 0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm[nb & 1], qs[t].mm, acc[t][nb], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+              if (!(NMFK_WIDE_ABL & 8)) acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm[nb & 1], qs[t].mm, acc[t][nb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alh[nb & 1], qs[t].hl, acc[t][nb], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+              if (!(NMFK_WIDE_ABL & 8)) acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alh[nb & 1], qs[t].hl, acc[t][nb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
           continue;

@@ -30,6 +30,9 @@
 #include <algorithm>
 #include <type_traits>
 
+#ifndef NMFK_HYB_ABL
+#define NMFK_HYB_ABL 0  // measurement builds only: resident half-step with bit 0 no X loads in the chunk loop, bit 1 no LDS operand reads in it (wrong results)
+#endif
 #ifndef NMFK_WIDE_XA
 #define NMFK_WIDE_XA 2  // chunks the X loads of wide2_step_kernel run ahead (2 or 3; 3: k = 64 2.95 -> 2.93 ms per iteration, k = 32 1.77 -> 1.98: registers)
 #endif
@@ -1208,6 +1211,10 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
     xoffs(tp, xo);
     xload(xo, 0, xr[0]);
     xload(xo, 1, xr[1]);
+    if (NMFK_HYB_ABL & 1) {
+      xload(xo, 2, xr[2]);
+      xload(xo, 3, xr[3]);
+    }
 #pragma unroll
     for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(sb + fofs[j]);
   }
@@ -1350,14 +1357,16 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
         constexpr bool dummy = false;
         (void)dummy;
         const bool last = TAIL && ci == 3;  // (compile-time after unrolling) the tile pair's last chunk: nothing behind it
-        if (TAIL && ci >= 2)
-          xload(xn, ci - 2, xr[(ci + 2) & 3]);
-        else
-          xload(xo, c + 2, xr[(ci + 2) & 3]);
+        if (!(NMFK_HYB_ABL & 1)) {
+          if (TAIL && ci >= 2)
+            xload(xn, ci - 2, xr[(ci + 2) & 3]);
+          else
+            xload(xo, c + 2, xr[(ci + 2) & 3]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         f32x4_t bn[NSA];
 #pragma unroll
-        for (int sn = 0; sn < NSA; ++sn) bn[sn] = *(const f32x4_t *)(sb + nofs + sn * 64 + c * ST::CHT);
+        for (int sn = 0; sn < NSA; ++sn) bn[sn] = (NMFK_HYB_ABL & 2) ? pc[0] : *(const f32x4_t *)(sb + nofs + sn * 64 + c * ST::CHT);
         f32x4_t pn[NT];
         if (!last) {
 #pragma unroll
@@ -1409,7 +1418,7 @@ __device__ __forceinline__ void hyb_res_body(char *arena, const float *__restric
 #undef HYB_MFMA_THEN_RCP
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!last) {  // operands of the chunk after next (the last-but-one chunk fetches chunk 0 again: the next tile pair's)
+        if (!last && !(NMFK_HYB_ABL & 2)) {  // operands of the chunk after next (the last-but-one chunk fetches chunk 0 again: the next tile pair's)
           const char *nx = sb + ((TAIL && ci == 2) ? 0 : (c + 2) * ST::CHP);
 #pragma unroll
           for (int j = 0; j < NM; ++j) avn[j] = *(const u32x4_t *)(nx + fofs[j]);

@@ -527,6 +527,8 @@ NMFK_EXPORT int nmfk_mu_sweep_sharded(nmfk_ctx *ctx, nmfk_comm *c, int nk, const
     CommTimer tg(ctx, "comm_allgather", (double)tot * N);  // (bytes received; enqueue to completion on this rank's stream)
     rc = coll_allgather(c, S, c->recv.p, tot, "ncclAllGather(results)");
     if (rc != NMFK_OK) return rc;
+    // (profiling only: the wait for the collective is booked under comm_allgather instead of under the first copy of comm_deliver, which sits
+    //  behind it on the same stream and would wait for it anyway -- the call's total does not change, only where the wait is accounted)
     if (ctx->profiling) HIPCHECK(hipStreamSynchronize(st));
   }
   CommTimer td(ctx, "comm_deliver");  // strided copies into the caller's arrays

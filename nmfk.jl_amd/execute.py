@@ -504,9 +504,18 @@ def execute(X, nkrange, nNMF=10, opts=None, *, cutoff=0.5, clusterWmatrix=False,
         if load or save:  # Exec:256-262 (the reference hashes X once per k; here once per call, when the cache is in use)
             xs = "_".join(str(v) for v in X.shape)
             xfile = os.path.join(resultdir, f"{casefilename or 'nmfk'}_x_matrix_{xs}{resultio.EXT}")
-            if save and not single and not _is_sparse(X):  # Exec:185-192: the range form keeps the matrix next to its results, key "X"
+            if save and not single:  # Exec:185-192: the range form keeps the matrix next to its results, key "X"
                 os.makedirs(resultdir, exist_ok=True)
-                resultio.save(xfile, X=np.asfortranarray(X))
+                if _is_sparse(X):
+                    # Deviation (stated in DESIGN.md section 8): the reference writes `X` itself, i.e. for a sparse input a Julia SparseMatrixCSC
+                    # (a JLD compound type this writer does not produce).  The same information goes into the same file as the CSC's own fields
+                    # under Julia's field names, 1-based like Julia stores them: SparseMatrixCSC(X_m, X_n, X_colptr, X_rowval, X_nzval)
+                    Xc = X.tocsc()
+                    Xc.sort_indices()
+                    resultio.save(xfile, X_m=np.int64(Xc.shape[0]), X_n=np.int64(Xc.shape[1]), X_colptr=Xc.indptr.astype(np.int64) + 1,
+                                  X_rowval=Xc.indices.astype(np.int64) + 1, X_nzval=np.asarray(Xc.data))
+                else:
+                    resultio.save(xfile, X=np.asfortranarray(X))
             check_x_hash(X, xfile, quiet=quiet)
         for nk in ks:  # Exec:264-303: per-k result cache
             fn = _result_filename(resultdir, casefilename, n, m, nk, nNMF)

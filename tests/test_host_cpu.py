@@ -497,6 +497,22 @@ def test_retire_aware_tiers_are_consistent_launch_geometries(monkeypatch):
         t = byu[units]
         assert t["H"]["wsplit"] == 1 and t["H"]["S"] in S_ok and t["W"]["res"] in res_ok, t
     assert byu[120]["cohorts"] == 2 and byu[60]["cohorts"] == 2 and byu[30]["cohorts"] == 2 and byu[1]["cohorts"] == 1
+    # structural invariants at the bench shape (beside the pinned values): as the units halve a unit never gets FEWER workgroups, and a
+    # launch of eight units or more is not starved -- at least a quarter of the CUs' worth of workgroups per cohort
+
+    def wgs_per_unit(t, half, L):
+        g = t[half]
+        return g["res"] if g["res"] else ((L + (32 if g["wsplit"] > 1 else 256) - 1) // (32 if g["wsplit"] > 1 else 256)) * g["S"]
+
+    for variant in (0, 4, 16):
+        prev = {"H": 0, "W": 0}
+        for t in _lib.plan_hyb_tiers(8192, 512, variant, 480):
+            for half, L in (("H", 512), ("W", 8192)):
+                w = wgs_per_unit(t, half, L)
+                assert w >= prev[half], (variant, t["units"], half, w, prev[half])
+                prev[half] = w
+                if t["units"] >= 8:  # (below that the resident form's 16 workgroups per unit are all there is)
+                    assert w * t["units"] / t["cohorts"] >= 64, (variant, t["units"], half, w)
     # the resident form's workgroups per unit double from their minimum (lane tile t of every unit stays on XCD t mod 8)
     for t in _lib.plan_hyb_tiers(65536, 256, 4, 40):
         assert t["W"]["res"] == 0 or (t["W"]["res"] & (t["W"]["res"] - 1)) == 0, t

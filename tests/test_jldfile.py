@@ -189,3 +189,20 @@ def test_x_matrix_file_roundtrip(tmp_path):
     assert list(z) == ["X"] and z["X"].dtype == np.float32 and z["X"].shape == (7, 5)
     np.testing.assert_array_equal(z["X"], X)
     assert not [f for f in os.listdir(tmp_path) if ".tmp" in f]  # (written to a temporary name, then renamed)
+
+
+def test_x_matrix_file_of_a_sparse_input(tmp_path):
+    """Round 6: execute(X, nkrange; save=true) keeps the analysed matrix next to its results also when X is sparse (Exec:185-192 saves
+    `X` whatever it is).  A Julia SparseMatrixCSC is a JLD compound type this writer does not produce; the file holds the CSC's own fields under
+    Julia's field names, 1-based like Julia stores them (stated deviation: DESIGN.md section 8)."""
+    import scipy.sparse as sp
+    from nmfk_jl_amd import resultio
+
+    X = sp.random(9, 6, 0.4, format="csc", dtype=np.float32, random_state=2)
+    fn = str(tmp_path / "nmfk_x_matrix_9_6.jld")
+    resultio.save(fn, X_m=np.int64(9), X_n=np.int64(6), X_colptr=X.indptr.astype(np.int64) + 1, X_rowval=X.indices.astype(np.int64) + 1,
+                  X_nzval=np.asarray(X.data))
+    z = resultio.load(fn)
+    assert sorted(z) == ["X_colptr", "X_m", "X_n", "X_nzval", "X_rowval"] and int(z["X_colptr"][0]) == 1 and int(z["X_colptr"][-1]) == X.nnz + 1
+    Y = sp.csc_matrix((z["X_nzval"], np.asarray(z["X_rowval"]) - 1, np.asarray(z["X_colptr"]) - 1), shape=(int(z["X_m"]), int(z["X_n"])))
+    assert abs(Y - X).sum() == 0

@@ -151,8 +151,10 @@ def test_feature_extraction_notebook_known_answers(oracle):
         # test_feature_extraction_notebook_objective_distributions: the notebook's older NMFk left its restarts closer to the exact fit
         assert 0.95 < rob[3] < sil_ref[2]
         assert all(-0.9 < rob[k - 1] < -0.3 for k in range(5, 11)) and all(-0.9 < v < -0.3 for v in sil_ref[3:])
-        # the notebook's criterion: the ranks above the cutoff are exactly 2, 3, 4, and their ORDER by robustness is the notebook's
+        # the notebook's criterion: the ranks above the cutoff are exactly 2, 3, 4, and k = 2 leads both orderings.  (The notebook's full ORDER by
+        # robustness is 2 > 4 > 3; the oracle's is 2 > 3 > 4 because of the k = 4 offset discussed above -- the order of k = 3 and 4 is NOT asserted.)
         assert [k for k in ks if rob[k - 1] > 0.5] == [2, 3, 4] == [k for k, v in zip(ks, sil_ref) if v > 0.5]
+        assert int(np.argmax(rob[1:])) + 2 == 2 == ks[int(np.argmax(sil_ref))]
         assert abs(float(fit[1]) ** 2 - fit_ref[0]) < 1e-3 * fit_ref[0] and abs(float(fit[2]) ** 2 - fit_ref[1]) < 2e-3 * fit_ref[1]
         of2 = np.sort(det[2]["objvalue"].astype(np.float64) ** 2)
         assert of2[0] > 0.999 * z["of_min_max_k2"][0] and of2[-1] < 1.01 * z["of_min_max_k2"][1]  # 'OF: min ... max ...', :206

@@ -29,7 +29,7 @@ PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 
 
-TRAFFIC_FILES = ("profiles/r05/traffic.json", "profiles/r05/traffic_h_step.json", "profiles/r04/traffic.json", "profiles/r03/traffic.json", "profiles/r02/traffic.json")
+TRAFFIC_FILES = ("profiles/r06/traffic.json", "profiles/r06/traffic_h_step.json", "profiles/r05/traffic.json", "profiles/r05/traffic_h_step.json", "profiles/r04/traffic.json", "profiles/r03/traffic.json", "profiles/r02/traffic.json")
 
 
 def _pmc_traffic(kernel):

@@ -327,7 +327,9 @@ int nmfk_get_profile(nmfk_ctx *ctx, int max_entries, char (*names)[64], double *
  *                     reduce_kernel's bits; rowsum(H) is added in another order, so the results differ from the default path by rounding.
  *                     Every workgroup of a unit repeats the sum: measured 2.5 % slower on a 60-unit share (profiles/r05/dense_probes.txt)
  *   NMFK_HYB_LAG      0 / 1: the matrix-pipe streaming half-step never / always runs its second lane tile one chunk late (default: where a wave
- *                     walks 32 chunks or more; same bits either way)
+ *                     walks 32 chunks or more; same bits either way).  Exception: the half-step that also leaves the deferred check's objective
+ *                     (1 launch in 10) always runs the lagged form -- its monitored objective is compared with the plain check order
+ *                     (NMFK_DEFER_OBJ=0) by tests/test_gpu_parity.py::test_deferred_check_against_the_plain_order
  *   NMFK_WIDE_BN      ranks 17..64 (wide2_step_kernel): 0 = numerators on the fp32 matrix pipe (rounds 3-5), 1 (default) = on the bf16 pipe from exact
  *                     three-term splits of the ratios where the padded width is 48 or 64 signals, 2 = at 32 signals too (slower there)
  *   NMFK_SP_BLK       0: sparse X in the gather form only (no sliced-ELL copies are built); 2: blocked form whatever the size

@@ -72,7 +72,7 @@ def _assert_same_ordering(rob, ref, exact, what):
     """SURVEY 8d's parity clause for the default stop rule: identical kopt AND identical ordering of robustness[k] (Exec:225,
     Post:7-41).  exact: the whole argsort; else (fp32 compute against a Float64 reference: the stop decisions are not identical,
     the silhouettes of the ranks far below the cutoff move by a few 1e-2) the ORDER of the ranks above the cutoff and a rank
-    correlation >= 0.9 over all ranks.  Measured (round 5): Spearman = 1.0000 -- the IDENTICAL ordering -- for the fp32 product against
+    correlation >= 0.97 over all ranks.  Measured (round 5): Spearman = 1.0000 -- the IDENTICAL ordering -- for the fp32 product against
     the oracle fixture in all three launch geometries and against the fp64 compute mode on the planted rank-6 matrix at 8192 x 512."""
     rob, ref = np.asarray(rob, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     if exact:
@@ -81,7 +81,7 @@ def _assert_same_ordering(rob, ref, exact, what):
     top = [int(i) for i in np.argsort(-ref, kind="stable") if ref[i] > 0.5]
     assert [int(i) for i in np.argsort(-rob, kind="stable") if rob[i] > 0.5] == top, (what, rob, ref)
     rho = _spearman(rob, ref)
-    assert rho >= 0.9, (what, rho, rob, ref)
+    assert rho >= 0.97, (what, rho, rob, ref)  # (measured 1.0000 everywhere: round 6 tightened the bound from 0.9 to the measured value minus a margin)
     return rho
 
 
@@ -353,7 +353,8 @@ def test_default_stop_rule_against_the_oracle_fixture(NMFk, ctx, oracle, geometr
     it32 = np.stack([det[k]["iters"] for k in ks])
     diff = np.abs(it32 - fx["iters"])
     assert (diff <= np.maximum(50, fx["iters"] // 20)).mean() >= 0.97, (diff.max(), worst)
-    assert (diff <= 10).mean() >= 0.93 and (diff == 0).mean() >= 0.85, ((diff <= 10).mean(), (diff == 0).mean())
+    # (round 6: bounds tightened to the measured 98-99 % / 91-92 % minus a margin of three points; they were 93 % / 85 %)
+    assert (diff <= 10).mean() >= 0.95 and (diff == 0).mean() >= 0.88, ((diff <= 10).mean(), (diff == 0).mean())
     # fp64 compute (the reference's arithmetic, packed-VALU fp64 kernels)
     W, H, fit64, rob64, aic64, kopt64, det64 = NMFk.execute(X, ks, R, load=False, save=False, quiet=True, seed=seed, ctx=ctx,
                                                              compute="f64", return_details=True)

@@ -38,7 +38,7 @@
 #endif
 #ifndef NMFK_WIDE_ABL
 #define NMFK_WIDE_ABL 0  // measurement builds only (scripts/r6_wide_ablate.sh): bit 0 no staging writes behind the first block, 1 no X loads in the loop,
-#endif                   // 2 no ratio pieces, 3 no second product, 4 no LDS operand reads in the loop (wrong results, same control flow)
+#endif                   // 2 no ratio pieces, 3 no second product, 4 no LDS operand reads in the loop, 5 X loads from the tile's first four chunks only (wrong results, same control flow)
 #ifndef NMFK_HYB_CPB
 #define NMFK_HYB_CPB 4  // chunks of 16 loop steps per staged block of a workgroup (one barrier per block)
 #endif
@@ -1642,9 +1642,9 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
   static_assert(NITEM % 512 == 0, "items divide evenly");
   // Which (lane tile / split, unit) this workgroup serves.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest).  Taken as they
   // come -- x = tile, y = unit -- the chip works through ONE unit at a time, and at BASELINE configs[4]'s size (X = 537 MB: neither the L2s nor
-  // the 256 MB Infinity Cache hold it) every unit streams all of X from HBM: compiled out, the X loads were a third of the half-step
-  // (profiles/r06/wide_ablation.txt).  Remapped so that, on every XCD, the UNITS of a tile run side by side (unit fastest within the XCD's share of
-  // the tiles): the restarts walk the same tile of X chunk by chunk at the same pace and all but the first find it in that XCD's L2.
+  // the 256 MB Infinity Cache hold it) every unit streams all of X from HBM (TCC hit 50 %).  Remapped so that, on every XCD, the UNITS of a tile run
+  // side by side (unit fastest within the XCD's share of the tiles): the restarts walk the same tile of X chunk by chunk at the same pace and all but
+  // the first find it in that XCD's L2 (k = 64: 3.10 -> 2.95 ms per iteration; the fp32-numerator form 3.65 -> 3.48).
   int bx = blockIdx.x, by = blockIdx.y;
   if ((gridDim.x & 7) == 0 && gridDim.y > 1) {
     const int lin = by * gridDim.x + bx, j = lin >> 3;
@@ -1814,9 +1814,9 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
     for (int i = 0; i < NTAB; ++i) tabv[i] = tid + 512 * i < ntab ? sumB[tid + 512 * i] : 0.0;
   }
   f32x4_t xr[4][NT];
-  // X runs XA chunks ahead of its use in four register sets (a chunk's set is free once its ratios are formed).  Compiled out, the X loads are a
-  // quarter of the half-step at BASELINE configs[4]'s size (2.98 -> 2.23 ms per iteration, profiles/r06/wide_ablation.txt) -- but it is not their
-  // latency: three chunks ahead instead of two changes nothing at 48 / 64 signals and costs the 32-signal form its registers.
+  // X runs XA chunks ahead of its use in four register sets (a chunk's set is free once its ratios are formed).  Compiled out, the X loads are
+  // 4-5 % of the half-step at BASELINE configs[4]'s size, 1 % of it the misses (profiles/r06/wide_ablation.txt); three chunks ahead instead of two
+  // changes nothing at 48 / 64 signals and costs the 32-signal form its registers.
   constexpr int XA = NMFK_WIDE_XA;
   if (nchunks > 0) {
     const int dlast = d0 + 16 * (nchunks - 1);
@@ -1895,7 +1895,10 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
         const int c = blk * CPB + ch;
         if (c >= nchunks) break;
         const int dch = d0 + 16 * c;
-        if (!(BN && (NMFK_WIDE_ABL & 2))) xload(min(dch + 16 * XA, dlast), xr[(ch + XA) & 3]);
+        if (BN && (NMFK_WIDE_ABL & 32))  // (X loads issued as always, but from the same four chunks of the tile over and over: cache hits)
+          xload(d0 + 16 * ((ch + XA) & 3), xr[(ch + XA) & 3]);
+        else if (!(BN && (NMFK_WIDE_ABL & 2)))
+          xload(min(dch + 16 * XA, dlast), xr[(ch + XA) & 3]);
         __builtin_amdgcn_sched_barrier(0);
         // PIPE (round 5; NB >= 3, half-step modes): inside a staged block the first product of chunk ch + 1 is issued BEFORE the ratios of
         // chunk ch, whose reciprocals then sit beside bf16 matrix instructions (2-6 cycles each instead of 8 beside the fp32 ones:

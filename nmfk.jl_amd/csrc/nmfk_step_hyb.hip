@@ -1754,18 +1754,33 @@ __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const f
   const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void *)B, 0, -1, 0x00020000);
   char *sb = (char *)(lds + 9 * NMFK_MAX_K);
   float sv[NI][2];
+  // Item i of a thread -> (row r of the block, signal pair cp).  Round 6: the 32 lanes of a half wave take 8 rows x 4 adjacent pairs of one plane
+  // (J = the (row group, plane) the half wave serves), so that their ds_write_b32 of a split plane land on 128 contiguous bytes = 32 different banks;
+  // with the lanes along a row (rounds 3-5: q = tid + 512 i, r = q / PPR) eight planes of 256 B met on four banks (8-way conflicts; half of the
+  // LDS's busy cycles were bank conflicts, profiles/r06/wide_pmc_summary_bn1.txt).  The memory side reads 32-byte pieces of eight rows instead of whole
+  // rows: the factor's rows are L2-resident and a block is NI load instructions per thread.
+  auto stage_item = [&](int i, int &r, int &cp) __attribute__((always_inline)) {
+    const int J = ((tid >> 6) * NI + i) * 2 + ((tid >> 5) & 1);  // 0 .. 2 PPR - 1
+    const int rh = J / (PPR / 4), cph = J - rh * (PPR / 4);
+    r = 8 * rh + ((tid >> 2) & 7);
+    cp = 4 * cph + (tid & 3);
+  };
+  static_assert(NI * 8 == PPR, "eight waves x NI items x two half waves = 2 PPR (row group, plane) pairs");
   auto stage_load = [&](int row0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int q = tid + 512 * i, r = q / PPR, cp = q - r * PPR;
+      int r, cp;
+      stage_item(i, r, cp);
       const uint32_t vo = (uint32_t)((r * kp + min(2 * cp, max(kp - 2, 0))) * 4);
-      sv[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsb, vo, row0 * kp * 4, 0));
-      sv[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsb, vo + 4, row0 * kp * 4, 0));
+      const f32x2_t v = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rsb, vo, row0 * kp * 4, 0));
+      sv[i][0] = v.x;
+      sv[i][1] = v.y;
     }
   };
   auto stage_write_item = [&](char *dst, int row0, int i) __attribute__((always_inline)) {
     {
-      const int q = tid + 512 * i, r = q / PPR, cp = q - r * PPR;
+      int r, cp;
+      stage_item(i, r, cp);
       const bool ok = row0 + r < D;  // (rows past the factor's end and padding signals are staged as zeros)
       const float v0 = (ok && 2 * cp < kp) ? sv[i][0] : 0.0f, v1 = (ok && 2 * cp + 1 < kp) ? sv[i][1] : 0.0f;
       uint32_t h, m, lo;

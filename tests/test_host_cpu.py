@@ -627,3 +627,32 @@ def test_zero_line_warnings_follow_julias_minimum():
         E._zero_line_warnings(X)
     assert not rec  # only once per session
     E._first_warning = True
+
+
+def test_truncation_split_of_the_ratios_is_exact():
+    """Round 6, the numerics claim behind wide2_step_kernel's bf16 numerators (csrc/nmfk_step_hyb.hip, hyb_split_q): a Float32 ratio q splits by
+    TRUNCATION into three bf16 terms q = h + m + l EXACTLY (8 + 8 + 8 significand bits) with h = q & 0xffff0000, m = (q - h) & 0xffff0000,
+    l = (q - h) - m -- every residual is exact in Float32 and l itself is bf16-representable.  Restated in numpy bit operations over random values of
+    every magnitude a ratio X ./ (W*H) takes (the kernel's own instructions are checked on the GPU by tools/probe/coissue3.hip: 0 of 2^20 values differ).
+    The six products kept (b_h q_h, b_m q_h, b_l q_h, b_h q_m, b_m q_m, b_h q_l) leave out terms below 2^-24 |b||q|."""
+    rng = np.random.default_rng(5)
+    n = 1 << 18
+    bits = rng.integers(0, 1 << 23, n, dtype=np.uint32) | (rng.integers(90, 160, n, dtype=np.uint32) << 23)  # 2^-37 .. 2^32, any mantissa
+    q = bits.view(np.float32)
+    mask = np.uint32(0xFFFF0000)
+    h = (q.view(np.uint32) & mask).view(np.float32)
+    r1 = q - h
+    m = (r1.view(np.uint32) & mask).view(np.float32)
+    r2 = r1 - m
+    assert np.all(h.astype(np.float64) + m.astype(np.float64) + r2.astype(np.float64) == q.astype(np.float64))  # exact three-term sum
+    assert np.all((r2.view(np.uint32) & np.uint32(0x0000FFFF)) == 0)  # the third term needs no rounding to become bf16
+    assert np.all(np.abs(r1) <= np.abs(q) * 2.0 ** -7) and np.all(np.abs(r2) <= np.abs(q) * 2.0 ** -15)
+    # the dropped products (m*l', l*m', l*l' for a factor value b = h' + m' + l' split the same way) are below 2^-22 of |b||q| each, i.e. at fp32 rounding
+    b = rng.random(n).astype(np.float32) + np.float32(0.01)
+    bh = (b.view(np.uint32) & mask).view(np.float32)
+    bm = ((b - bh).view(np.uint32) & mask).view(np.float32)
+    bl = (b - bh) - bm
+    kept = (bh.astype(np.float64) * h + bm.astype(np.float64) * h + bl.astype(np.float64) * h + bh.astype(np.float64) * m + bm.astype(np.float64) * m
+            + bh.astype(np.float64) * r2)
+    exact = b.astype(np.float64) * q.astype(np.float64)
+    assert np.max(np.abs(kept - exact) / exact) <= 2.0 ** -21

@@ -196,7 +196,7 @@ def secondary_cfg5(NMFk, ctx, iters=40):
     # Roofs.  Round 6: at 48 / 64 signals BOTH products run on the bf16 matrix pipe from exact three-term splits (six term pairs each: 12 + 12
     # v_mfma_f32_16x16x32_bf16 of 16 cycles per 16 x 16 tile and 16 loop steps = 384 matrix cycles; rounds 3-5: 12 bf16 + 16 fp32 of 32 = 704; the
     # all-fp32 formulation the fp32 peak is quoted for: 1024).  The roof of THIS formulation is the dense bf16 peak / 6 term pairs; the fraction of it
-    # is the matrix pipe's busy fraction at the peak clock (cross-checked by SQ_VALU_MFMA_BUSY_CYCLES, profiles/r06/wide_pmc_summary_bn1.txt).  The
+    # is the matrix pipe's busy fraction at the peak clock (cross-checked by SQ_VALU_MFMA_BUSY_CYCLES, profiles/r06/wide_pmc_summary_bn1_final.txt).  The
     # algorithmic rate may exceed the fp32-MFMA peak -- that ratio is reported as a ratio, not as a fraction of a roof.
     bn = os.environ.get("NMFK_WIDE_BN", "1") != "0"
     cyc_per_tile = 384.0 if bn else 704.0
@@ -207,7 +207,7 @@ def secondary_cfg5(NMFk, ctx, iters=40):
                           if bn else "fp32 peak x 1024 / 704: 12 bf16 + 16 fp32 matrix instructions per tile instead of 32 fp32"),
             "frac": tf / roof, "matrix_pipe_busy": tf / roof,
             "matrix_pipe_busy_note": f"= algorithmic rate x {cyc_per_tile:.0f} matrix cycles per tile and chunk / (algorithmic flops per tile and chunk x SIMDs x 2.4 GHz); "
-                                     "counters: profiles/r06/wide_pmc_summary_bn1.txt (SQ_VALU_MFMA_BUSY_CYCLES 1.61e9 per launch of 1 024 SIMDs)",
+                                     "counters: profiles/r06/wide_pmc_summary_bn1_final.txt (SQ_VALU_MFMA_BUSY_CYCLES 1.61e9 per launch of 1 024 SIMDs, 3.03e6 cycles per launch)",
             "x_fp32_mfma_peak": tf / PEAK_FP32_TFLOPS,
             "x_fp32_mfma_peak_note": "ratio to the roof of an all-fp32-MFMA formulation (157.3): above 1 because the products run as bf16 splits at 3/8 of its matrix cycles",
             "half_steps": halves,

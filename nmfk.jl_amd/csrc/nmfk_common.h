@@ -161,9 +161,11 @@ struct NmfkSparseArgs {
 #define NMFK_SPB_MINK 0
 #endif
 __host__ __device__ static inline int nmfk_sp_blk_rank(int kp) { return kp > NMFK_SPB_MINK && kp <= 32; }
-// words between the staged rows of 4 * nc signals: + 4 so that 64 lanes reading 16 bytes of 64 different rows spread over
-// the banks, never a multiple of 32
-static inline int nmfk_spb_stride(int nc) { return (4 * nc + 4) % 32 == 0 ? 4 * nc + 8 : 4 * nc + 4; }
+// words between the staged rows of 4 * nc signals.  A ds_read_b128 is served 16 lanes at a time, each lane on a window of four banks: window =
+// (row * stride / 4 + chunk) mod 16.  Round 6: the stride / 4 is ODD for every nc (nc + 1 for even nc, nc + 2 for odd), so that the rows map onto all 16
+// windows; rounds 3-5 used nc + 1 throughout -- at 12 signals (stride 16 words = 64 B) the rows of a read fell on FOUR windows (a 4-way conflict on every
+// gather of the ranks 9..12), at 4 and 20 signals on eight.  (nc = 1 keeps 8 words: 12 would cost it two of its five granules per stage.)
+static inline int nmfk_spb_stride(int nc) { return nc == 1 ? 8 : (nc & 1) ? 4 * nc + 8 : 4 * nc + 4; }
 // granules of the gathered factor staged at a time
 static inline int nmfk_spb_gps(int nc) { return NMFK_SPB_LDS / (nmfk_spb_stride(nc) * 4) / NMFK_SPB_ROWS; }
 // lanes per lane element of the sparse kernels (four signals each) and lane elements per sum-table slot

@@ -1275,7 +1275,7 @@ template <int NC, bool OBJ, bool SSE = false>
 __device__ __forceinline__ void sp_blk_body(const NmfkSparseArgs &g, const NmfkRun &rd, const int tile, char *lds,
                                             const T *__restrict__ Hobj, double weight) {
   constexpr int KQ = 4 * NC;                   // signals a lane holds (kp rounded up to 4)
-  constexpr int STR = (KQ + 4) % 32 == 0 ? KQ + 8 : KQ + 4;  // = nmfk_spb_stride(NC)
+  constexpr int STR = NC == 1 ? 8 : (NC & 1) ? KQ + 8 : KQ + 4;  // = nmfk_spb_stride(NC): an odd number of 16-byte windows between rows
   constexpr int GPS = NMFK_SPB_LDS / (STR * 4) / NMFK_SPB_ROWS;  // = nmfk_spb_gps(NC)
   constexpr int P = NC > 4 ? 2 : 4;            // slot rows loaded ahead (four at 20..28 signals: no change, profiles/r03)
   constexpr int RSTEP = 1024 / KQ;             // rows staged per sweep of the workgroup (padded rows)

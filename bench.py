@@ -147,8 +147,8 @@ def secondary_cfg4(NMFk, ctx, iters=100):
             # aggregate HBM traffic (static: PMC passes cannot run inside the bench): 4.50 GB per launch x 8.44 launches per iteration, launches overlapping
             # 2.5-fold on their streams -- the chip's rate is bytes per iteration / ms per iteration, NOT the per-launch figure
             "hbm_bytes_per_iter_measured": 4.50e9 * 8.44, "hbm_GBps_measured": 4.50e9 * 8.44 / (ms * 1e-3) / 1e9,
-            "hbm_measured_source": "profiles/r05/traffic_sp_blk.json x profiles/r05/secondary_kernel_stats.csv (844 launches per 100 iterations); kernel unchanged in round 6 "
-                                   "(profiles/r06/sparse_analysis.txt: why, and what it waits for)",
+            "hbm_measured_source": "profiles/r06/traffic_sp_blk.json x profiles/r06/secondary_kernel_stats.csv (844 launches per 100 iterations); round 6 changed the "
+                                   "kernel's LDS side only (bank conflicts: profiles/r06/sparse_analysis.txt), not its global traffic",
             "kernel": "sp_blk_kernel<NC> (nmfk_step_impl.h; sliced ELL, one lane element per lane, the gathered factor through LDS) "
                       "for both half-steps of every rank <= 32",
             "profile": "profiles/r05/secondary_kernel_stats.csv (rocprofv3 --kernel-trace --stats of scripts/secondary.py)"}

@@ -129,28 +129,6 @@ __device__ __forceinline__ float hyb_trunc_rest(float v) {  // v - (v truncated 
 struct HybQ {  // B operands of a lane tile's four ratios (steps 4g .. 4g + 3 of the chunk; low half of a word = the even step's term)
   bf16x8_t hh, mm, hl;
 };
-__device__ __forceinline__ HybQ hyb_split_q(const f32x4_t q) {
-  float r1[4], r2[4];
-  const uint32_t h01 = hyb_pack_hi(q[0], q[1]), h23 = hyb_pack_hi(q[2], q[3]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r1[i] = hyb_trunc_rest(q[i]);
-  const uint32_t m01 = hyb_pack_hi(r1[0], r1[1]), m23 = hyb_pack_hi(r1[2], r1[3]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r2[i] = hyb_trunc_rest(r1[i]);
-  const uint32_t l01 = hyb_pack_hi(r2[0], r2[1]), l23 = hyb_pack_hi(r2[2], r2[3]);
-  HybQ o;
-  o.hh = __builtin_bit_cast(bf16x8_t, (u32x4_t){h01, h23, h01, h23});
-  o.mm = __builtin_bit_cast(bf16x8_t, (u32x4_t){m01, m23, m01, m23});
-  o.hl = __builtin_bit_cast(bf16x8_t, (u32x4_t){h01, h23, l01, l23});
-  return o;
-}
-// second product of a lane tile and block of 16 signals; alh / ahm: the loop factor's operand forms of signal c16, steps [4g, 4g + 4)
-__device__ __forceinline__ f32x4_t hyb_bnum_mfma(const bf16x8_t alh, const bf16x8_t ahm, const HybQ &q, f32x4_t acc) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm, q.hh, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm, q.mm, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alh, q.hl, acc, 0, 0, 0);
-  return acc;
-}
 // bytes of a block of 16 signals x 16 loop steps in the two operand forms: plane (b_l | b_h), plane (b_h | b_m), each [k-lane group g][signal]
 // 16 bytes (+ 16: the blocks' rows start on different banks for the staging writes)
 constexpr int HYB_BN_BLK = 2048 + 16;
@@ -1619,7 +1597,7 @@ struct WideFpOrder {
     return l;
   }
 };
-// BN (round 6): the numerators on the bf16 pipe (see hyb_split_q): the second product's operand block is staged as three bf16 term
+// BN (round 6): the numerators on the bf16 pipe (see hyb_pack_hi / hyb_trunc_rest above): the second product's operand block is staged as bf16 term
 // planes per block of 16 signals, loop steps contiguous ([term][k-lane group g][signal][4 steps] = 8 bytes per lane).
 template <int NB, int NT, int MODE, bool BN = false>
 __global__ __launch_bounds__(512, 2) void wide2_step_kernel(char *arena, const float *__restrict__ Xt, const NmfkRun *__restrict__ runs,
